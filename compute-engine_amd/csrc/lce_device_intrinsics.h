@@ -1,0 +1,91 @@
+// gfx950 (CDNA4) device intrinsics used by the LCE kernels.
+//
+// Everything ISA-specific that the kernels need is funnelled through this header so
+// that the kernel bodies in lce_kernels.h read as plain index arithmetic.  (The test
+// tree has a lock-step-free host replacement of this one header, tests/hostsim/, which
+// lets the CPU-only test suite execute the very same kernel bodies thread by thread to
+// check their index/padding/epilogue logic; the product is only ever built with this
+// file.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LCE_DEVICE __device__ __forceinline__
+#define LCE_KERNEL __global__
+
+namespace lce_dev {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+LCE_DEVICE int thread_idx_x() { return (int)threadIdx.x; }
+LCE_DEVICE int block_idx_x() { return (int)blockIdx.x; }
+LCE_DEVICE int block_idx_y() { return (int)blockIdx.y; }
+LCE_DEVICE int block_dim_x() { return (int)blockDim.x; }
+LCE_DEVICE int grid_dim_x() { return (int)gridDim.x; }
+
+// Promote a value the programmer knows to be wave-uniform into an SGPR so that the
+// loads indexed by it become scalar (s_load) and the VALU ops take it as an SGPR operand.
+LCE_DEVICE uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+LCE_DEVICE int uniform(int x) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)x); }
+
+// Raw buffer resource over [base, base+bytes): loads whose byte offset falls outside
+// return 0 -- which is exactly the "+1" padding word of the reference
+// (core/bconv2d/reference.h:105-106), so out-of-image taps need no select.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+LCE_DEVICE rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride=*/0, (int)bytes,
+                                           /*flags: DATA_FORMAT=32*/ 0x00020000);
+}
+constexpr uint32_t kOobOffset = 0x80000000u;  // > any num_records we ever bind (< 2 GiB)
+
+LCE_DEVICE uint32_t buf_load(rsrc_t r, uint32_t byte_off, uint32_t*) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0);
+}
+LCE_DEVICE u32x2 buf_load(rsrc_t r, uint32_t byte_off, u32x2*) {
+  return __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+}
+LCE_DEVICE u32x4 buf_load(rsrc_t r, uint32_t byte_off, u32x4*) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
+LCE_DEVICE uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+LCE_DEVICE int popc(uint32_t x) { return __popc(x); }
+LCE_DEVICE bool wave_any(bool p) { return __ballot(p) != 0ull; }
+LCE_DEVICE unsigned long long wave_ballot(bool p) { return __ballot(p); }
+LCE_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
+LCE_DEVICE float round_half_away(float y) { return roundf(y); }  // std::round semantics
+
+// acc_i += popcount(a_i ^ w) for TM independent activations against ONE weight word.
+// Hand-written so that (1) the weight word stays in an SGPR (VOP2 src0), (2) the
+// accumulate is the free addend of v_bcnt_u32_b32 instead of a separate v_add (hipcc
+// re-associates `acc += __popc(..)` chains into bcnt(x,0) + v_add3), and (3) the TM
+// xors are issued ahead of the TM dependent bcnts.
+LCE_DEVICE void xor_popc_acc(int& c0, uint32_t w, uint32_t a0) {
+  uint32_t t0;
+  asm("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0"
+      : "+v"(c0), "=&v"(t0)
+      : "s"(w), "v"(a0));
+}
+LCE_DEVICE void xor_popc_acc(int& c0, int& c1, uint32_t w, uint32_t a0, uint32_t a1) {
+  uint32_t t0, t1;
+  asm("v_xor_b32 %2, %4, %5\n\tv_xor_b32 %3, %4, %6\n\t"
+      "v_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %1, %3, %1"
+      : "+v"(c0), "+v"(c1), "=&v"(t0), "=&v"(t1)
+      : "s"(w), "v"(a0), "v"(a1));
+}
+LCE_DEVICE void xor_popc_acc(int& c0, int& c1, int& c2, int& c3, uint32_t w, uint32_t a0,
+                             uint32_t a1, uint32_t a2, uint32_t a3) {
+  uint32_t t0, t1, t2, t3;
+  asm("v_xor_b32 %4, %8, %9\n\tv_xor_b32 %5, %8, %10\n\t"
+      "v_xor_b32 %6, %8, %11\n\tv_xor_b32 %7, %8, %12\n\t"
+      "v_bcnt_u32_b32 %0, %4, %0\n\tv_bcnt_u32_b32 %1, %5, %1\n\t"
+      "v_bcnt_u32_b32 %2, %6, %2\n\tv_bcnt_u32_b32 %3, %7, %3"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "s"(w), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+}
+
+}  // namespace lce_dev

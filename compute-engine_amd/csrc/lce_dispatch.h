@@ -1,0 +1,52 @@
+// Kernel-instance lookup shared by the C ABI (lce_hip_api.hip) and the host simulation
+// used by the CPU-only tests (tests/hostsim/).
+#pragma once
+#include "../../include/lce_hip.h"
+#include "lce_kernels.h"
+
+namespace lce {
+
+typedef void (*tiled_fn)(const ConvArgs, const uint32_t*, const uint32_t*, const float*,
+                         const float*, const int32_t*, const int32_t*, const float*, void*);
+typedef void (*general_fn)(const ConvArgs, const uint32_t*, const uint32_t*, const float*,
+                           const float*, const int32_t*, const float*, void*);
+
+template <int DST, int TM, int TN>
+tiled_fn tiled_by_ch(int ch) {
+  switch (ch) {
+    case 4: return bconv2d_tiled<DST, TM, TN, 4>;
+    case 2: return bconv2d_tiled<DST, TM, TN, 2>;
+    default: return bconv2d_tiled<DST, TM, TN, 1>;
+  }
+}
+
+template <int DST>
+tiled_fn tiled_by_tile(int tm, int tn, int ch) {
+  if (tm == 2 && tn == 32) return tiled_by_ch<DST, 2, 32>(ch);
+  if (tm == 1 && tn == 32) return tiled_by_ch<DST, 1, 32>(ch);
+  if constexpr (DST != kDstBitpacked) {
+    if (tm == 4 && tn == 16) return tiled_by_ch<DST, 4, 16>(ch);
+    if (tm == 2 && tn == 16) return tiled_by_ch<DST, 2, 16>(ch);
+    if (tm == 1 && tn == 16) return tiled_by_ch<DST, 1, 16>(ch);
+  }
+  return nullptr;
+}
+
+inline tiled_fn find_tiled(int dst, int tm, int tn, int ch) {
+  switch (dst) {
+    case LCE_HIP_F32: return tiled_by_tile<kDstFloat>(tm, tn, ch);
+    case LCE_HIP_I8: return tiled_by_tile<kDstInt8>(tm, tn, ch);
+    default: return tiled_by_tile<kDstBitpacked>(tm, tn, ch);
+  }
+}
+
+inline general_fn find_general(int dst) {
+  switch (dst) {
+    case LCE_HIP_F32: return bconv2d_general<kDstFloat>;
+    case LCE_HIP_I8: return bconv2d_general<kDstInt8>;
+    default: return bconv2d_general<kDstBitpacked>;
+  }
+}
+
+
+}  // namespace lce

@@ -1,0 +1,489 @@
+// C ABI (include/lce_hip.h) over the gfx950 kernels in lce_kernels.h.
+// There is no CPU fallback in this file: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/lce_hip.h"
+#include "lce_kernels.h"
+#include "lce_dispatch.h"
+#include "lce_plan.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+lce_hip_status fail(lce_hip_status code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define LCE_HIP_TRY(expr)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? LCE_HIP_ERR_NO_DEVICE \
+                                                                         : LCE_HIP_ERR_RUNTIME, \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                          \
+  } while (0)
+
+lce_hip_status require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(LCE_HIP_ERR_NO_DEVICE,
+                "no usable HIP device (hipGetDeviceCount: %s, count %d); this library has no CPU "
+                "fallback", hipGetErrorString(e), n);
+  }
+  return LCE_HIP_OK;
+}
+
+unsigned grid_for_stream(uint64_t wave_tasks, int waves_per_block) {
+  // memory-bound streams: cap at ~8 blocks per CU and grid-stride the rest
+  const uint64_t blocks = (wave_tasks + waves_per_block - 1) / waves_per_block;
+  const uint64_t cap = 256ull * 8ull;
+  return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+template <typename T>
+struct DevBuf {
+  T* ptr = nullptr;
+  size_t count = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    release();
+    if (v.empty()) return hipSuccess;
+    // +64 B of slack: the kernels' padded tables are read with wide scalar loads
+    hipError_t e = hipMalloc((void**)&ptr, v.size() * sizeof(T) + 64);
+    if (e != hipSuccess) return e;
+    count = v.size();
+    return hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+};
+
+}  // namespace
+
+struct lce_hip_bconv2d_plan {
+  lce::HostPlan host;
+  bool device_current = false;
+  int64_t selected_for_pixels = -1;
+  DevBuf<uint32_t> d_packed, d_filter;
+  DevBuf<float> d_mul, d_bias, d_zpc;
+  DevBuf<int32_t> d_thr, d_oobc;
+  // staging for run_host
+  void* stage_in = nullptr;
+  void* stage_out = nullptr;
+  size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  ~lce_hip_bconv2d_plan() {
+    if (stage_in) (void)hipFree(stage_in);
+    if (stage_out) (void)hipFree(stage_out);
+  }
+};
+
+namespace {
+
+using lce::ConvArgs;
+using lce::tiled_fn;
+using lce::general_fn;
+using lce::find_tiled;
+using lce::find_general;
+
+size_t out_elem_bytes(int dst) { return dst == LCE_HIP_I8 ? 1 : 4; }
+
+lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
+  lce::HostPlan& h = plan->host;
+  const int64_t pixels = (int64_t)batch_chunk * h.out_h * h.out_w;
+  if (plan->selected_for_pixels == pixels && !h.kernel_name.empty() &&
+      (!h.use_tiled || !h.packed.empty() || !h.have_weights))
+    return LCE_HIP_OK;
+  const std::string err = lce::select_kernel(h, pixels);
+  if (!err.empty()) return fail(LCE_HIP_ERR_UNSUPPORTED, "%s", err.c_str());
+  plan->selected_for_pixels = pixels;
+  plan->device_current = false;
+  return LCE_HIP_OK;
+}
+
+lce_hip_status ensure_uploaded(lce_hip_bconv2d_plan* plan) {
+  if (plan->device_current) return LCE_HIP_OK;
+  lce::HostPlan& h = plan->host;
+  if (h.use_tiled) {
+    LCE_HIP_TRY(plan->d_packed.upload(h.packed));
+    LCE_HIP_TRY(plan->d_mul.upload(h.mul_p));
+    LCE_HIP_TRY(plan->d_bias.upload(h.bias_p));
+    LCE_HIP_TRY(plan->d_thr.upload(h.thr_p));
+    LCE_HIP_TRY(plan->d_oobc.upload(h.oob_corr));
+    plan->d_filter.release();
+  } else {
+    LCE_HIP_TRY(plan->d_filter.upload(h.filter));
+    LCE_HIP_TRY(plan->d_mul.upload(h.mul));
+    LCE_HIP_TRY(plan->d_bias.upload(h.bias));
+    LCE_HIP_TRY(plan->d_thr.upload(h.thresholds));
+    plan->d_packed.release();
+    plan->d_oobc.release();
+  }
+  LCE_HIP_TRY(plan->d_zpc.upload(h.zero_pad_cache));
+  plan->device_current = true;
+  return LCE_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lce_hip_abi_version(void) { return LCE_HIP_ABI_VERSION; }
+const char* lce_hip_last_error(void) { return g_last_error.c_str(); }
+
+int lce_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+lce_hip_status lce_hip_set_device(int device) {
+  if (lce_hip_status s = require_device()) return s;
+  LCE_HIP_TRY(hipSetDevice(device));
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_malloc(void** dev_ptr, size_t bytes) {
+  if (!dev_ptr) return fail(LCE_HIP_ERR_INVALID, "lce_hip_malloc: null out pointer");
+  if (lce_hip_status s = require_device()) return s;
+  LCE_HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_free(void* dev_ptr) {
+  if (dev_ptr) LCE_HIP_TRY(hipFree(dev_ptr));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  LCE_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  LCE_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_memset(void* dst, int value, size_t bytes, void* stream) {
+  LCE_HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_stream_create(void** stream) {
+  if (!stream) return fail(LCE_HIP_ERR_INVALID, "lce_hip_stream_create: null out pointer");
+  if (lce_hip_status s = require_device()) return s;
+  hipStream_t st;
+  LCE_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = (void*)st;
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_stream_destroy(void* stream) {
+  if (stream) LCE_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_stream_synchronize(void* stream) {
+  LCE_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+
+int32_t lce_hip_bitpacked_size(int32_t n) { return (n + 31) / 32; }
+
+// ------------------------------------------------------------------------------------
+// LceQuantize / LceDequantize
+// ------------------------------------------------------------------------------------
+static lce_hip_status launch_bitpack_rows(lce_hip_dtype in_type, const void* in_dev, uint64_t rows,
+                                          uint64_t cols, int32_t zero_point, uint32_t* out_dev,
+                                          hipStream_t st) {
+  const uint32_t wpr = (uint32_t)((cols + 31) / 32);
+  const uint32_t segs = (uint32_t)((cols + 63) / 64);
+  const uint64_t tasks = rows * segs;
+  const unsigned grid = grid_for_stream(tasks, 4);
+  const lce::FastDiv dv = lce::make_fastdiv(segs);
+  if (in_type == LCE_HIP_F32)
+    lce::bitpack_rows<float><<<grid, 256, 0, st>>>((const float*)in_dev, out_dev, (uint32_t)rows, (uint32_t)cols, wpr, 0, dv, segs, tasks);
+  else if (in_type == LCE_HIP_I8)
+    lce::bitpack_rows<int8_t><<<grid, 256, 0, st>>>((const int8_t*)in_dev, out_dev, (uint32_t)rows, (uint32_t)cols, wpr, zero_point, dv, segs, tasks);
+  else
+    lce::bitpack_rows<uint8_t><<<grid, 256, 0, st>>>((const uint8_t*)in_dev, out_dev, (uint32_t)rows, (uint32_t)cols, wpr, zero_point, dv, segs, tasks);
+  LCE_HIP_TRY(hipGetLastError());
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bitpack(lce_hip_dtype in_type, const void* in_dev, size_t rows, size_t cols,
+                               int32_t zero_point, int32_t* out_dev, void* stream) {
+  if (in_type != LCE_HIP_F32 && in_type != LCE_HIP_I8 && in_type != LCE_HIP_BOOL)
+    return fail(LCE_HIP_ERR_INVALID, "lce_hip_bitpack: input type must be float32, int8 or bool");
+  if (in_type == LCE_HIP_F32 && zero_point != 0)
+    return fail(LCE_HIP_ERR_INVALID, "lce_hip_bitpack: float input requires zero_point 0");
+  if (rows == 0 || cols == 0) return LCE_HIP_OK;
+  if (!in_dev || !out_dev) return fail(LCE_HIP_ERR_INVALID, "lce_hip_bitpack: null tensor");
+  if (cols >= (1ull << 31) || rows >= (1ull << 32))
+    return fail(LCE_HIP_ERR_UNSUPPORTED, "lce_hip_bitpack: tensor too large");
+  if (lce_hip_status s = require_device()) return s;
+  hipStream_t st = (hipStream_t)stream;
+  if (in_type == LCE_HIP_BOOL) zero_point = 1;  // quantization.cc:86-108
+  const size_t esz = in_type == LCE_HIP_F32 ? 4 : 1;
+  const uint64_t wpr = (cols + 31) / 32;
+  const uint64_t total_words = (uint64_t)rows * wpr;
+  const bool flat = cols % 32 == 0 && ((uintptr_t)in_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0);
+  if (!flat || total_words < 32)
+    return launch_bitpack_rows(in_type, in_dev, rows, cols, zero_point, (uint32_t*)out_dev, st);
+  // bitpack.h:294-298: no per-row padding -> the tensor is one flat array; 32 words per wave step
+  const uint64_t blocks32 = total_words / 32;
+  const unsigned grid = grid_for_stream(blocks32, 4);
+  if (in_type == LCE_HIP_F32)
+    lce::bitpack_f32_flat<<<grid, 256, 0, st>>>((const float*)in_dev, (uint32_t*)out_dev, blocks32);
+  else if (in_type == LCE_HIP_I8)
+    lce::bitpack_b8_flat<false><<<grid, 256, 0, st>>>((const uint8_t*)in_dev, (uint32_t*)out_dev, blocks32, zero_point);
+  else
+    lce::bitpack_b8_flat<true><<<grid, 256, 0, st>>>((const uint8_t*)in_dev, (uint32_t*)out_dev, blocks32, zero_point);
+  LCE_HIP_TRY(hipGetLastError());
+  const uint64_t done_words = blocks32 * 32;
+  if (done_words == total_words) return LCE_HIP_OK;
+  // fewer than 32 words left: one ragged "row" of the flat array
+  return launch_bitpack_rows(in_type, (const char*)in_dev + done_words * 32 * esz, 1,
+                             (total_words - done_words) * 32, zero_point,
+                             (uint32_t*)out_dev + done_words, st);
+}
+
+lce_hip_status lce_hip_unpack(lce_hip_dtype out_type, const int32_t* in_dev, size_t rows, size_t cols,
+                              float scale, int32_t zero_point, void* out_dev, void* stream) {
+  if (out_type != LCE_HIP_F32 && out_type != LCE_HIP_I8 && out_type != LCE_HIP_BOOL)
+    return fail(LCE_HIP_ERR_INVALID, "lce_hip_unpack: output type must be float32, int8 or bool");
+  if (rows == 0 || cols == 0) return LCE_HIP_OK;
+  if (!in_dev || !out_dev) return fail(LCE_HIP_ERR_INVALID, "lce_hip_unpack: null tensor");
+  if (cols >= (1ull << 31)) return fail(LCE_HIP_ERR_UNSUPPORTED, "lce_hip_unpack: cols too large");
+  if (lce_hip_status s = require_device()) return s;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t wpr = (uint32_t)((cols + 31) / 32);
+  const uint64_t total = (uint64_t)rows * cols;
+  const unsigned grid = grid_for_stream((total + 63) / 64, 4);
+  if (out_type == LCE_HIP_F32) {
+    lce::unpack_rows<float><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (float*)out_dev, total, (uint32_t)cols, wpr, 1.0f, -1.0f);
+  } else if (out_type == LCE_HIP_I8) {
+    // quantization.cc:131-138
+    if (!(scale > 0.0f)) return fail(LCE_HIP_ERR_INVALID, "lce_hip_unpack: int8 output needs a positive scale");
+    const int offset = (int)std::round(1.0f / scale);
+    const int zero_bit = std::min(127, zero_point + offset);
+    const int one_bit = std::max(-128, zero_point - offset);
+    lce::unpack_rows<int8_t><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (int8_t*)out_dev, total, (uint32_t)cols, wpr, (int8_t)zero_bit, (int8_t)one_bit);
+  } else {
+    lce::unpack_rows<uint8_t><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (uint8_t*)out_dev, total, (uint32_t)cols, wpr, (uint8_t)1, (uint8_t)0);
+  }
+  LCE_HIP_TRY(hipGetLastError());
+  return LCE_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// LceBconv2d
+// ------------------------------------------------------------------------------------
+lce_hip_status lce_hip_bconv2d_plan_create(const lce_hip_bconv2d_desc* desc, lce_hip_bconv2d_plan** plan) {
+  if (!desc || !plan) return fail(LCE_HIP_ERR_INVALID, "lce_hip_bconv2d_plan_create: null argument");
+  lce_hip_bconv2d_plan* p = new lce_hip_bconv2d_plan();
+  p->host.d = *desc;
+  const std::string err = lce::validate_and_infer(p->host);
+  if (!err.empty()) {
+    delete p;
+    *plan = nullptr;
+    return fail(LCE_HIP_ERR_INVALID, "%s", err.c_str());
+  }
+  *plan = p;
+  return LCE_HIP_OK;
+}
+
+void lce_hip_bconv2d_plan_destroy(lce_hip_bconv2d_plan* plan) { delete plan; }
+
+lce_hip_status lce_hip_bconv2d_plan_output_shape(const lce_hip_bconv2d_plan* plan, int32_t dims[4]) {
+  if (!plan || !dims) return fail(LCE_HIP_ERR_INVALID, "plan_output_shape: null argument");
+  const lce::HostPlan& h = plan->host;
+  dims[0] = h.d.batch;
+  dims[1] = h.out_h;
+  dims[2] = h.out_w;
+  dims[3] = h.d.dst_type == LCE_HIP_BITPACKED ? h.wout : h.d.channels_out;
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bconv2d_plan_padding(const lce_hip_bconv2d_plan* plan, int32_t* pad_h, int32_t* pad_w) {
+  if (!plan || !pad_h || !pad_w) return fail(LCE_HIP_ERR_INVALID, "plan_padding: null argument");
+  *pad_h = plan->host.pad_h;
+  *pad_w = plan->host.pad_w;
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bconv2d_plan_set_weights(lce_hip_bconv2d_plan* plan, const int32_t* filter,
+                                                const float* post_mul, const float* post_bias,
+                                                const int32_t* thresholds) {
+  if (!plan || !filter) return fail(LCE_HIP_ERR_INVALID, "plan_set_weights: null plan or filter");
+  const bool bp = plan->host.d.dst_type == LCE_HIP_BITPACKED;
+  if (bp && !thresholds) return fail(LCE_HIP_ERR_INVALID, "plan_set_weights: bitpacked output needs thresholds");
+  if (!bp && (!post_mul || !post_bias))
+    return fail(LCE_HIP_ERR_INVALID, "plan_set_weights: float/int8 output needs post_activation_multiplier and _bias");
+  lce::fold_parameters(plan->host, filter, post_mul, post_bias, thresholds);
+  plan->device_current = false;
+  plan->selected_for_pixels = -1;
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, float* mul, float* bias,
+                                           int32_t* clamp_min, int32_t* clamp_max) {
+  if (!plan) return fail(LCE_HIP_ERR_INVALID, "plan_folded: null plan");
+  const lce::HostPlan& h = plan->host;
+  if (!h.have_weights || h.d.dst_type == LCE_HIP_BITPACKED)
+    return fail(LCE_HIP_ERR_INVALID, "plan_folded: no folded float transform on this plan");
+  if (mul) memcpy(mul, h.mul.data(), h.mul.size() * sizeof(float));
+  if (bias) memcpy(bias, h.bias.data(), h.bias.size() * sizeof(float));
+  if (clamp_min) *clamp_min = h.clamp_min;
+  if (clamp_max) *clamp_max = h.clamp_max;
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key, const char* value) {
+  if (!plan || !key || !value) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: null argument");
+  lce::HostPlan& h = plan->host;
+  if (!strcmp(key, "kernel")) {
+    if (!strcmp(value, "auto")) h.kernel_pref = 0;
+    else if (!strcmp(value, "tiled")) h.kernel_pref = 1;
+    else if (!strcmp(value, "general")) h.kernel_pref = 2;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: kernel must be auto|tiled|general");
+  } else if (!strcmp(key, "tile")) {
+    int tm = 0, tn = 0;
+    if (!strcmp(value, "auto")) { h.tile_pref = lce::TileShape{0, 0}; }
+    else if (sscanf(value, "%dx%d", &tm, &tn) == 2 && (tm == 1 || tm == 2 || tm == 4) &&
+             (tn == 16 || tn == 32) && !(tm == 4 && tn == 32)) { h.tile_pref = lce::TileShape{tm, tn}; }
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: tile must be auto|4x16|2x32|2x16|1x32|1x16");
+  } else {
+    return fail(LCE_HIP_ERR_INVALID, "plan_set_option: unknown key '%s'", key);
+  }
+  plan->selected_for_pixels = -1;
+  plan->device_current = false;
+  h.packed.clear();
+  return LCE_HIP_OK;
+}
+
+const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan) {
+  if (!plan) return "";
+  const int chunk = lce::max_batch_per_launch(plan->host);
+  if (ensure_selected(plan, chunk) != LCE_HIP_OK) return "";
+  return plan->host.kernel_name.c_str();
+}
+
+lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, void* output_dev, void* stream) {
+  if (!plan || !input_dev || !output_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: null argument");
+  lce::HostPlan& h = plan->host;
+  if (!h.have_weights) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: plan_set_weights was not called");
+  if (lce_hip_status s = require_device()) return s;
+  const int chunk = lce::max_batch_per_launch(h);
+  if (lce_hip_status s = ensure_selected(plan, chunk)) return s;
+  if (lce_hip_status s = ensure_uploaded(plan)) return s;
+  hipStream_t st = (hipStream_t)stream;
+
+  const size_t in_img_words = (size_t)h.d.in_height * h.d.in_width * h.cw;
+  const size_t out_row = h.d.dst_type == LCE_HIP_BITPACKED ? (size_t)h.wout : (size_t)h.d.channels_out;
+  const size_t out_img_bytes = (size_t)h.out_h * h.out_w * out_row * out_elem_bytes(h.d.dst_type);
+
+  for (int b0 = 0; b0 < h.d.batch; b0 += chunk) {
+    const int nb = std::min(chunk, h.d.batch - b0);
+    ConvArgs A = lce::make_conv_args(h, nb);
+    const uint32_t* in = (const uint32_t*)input_dev + (size_t)b0 * in_img_words;
+    void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
+    if (h.use_tiled) {
+      tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
+      if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
+      const int64_t tasks = (int64_t)A.PT * A.NT;
+      const int wpb = 4;
+      const unsigned grid = (unsigned)((tasks + wpb - 1) / wpb);
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * wpb), 0, st, A, in, plan->d_packed.ptr,
+                         plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thr.ptr, plan->d_oobc.ptr,
+                         plan->d_zpc.ptr, out);
+    } else {
+      general_fn fn = find_general(h.d.dst_type);
+      const unsigned gx = (unsigned)((A.M + 255) / 256);
+      const unsigned gy = (unsigned)((h.d.channels_out + 31) / 32);
+      hipLaunchKernelGGL(fn, dim3(gx, gy), dim3(256), 0, st, A, in, plan->d_filter.ptr,
+                         plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thr.ptr, plan->d_zpc.ptr, out);
+    }
+    LCE_HIP_TRY(hipGetLastError());
+  }
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bconv2d_run_host(lce_hip_bconv2d_plan* plan, const int32_t* input_host, void* output_host) {
+  if (!plan || !input_host || !output_host) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_host: null argument");
+  if (lce_hip_status s = require_device()) return s;
+  const lce::HostPlan& h = plan->host;
+  const size_t in_bytes = (size_t)h.d.batch * h.d.in_height * h.d.in_width * h.cw * 4;
+  const size_t out_row = h.d.dst_type == LCE_HIP_BITPACKED ? (size_t)h.wout : (size_t)h.d.channels_out;
+  const size_t out_bytes = (size_t)h.d.batch * h.out_h * h.out_w * out_row * out_elem_bytes(h.d.dst_type);
+  if (plan->stage_in_bytes < in_bytes) {
+    if (plan->stage_in) (void)hipFree(plan->stage_in);
+    plan->stage_in = nullptr;
+    LCE_HIP_TRY(hipMalloc(&plan->stage_in, in_bytes));
+    plan->stage_in_bytes = in_bytes;
+  }
+  if (plan->stage_out_bytes < out_bytes) {
+    if (plan->stage_out) (void)hipFree(plan->stage_out);
+    plan->stage_out = nullptr;
+    LCE_HIP_TRY(hipMalloc(&plan->stage_out, out_bytes));
+    plan->stage_out_bytes = out_bytes;
+  }
+  LCE_HIP_TRY(hipMemcpy(plan->stage_in, input_host, in_bytes, hipMemcpyHostToDevice));
+  if (lce_hip_status s = lce_hip_bconv2d_run(plan, (const int32_t*)plan->stage_in, plan->stage_out, nullptr)) return s;
+  LCE_HIP_TRY(hipMemcpy(output_host, plan->stage_out, out_bytes, hipMemcpyDeviceToHost));
+  return LCE_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// LceBMaxPool2d
+// ------------------------------------------------------------------------------------
+static int pool_out(int padding, int in, int filter, int stride) {
+  if (stride == 0) return 0;
+  return padding == LCE_HIP_PADDING_SAME ? (in + stride - 1) / stride : (in + stride - filter) / stride;
+}
+
+lce_hip_status lce_hip_bmaxpool_output_shape(int32_t in_h, int32_t in_w, int32_t fh, int32_t fw, int32_t sh,
+                                             int32_t sw, int32_t padding, int32_t* out_h, int32_t* out_w) {
+  if (!out_h || !out_w) return fail(LCE_HIP_ERR_INVALID, "bmaxpool_output_shape: null argument");
+  if (sh == 0 || sw == 0 || fh == 0 || fw == 0)
+    return fail(LCE_HIP_ERR_INVALID, "bmaxpool: strides and filter sizes must be non-zero");  // bmaxpool.cc:52-55
+  if (padding != LCE_HIP_PADDING_SAME && padding != LCE_HIP_PADDING_VALID)
+    return fail(LCE_HIP_ERR_INVALID, "bmaxpool: padding must be SAME or VALID");
+  *out_h = pool_out(padding, in_h, fh, sh);
+  *out_w = pool_out(padding, in_w, fw, sw);
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t in_h, int32_t in_w,
+                                int32_t words, int32_t fh, int32_t fw, int32_t sh, int32_t sw,
+                                int32_t padding, int32_t* output_dev, void* stream) {
+  int32_t oh = 0, ow = 0;
+  if (lce_hip_status s = lce_hip_bmaxpool_output_shape(in_h, in_w, fh, fw, sh, sw, padding, &oh, &ow)) return s;
+  if (!input_dev || !output_dev) return fail(LCE_HIP_ERR_INVALID, "bmaxpool: null tensor");
+  if (oh < 1 || ow < 1 || batch < 1 || words < 1) return fail(LCE_HIP_ERR_INVALID, "bmaxpool: empty tensor");
+  if (lce_hip_status s = require_device()) return s;
+  const int ph = std::max(0, (oh - 1) * sh + fh - in_h) / 2;
+  const int pw = std::max(0, (ow - 1) * sw + fw - in_w) / 2;
+  const uint64_t total = (uint64_t)batch * oh * ow * words;
+  const unsigned grid = grid_for_stream((total + 63) / 64, 4);
+  lce::bmaxpool_words<<<grid, 256, 0, (hipStream_t)stream>>>((const uint32_t*)input_dev, (uint32_t*)output_dev, batch, in_h, in_w,
+                                                              words, oh, ow, fh, fw, sh, sw, ph, pw, total);
+  LCE_HIP_TRY(hipGetLastError());
+  return LCE_HIP_OK;
+}
+
+}  // extern "C"

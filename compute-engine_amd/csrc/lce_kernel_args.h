@@ -1,0 +1,59 @@
+// Plain-old-data launch descriptors shared by the host planner (lce_plan.cpp) and the
+// device kernels (lce_kernels.h).  No HIP types here: this header is also compiled by
+// plain g++ for the host-side planner tests.
+#pragma once
+#include <stdint.h>
+
+namespace lce {
+
+// Destination types of LceBconv2d (tflite/kernels/bconv2d.cc:550-564).
+enum : int { kDstFloat = 0, kDstInt8 = 1, kDstBitpacked = 2 };
+
+// How SAME padding with pad_values == 0 is realised.
+enum : int {
+  kZeroPadNone = 0,        // VALID, or SAME with pad_values == 1 (out-of-image word = 0 = +1)
+  kZeroPadExact = 1,       // reference kernel: accum += (Cin/G)/2 per outside tap (reference.h:76-103)
+  kZeroPadCorrection = 2,  // optimized kernels: one-padded conv, float correction after the
+                           // output transform (zero_padding_correction.h:178-297)
+};
+
+// Unsigned division of n < 2^31 by a launch-constant d via one v_mul_hi + shift
+// (q = mulhi(n, magic) >> shift; d == 1 is flagged by magic == 0).
+struct FastDiv {
+  uint32_t magic;
+  uint32_t shift;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{0u, 0u};
+  if (d <= 1) return f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;  // l = ceil(log2 d) >= 1
+  const uint64_t two = 1ull << (31 + l);
+  f.magic = (uint32_t)((two + d - 1) / d);  // ceil(2^(31+l) / d) < 2^32
+  f.shift = l - 1;
+  return f;
+}
+
+struct ConvArgs {
+  // geometry of this launch
+  int32_t H, W;        // input height / width
+  int32_t Cw, Cwg;     // bitpacked words per input pixel: all groups / one group
+  int32_t OH, OW;      // output height / width
+  int32_t N, Npg;      // output channels: total / per group
+  int32_t KH, KW, SH, SW, DH, DW, PH, PW;
+  int32_t M;           // output pixels of this launch = batch * OH * OW
+  int32_t PT, NT;      // fast kernel: pixel tiles (64*TM pixels each), channel tiles (TN each)
+  int32_t Wout;        // bitpacked output words per pixel = ceil(N / 32)
+  uint32_t in_bytes;   // bytes bound to the input buffer resource (< 2^31)
+  FastDiv div_ow, div_oh;
+  // output transform (core/bconv2d/output_transform.h)
+  int32_t clamp_min, clamp_max;
+  // SAME-zero padding
+  int32_t zero_pad_mode;   // kZeroPad*
+  int32_t bzp;             // (Cin/G)/2, reference.h:76-77
+  int32_t eKH, eKW;        // effective (dilated) filter extent
+  int32_t left_off, top_off;  // zero_padding_correction.h:189-194
+};
+
+}  // namespace lce

@@ -1,0 +1,297 @@
+// Host-side planner for LceBconv2d on MI355X (see lce_plan.h).
+// Citations are relative to /root/reference/larq_compute_engine/.
+#include "lce_plan.h"
+
+#include <limits.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cstdio>
+
+namespace lce {
+
+static int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// TFLite ComputeOutSize / ComputePaddingWithOffset (tensorflow v2.16.1
+// tensorflow/lite/kernels/padding.h; third-party, restated from its published
+// definition -- the reference calls it at tflite/kernels/bconv2d.cc:203-210).
+static int out_size(int padding, int image, int filter, int stride, int dilation) {
+  const int eff = (filter - 1) * dilation + 1;
+  if (stride == 0) return 0;
+  if (padding == LCE_HIP_PADDING_SAME) return (image + stride - 1) / stride;
+  if (padding == LCE_HIP_PADDING_VALID) return (image + stride - eff) / stride;
+  return 0;
+}
+static int pad_before(int stride, int dilation, int in, int filter, int out) {
+  const int eff = (filter - 1) * dilation + 1;
+  const int total = std::max(0, (out - 1) * stride + eff - in);
+  return total / 2;
+}
+
+std::string validate_and_infer(HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  char buf[256];
+  if (d.batch < 1 || d.in_height < 1 || d.in_width < 1 || d.channels_in < 1 ||
+      d.filter_height < 1 || d.filter_width < 1 || d.channels_out < 1)
+    return "bconv2d: all tensor dimensions must be positive";
+  if (d.stride_height < 1 || d.stride_width < 1 || d.dilation_height < 1 || d.dilation_width < 1)
+    return "bconv2d: strides and dilations must be positive";
+  if (d.padding != LCE_HIP_PADDING_SAME && d.padding != LCE_HIP_PADDING_VALID)
+    return "bconv2d: padding must be SAME or VALID";
+  if (d.pad_values != 0 && d.pad_values != 1)
+    return "Attribute pad_values must be 0 or 1.";  // bconv2d.cc:109-112
+  if (d.activation < LCE_HIP_ACT_NONE || d.activation > LCE_HIP_ACT_RELU6)
+    return "bconv2d: unsupported fused activation";
+  if (d.dst_type != LCE_HIP_F32 && d.dst_type != LCE_HIP_I8 && d.dst_type != LCE_HIP_BITPACKED)
+    return "Supported output types are int8, int32, and float32.";  // bconv2d.cc:158-162
+  if (d.groups < 1) return "bconv2d: groups must be >= 1";
+  if (d.groups > 1) {
+    // bconv2d.cc:173-185
+    if (d.channels_in % d.groups) return "bconv2d: channels_in must be divisible by groups";
+    if ((d.channels_in / d.groups) % 32)
+      return "bconv2d: group_size % core::bitpacking_bitwidth was not 0";
+    if (d.channels_out % d.groups) return "bconv2d: channels_out % groups was not 0";
+  }
+  if (d.padding == LCE_HIP_PADDING_SAME && d.pad_values == 0) {
+    // bconv2d.cc:188-200
+    const bool ok = (d.semantics == LCE_HIP_SEM_REFERENCE && d.channels_in % 2 == 0) ||
+                    (d.semantics != LCE_HIP_SEM_REFERENCE && d.dst_type == LCE_HIP_F32 &&
+                     d.activation == LCE_HIP_ACT_NONE);
+    if (!ok)
+      return "Zero-padding is only supported by the reference kernel with an even number of "
+             "input channels, or when using float output with no fused activation function.";
+  }
+  if (d.dst_type == LCE_HIP_I8 && !(d.out_scale > 0.0f))
+    return "bconv2d: int8 output needs a positive output scale";
+
+  p.out_h = out_size(d.padding, d.in_height, d.filter_height, d.stride_height, d.dilation_height);
+  p.out_w = out_size(d.padding, d.in_width, d.filter_width, d.stride_width, d.dilation_width);
+  if (p.out_h < 1 || p.out_w < 1) {
+    snprintf(buf, sizeof buf, "bconv2d: empty output (%d x %d)", p.out_h, p.out_w);
+    return buf;
+  }
+  p.pad_h = pad_before(d.stride_height, d.dilation_height, d.in_height, d.filter_height, p.out_h);
+  p.pad_w = pad_before(d.stride_width, d.dilation_width, d.in_width, d.filter_width, p.out_w);
+  p.cw = ceil_div(d.channels_in, 32);
+  p.cwg = ceil_div(d.channels_in / d.groups, 32);
+  p.npg = d.channels_out / d.groups;
+  p.wout = ceil_div(d.channels_out, 32);
+  p.backtransform_add = d.filter_height * d.filter_width * (d.channels_in / d.groups);
+  p.zero_pad_mode = kZeroPadNone;
+  if (d.padding == LCE_HIP_PADDING_SAME && d.pad_values == 0)
+    p.zero_pad_mode = d.semantics == LCE_HIP_SEM_REFERENCE ? kZeroPadExact : kZeroPadCorrection;
+  const int64_t per_image_bytes = (int64_t)d.in_height * d.in_width * p.cw * 4;
+  if (per_image_bytes >= (1ll << 31)) return "bconv2d: one input image must be smaller than 2 GiB";
+  if ((int64_t)p.out_h * p.out_w >= (1ll << 31)) return "bconv2d: output plane too large";
+  return "";
+}
+
+static int popcount32(uint32_t x) { return __builtin_popcount(x); }
+
+// core/bconv2d/zero_padding_correction.h:39-176
+static void fill_zero_pad_cache(HostPlan& p, const float* post_mul) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const int ew = (d.filter_width - 1) * d.dilation_width + 1;
+  const int eh = (d.filter_height - 1) * d.dilation_height + 1;
+  const int cin_g = d.channels_in / d.groups;
+  const int n = d.channels_out;
+  p.zero_pad_cache.assign((size_t)4 * eh * ew * n, 0.0f);
+  // value of every filter tap as a +-1 sum: Cin_g - 2*popcount (:124-125)
+  std::vector<float> tap_val((size_t)n * d.filter_height * d.filter_width);
+  for (int oc = 0; oc < n; ++oc)
+    for (int t = 0; t < d.filter_height * d.filter_width; ++t) {
+      int pop = 0;
+      const uint32_t* w = &p.filter[((size_t)oc * d.filter_height * d.filter_width + t) * p.cwg];
+      for (int k = 0; k < p.cwg; ++k) pop += popcount32(w[k]);
+      tap_val[(size_t)oc * d.filter_height * d.filter_width + t] = (float)(cin_g - 2 * pop);
+    }
+  for (int y = 0; y < eh; ++y)
+    for (int x = 0; x < ew; ++x)
+      for (int oc = 0; oc < n; ++oc) {
+        float corr[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int fy = 0; fy < d.filter_height; ++fy)
+          for (int fx = 0; fx < d.filter_width; ++fx) {
+            const float cur = tap_val[((size_t)oc * d.filter_height + fy) * d.filter_width + fx];
+            const int efx = d.dilation_width * fx, efy = d.dilation_height * fy;
+            const bool top = efy < y, bot = (eh - efy) <= y;
+            const bool left = efx < x, right = (ew - efx) <= x;
+            if (top || left) corr[0] += cur;
+            if (top || right) corr[1] += cur;
+            if (bot || left) corr[2] += cur;
+            if (bot || right) corr[3] += cur;
+          }
+        const float m = -1.0f * post_mul[oc];
+        for (int k = 0; k < 4; ++k)
+          p.zero_pad_cache[(((size_t)k * eh + y) * ew + x) * n + oc] = m * corr[k];
+      }
+}
+
+void fold_parameters(HostPlan& p, const int32_t* filter_ohwi, const float* post_mul,
+                     const float* post_bias, const int32_t* thresholds) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const int n = d.channels_out;
+  const size_t fwords = (size_t)n * d.filter_height * d.filter_width * p.cwg;
+  p.filter.assign((const uint32_t*)filter_ohwi, (const uint32_t*)filter_ohwi + fwords);
+  p.mul.clear();
+  p.bias.clear();
+  p.thresholds.clear();
+  p.zero_pad_cache.clear();
+  if (d.dst_type == LCE_HIP_BITPACKED) {
+    p.thresholds.assign(thresholds, thresholds + n);
+  } else {
+    // bconv2d.cc:364-378 -- double arithmetic, stored as float
+    const double scale = d.dst_type == LCE_HIP_I8 ? (double)d.out_scale : 1.0;
+    const double zp = d.dst_type == LCE_HIP_I8 ? (double)d.out_zero_point : 0.0;
+    const double a = (double)p.backtransform_add;
+    p.mul.resize(n);
+    p.bias.resize(n);
+    for (int i = 0; i < n; ++i) {
+      const double m = post_mul[i], b = post_bias[i];
+      p.mul[i] = (float)(-1 * m / scale);
+      p.bias[i] = (float)((b + a * m) / scale + zp);
+    }
+    // CalculateActivationRange<int32> then bconv2d.cc:380-388
+    int32_t lo = INT32_MIN, hi = INT32_MAX;
+    switch (d.activation) {
+      case LCE_HIP_ACT_RELU: lo = 0; break;
+      case LCE_HIP_ACT_RELU6: lo = 0; hi = 6; break;
+      case LCE_HIP_ACT_RELU_N1_TO_1: lo = -1; hi = 1; break;
+      default: break;
+    }
+    lo = std::max(lo, -p.backtransform_add);
+    hi = std::min(hi, p.backtransform_add);
+    p.clamp_min = -hi + p.backtransform_add;
+    p.clamp_max = -lo + p.backtransform_add;
+    if (p.zero_pad_mode == kZeroPadCorrection) fill_zero_pad_cache(p, post_mul);
+  }
+  p.have_weights = true;
+  p.packed.clear();  // force a repack on the next select_kernel
+}
+
+bool tiled_supports(const HostPlan& p, int tn) {
+  if (p.d.dst_type == LCE_HIP_BITPACKED && tn != 32) return false;
+  if (p.d.groups > 1 && p.npg % tn != 0) return false;  // a tile must not straddle groups
+  return true;
+}
+
+static void pack_for_tile(HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const int tn = p.tile.tn, taps = d.filter_height * d.filter_width, n = d.channels_out;
+  p.nt = ceil_div(n, tn);
+  p.packed.assign((size_t)p.nt * taps * p.cwg * tn, 0u);
+  p.oob_corr.assign((size_t)p.nt * taps * tn, 0);
+  const int bzp = (d.channels_in / d.groups) / 2;
+  for (int oc = 0; oc < n; ++oc) {
+    const int t_idx = oc / tn, j = oc % tn;
+    for (int t = 0; t < taps; ++t) {
+      int pop = 0;
+      for (int c = 0; c < p.cwg; ++c) {
+        const uint32_t w = p.filter[((size_t)oc * taps + t) * p.cwg + c];
+        p.packed[(((size_t)t_idx * taps + t) * p.cwg + c) * tn + j] = w;
+        pop += popcount32(w);
+      }
+      p.oob_corr[((size_t)t_idx * taps + t) * tn + j] = bzp - pop;
+    }
+  }
+  const size_t padded = (size_t)p.nt * tn;
+  p.mul_p.assign(padded, 0.0f);
+  p.bias_p.assign(padded, 0.0f);
+  p.thr_p.assign(padded, INT32_MAX);  // padded channels never set a bit
+  std::copy(p.mul.begin(), p.mul.end(), p.mul_p.begin());
+  std::copy(p.bias.begin(), p.bias.end(), p.bias_p.begin());
+  std::copy(p.thresholds.begin(), p.thresholds.end(), p.thr_p.begin());
+}
+
+std::string select_kernel(HostPlan& p, int64_t pixels) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const bool bp = d.dst_type == LCE_HIP_BITPACKED;
+  p.ch = (p.cwg % 4 == 0) ? 4 : (p.cwg % 2 == 0) ? 2 : 1;
+
+  TileShape chosen{0, 0};
+  if (p.kernel_pref != 2) {
+    if (p.tile_pref.tm != 0) {
+      if (tiled_supports(p, p.tile_pref.tn)) chosen = p.tile_pref;
+      else if (p.kernel_pref == 1) return "bconv2d: the requested tile cannot run this convolution";
+    } else {
+      // One wave task = 64*TM pixels x TN channels.  Keep the per-lane accumulator tile
+      // as large as possible (fewer activation re-reads, better VALU density) while
+      // still producing enough tasks to fill 256 CUs x 4 SIMDs with several waves each.
+      const int64_t want_tasks = 256 * 4 * 4;
+      const TileShape order_f[] = {{4, 16}, {2, 32}, {2, 16}, {1, 32}, {1, 16}};
+      const TileShape order_b[] = {{2, 32}, {1, 32}};
+      const TileShape* order = bp ? order_b : order_f;
+      const int count = bp ? 2 : 5;
+      for (int k = 0; k < count && chosen.tm == 0; ++k) {
+        const TileShape t = order[k];
+        if (!tiled_supports(p, t.tn)) continue;
+        const int64_t tasks = ((pixels + 64 * t.tm - 1) / (64 * t.tm)) * ceil_div(d.channels_out, t.tn);
+        if (tasks >= want_tasks || k == count - 1) chosen = t;
+      }
+      if (chosen.tm == 0) {  // nothing large enough: take the smallest supported tile
+        for (int k = count - 1; k >= 0 && chosen.tm == 0; --k)
+          if (tiled_supports(p, order[k].tn)) chosen = order[k];
+      }
+    }
+  }
+  if (chosen.tm == 0 && p.kernel_pref == 1)
+    return "bconv2d: the tiled kernel cannot run this convolution (grouped, channels per group "
+           "not a multiple of the tile)";
+
+  const bool tiled = chosen.tm != 0;
+  char name[96];
+  if (tiled) {
+    const bool repack = !p.use_tiled || p.tile.tn != chosen.tn || p.packed.empty();
+    p.use_tiled = true;
+    p.tile = chosen;
+    if (repack && p.have_weights) pack_for_tile(p);
+    p.nt = ceil_div(d.channels_out, chosen.tn);
+    snprintf(name, sizeof name, "bconv2d_tiled<%s,TM=%d,TN=%d,CH=%d>",
+             d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked",
+             chosen.tm, chosen.tn, p.ch);
+  } else {
+    p.use_tiled = false;
+    p.tile = TileShape{0, 0};
+    snprintf(name, sizeof name, "bconv2d_general<%s>",
+             d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked");
+  }
+  p.kernel_name = name;
+  return "";
+}
+
+int max_batch_per_launch(const HostPlan& p) {
+  const int64_t per_image_bytes = (int64_t)p.d.in_height * p.d.in_width * p.cw * 4;
+  const int64_t per_image_pixels = (int64_t)p.out_h * p.out_w;
+  int64_t by_bytes = ((1ll << 31) - 1) / per_image_bytes;
+  int64_t by_pixels = ((1ll << 31) - 64 * 4 - 1) / per_image_pixels;
+  int64_t b = std::min(by_bytes, by_pixels);
+  b = std::max<int64_t>(1, std::min<int64_t>(b, p.d.batch));
+  return (int)b;
+}
+
+ConvArgs make_conv_args(const HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  ConvArgs A{};
+  A.H = d.in_height; A.W = d.in_width; A.Cw = p.cw; A.Cwg = p.cwg;
+  A.OH = p.out_h; A.OW = p.out_w; A.N = d.channels_out; A.Npg = p.npg;
+  A.KH = d.filter_height; A.KW = d.filter_width;
+  A.SH = d.stride_height; A.SW = d.stride_width;
+  A.DH = d.dilation_height; A.DW = d.dilation_width;
+  A.PH = p.pad_h; A.PW = p.pad_w;
+  A.M = batch_chunk * p.out_h * p.out_w;
+  A.NT = p.nt;
+  A.PT = p.use_tiled ? (A.M + 64 * p.tile.tm - 1) / (64 * p.tile.tm) : 0;
+  A.Wout = p.wout;
+  A.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
+  A.div_ow = make_fastdiv((uint32_t)p.out_w);
+  A.div_oh = make_fastdiv((uint32_t)p.out_h);
+  A.clamp_min = p.clamp_min; A.clamp_max = p.clamp_max;
+  A.zero_pad_mode = p.zero_pad_mode;
+  A.bzp = (d.channels_in / d.groups) / 2;
+  A.eKH = (d.filter_height - 1) * d.dilation_height + 1;
+  A.eKW = (d.filter_width - 1) * d.dilation_width + 1;
+  A.left_off = ((p.out_w - 1) * d.stride_width + A.eKW - d.in_width) / 2;   // zero_padding_correction.h:189-191
+  A.top_off = ((p.out_h - 1) * d.stride_height + A.eKH - d.in_height) / 2;  // :192-194
+  return A;
+}
+
+}  // namespace lce

@@ -1,0 +1,72 @@
+// Host-side planner for LceBconv2d on MI355X: validation and shape inference (the work of
+// bconv2d::Prepare), parameter folding (OneTimeSetup), filter repacking and kernel
+// selection.  Pure C++ -- no HIP types -- so it is unit-testable without a GPU.
+// Citations are relative to /root/reference/larq_compute_engine/.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lce_hip.h"
+#include "lce_kernel_args.h"
+
+namespace lce {
+
+struct TileShape {
+  int tm, tn;
+};
+
+struct HostPlan {
+  lce_hip_bconv2d_desc d{};
+  // inferred by Prepare (tflite/kernels/bconv2d.cc:203-210)
+  int out_h = 0, out_w = 0, pad_h = 0, pad_w = 0;
+  int cw = 0, cwg = 0, npg = 0, wout = 0;  // words per pixel / per group, Cout per group, out words
+  int backtransform_add = 0;               // KH*KW*Cin/G (bconv2d.cc:361-362)
+  int zero_pad_mode = kZeroPadNone;
+
+  // OneTimeSetup results (bconv2d.cc:324-392)
+  bool have_weights = false;
+  std::vector<float> mul, bias;            // channels_out entries
+  int32_t clamp_min = 0, clamp_max = 0;
+  std::vector<int32_t> thresholds;
+  std::vector<uint32_t> filter;            // OHWI copy (general kernel + repacking source)
+  std::vector<float> zero_pad_cache;       // zero_padding_correction.h:39-176
+
+  // kernel selection
+  int kernel_pref = 0;                     // 0 auto, 1 tiled, 2 general
+  TileShape tile_pref{0, 0};               // {0,0} = auto
+  bool use_tiled = false;
+  TileShape tile{0, 0};
+  int ch = 1;                              // activation words per vector load
+  int nt = 0;                              // channel tiles
+  std::string kernel_name;
+
+  // tiled-kernel operands (built by pack_for_tile)
+  std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
+  std::vector<float> mul_p, bias_p;        // NT*TN, padded
+  std::vector<int32_t> thr_p;              // NT*TN, padded with INT32_MAX
+  std::vector<int32_t> oob_corr;           // [NT][KH*KW][TN]: (Cin/G)/2 - popcount(tap)
+};
+
+// Returns "" when the descriptor is acceptable, otherwise the message Prepare would log.
+std::string validate_and_infer(HostPlan& p);
+
+// OneTimeSetup: fold multiplier/bias/clamps (double arithmetic, float storage), keep
+// thresholds, compute the zero-padding correction cache.
+void fold_parameters(HostPlan& p, const int32_t* filter_ohwi, const float* post_mul,
+                     const float* post_bias, const int32_t* thresholds);
+
+// Can the tiled kernel with channel tile `tn` run this convolution?
+bool tiled_supports(const HostPlan& p, int tn);
+
+// Choose kernel + tile for `pixels` output pixels per launch and (re)build the packed
+// operands.  Returns "" or an error message (e.g. a forced variant that cannot run).
+std::string select_kernel(HostPlan& p, int64_t pixels);
+
+// Largest batch chunk one launch may take (buffer resources bind < 2 GiB).
+int max_batch_per_launch(const HostPlan& p);
+
+ConvArgs make_conv_args(const HostPlan& p, int batch_chunk);
+
+}  // namespace lce

@@ -1,0 +1,196 @@
+/*
+ * lce_hip.h -- C ABI of the MI355X-native LceBconv2d / LceQuantize hot path.
+ *
+ * This is the drop-in boundary under Larq Compute Engine's TFLite custom-op glue: the
+ * C++ op glue (compute-engine_amd/csrc/tflite/, same Register_* entry points as the
+ * reference) and any other host language bind THESE functions -- plain pointers,
+ * sizes and int status codes, no C++/torch/HIP types in any signature.  Each entry
+ * point names the reference interface it replaces (paths relative to
+ * /root/reference/larq_compute_engine/).
+ *
+ * Conventions
+ *   - every function returns LCE_HIP_OK (0) or an error code; lce_hip_last_error()
+ *     returns a thread-local human-readable message for the last failure;
+ *   - `*_dev` pointers are device (HBM) pointers of the current HIP device, `*_host`
+ *     pointers are ordinary host memory; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - tensors use the reference's layouts: activations NHWC with channels bitpacked
+ *     into int32 words LSB-first (core/types.h:41, core/bitpacking/bitpack.h:72-110),
+ *     filters OHWI bitpacked (tflite/kernels/bconv2d.cc:145-152), outputs NHWC;
+ *   - there is NO CPU fallback: without a usable GPU the compute entry points fail
+ *     with LCE_HIP_ERR_NO_DEVICE.
+ */
+#ifndef LCE_HIP_H_
+#define LCE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCE_HIP_ABI_VERSION 1
+
+typedef enum lce_hip_status {
+  LCE_HIP_OK = 0,
+  LCE_HIP_ERR_INVALID = 1,     /* bad argument / rejected by the same checks as Prepare */
+  LCE_HIP_ERR_UNSUPPORTED = 2, /* valid for the reference but outside what this build runs */
+  LCE_HIP_ERR_RUNTIME = 3,     /* a HIP call failed */
+  LCE_HIP_ERR_NO_DEVICE = 4    /* no gfx950 device / HIP runtime unusable */
+} lce_hip_status;
+
+/* element types of the tensors that cross the boundary */
+typedef enum lce_hip_dtype {
+  LCE_HIP_F32 = 0,       /* kTfLiteFloat32 */
+  LCE_HIP_I8 = 1,        /* kTfLiteInt8    */
+  LCE_HIP_BITPACKED = 2, /* kTfLiteInt32 holding 32 sign bits (TBitpacked, core/types.h:41) */
+  LCE_HIP_BOOL = 3       /* kTfLiteBool (1 byte) */
+} lce_hip_dtype;
+
+/* tflite schema enums as they arrive in the op's flexbuffer options
+ * (tflite/kernels/bconv2d.cc:94-124, tflite/kernels/utils.h:10-35) */
+typedef enum lce_hip_padding { LCE_HIP_PADDING_SAME = 0, LCE_HIP_PADDING_VALID = 1 } lce_hip_padding;
+typedef enum lce_hip_activation {
+  LCE_HIP_ACT_NONE = 0, LCE_HIP_ACT_RELU = 1, LCE_HIP_ACT_RELU_N1_TO_1 = 2, LCE_HIP_ACT_RELU6 = 3
+} lce_hip_activation;
+
+/* Which reference registration's semantics to follow.  They only differ for SAME
+ * padding with pad_values == 0 (tflite/kernels/bconv2d.cc:188-200):
+ *   REFERENCE : Register_BCONV_2D_REF -- exact integer zero padding
+ *               (core/bconv2d/reference.h:76-103); needs an even channels_in.
+ *   OPTIMIZED : Register_BCONV_2D_OPT_BGEMM / _OPT_INDIRECT_BGEMM -- one-padded
+ *               convolution plus float correction (core/bconv2d/zero_padding_correction.h);
+ *               float output and no fused activation only. */
+typedef enum lce_hip_semantics { LCE_HIP_SEM_REFERENCE = 0, LCE_HIP_SEM_OPTIMIZED = 1 } lce_hip_semantics;
+
+/* ------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------- */
+int lce_hip_abi_version(void);
+const char* lce_hip_last_error(void);
+/* number of usable HIP devices (0 when there is none; never fails) */
+int lce_hip_device_count(void);
+lce_hip_status lce_hip_set_device(int device);
+
+/* Device-memory plumbing for hosts that have no HIP binding of their own (the TFLite
+ * glue stages interpreter tensors through these). */
+lce_hip_status lce_hip_malloc(void** dev_ptr, size_t bytes);
+lce_hip_status lce_hip_free(void* dev_ptr);
+lce_hip_status lce_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+lce_hip_status lce_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+lce_hip_status lce_hip_memset(void* dst_dev, int value, size_t bytes, void* stream);
+lce_hip_status lce_hip_stream_create(void** stream);
+lce_hip_status lce_hip_stream_destroy(void* stream);
+lce_hip_status lce_hip_stream_synchronize(void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LceQuantize / LceDequantize
+ * ---------------------------------------------------------------------------------- */
+
+/* ceil(n / 32): core/bitpacking/bitpack.h:24-26 (GetBitpackedSize) */
+int32_t lce_hip_bitpacked_size(int32_t unpacked_elements);
+
+/* Replaces core::bitpacking::bitpack_matrix<T> (core/bitpacking/bitpack.h:248-308) as
+ * called by QuantizeEval (tflite/kernels/quantization.cc:76-114): packs each of the
+ * `rows` rows of `cols` elements into ceil(cols/32) words; bit = (x < zero_point)
+ * (float: zero_point must be 0, test is x < 0; bool: pass zero_point 1), padding bits 0.
+ * in_type is F32, I8 or BOOL. */
+lce_hip_status lce_hip_bitpack(lce_hip_dtype in_type, const void* in_dev, size_t rows,
+                               size_t cols, int32_t zero_point, int32_t* out_dev, void* stream);
+
+/* Replaces core::bitpacking::unpack_matrix<T> (bitpack.h:327-346) as called by
+ * DequantizeEval (quantization.cc:116-147).  out_type F32: bit0 -> +1, bit1 -> -1;
+ * I8: zero_point +- round(1/scale) clamped to int8; BOOL: bit0 -> true. */
+lce_hip_status lce_hip_unpack(lce_hip_dtype out_type, const int32_t* in_dev, size_t rows,
+                              size_t cols, float scale, int32_t zero_point, void* out_dev,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LceBconv2d
+ * ---------------------------------------------------------------------------------- */
+
+/* The op attributes + tensor metadata that bconv2d::Init/Prepare collect
+ * (tflite/kernels/bconv2d.cc:85-131,137-300; core/bconv2d/params.h:12-32). */
+typedef struct lce_hip_bconv2d_desc {
+  int32_t batch, in_height, in_width;
+  int32_t channels_in;    /* unpacked input channels (attribute "channels_in") */
+  int32_t filter_height, filter_width;
+  int32_t channels_out;
+  int32_t groups;         /* the glue infers it from the filter shape, bconv2d.cc:169-186 */
+  int32_t stride_height, stride_width;
+  int32_t dilation_height, dilation_width;
+  int32_t padding;        /* lce_hip_padding    */
+  int32_t pad_values;     /* 0 or 1             */
+  int32_t activation;     /* lce_hip_activation */
+  int32_t dst_type;       /* LCE_HIP_F32 / LCE_HIP_I8 / LCE_HIP_BITPACKED */
+  int32_t semantics;      /* lce_hip_semantics  */
+  float out_scale;        /* int8 output: output->params.scale      */
+  int32_t out_zero_point; /* int8 output: output->params.zero_point */
+} lce_hip_bconv2d_desc;
+
+typedef struct lce_hip_bconv2d_plan lce_hip_bconv2d_plan;
+
+/* Validates the descriptor with the same rules as bconv2d::Prepare (bconv2d.cc:137-300)
+ * and infers padding and output shape (TFLite ComputePaddingHeightWidth, :203-210).
+ * Host-only: does not touch the GPU, so shape inference works anywhere. */
+lce_hip_status lce_hip_bconv2d_plan_create(const lce_hip_bconv2d_desc* desc,
+                                           lce_hip_bconv2d_plan** plan);
+void lce_hip_bconv2d_plan_destroy(lce_hip_bconv2d_plan* plan);
+
+/* [batch, out_height, out_width, channels_out or ceil(channels_out/32)] (bconv2d.cc:241-248) */
+lce_hip_status lce_hip_bconv2d_plan_output_shape(const lce_hip_bconv2d_plan* plan, int32_t dims[4]);
+/* padding_values.{height,width} as Prepare stores them (core/bconv2d/params.h:29-31) */
+lce_hip_status lce_hip_bconv2d_plan_padding(const lce_hip_bconv2d_plan* plan, int32_t* pad_h,
+                                            int32_t* pad_w);
+
+/* Replaces OneTimeSetup (bconv2d.cc:324-392) + indirect_bgemm::Kernel::PackWeights
+ * (core/indirect_bgemm/kernel.h:54-94): folds post_activation_{multiplier,bias}, the int8
+ * scale/zero-point and the fused activation into the output transform, precomputes the
+ * zero-padding correction, repacks the OHWI filter for the kernel.  All pointers are
+ * HOST memory and are copied; `thresholds` is required (and the float arrays ignored)
+ * iff dst_type is BITPACKED.  Host-only; the upload happens on first run. */
+lce_hip_status lce_hip_bconv2d_plan_set_weights(lce_hip_bconv2d_plan* plan,
+                                                const int32_t* filter_ohwi_host,
+                                                const float* post_activation_multiplier_host,
+                                                const float* post_activation_bias_host,
+                                                const int32_t* thresholds_host);
+
+/* The folded transform, for inspection: mul/bias have channels_out entries. */
+lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, float* mul,
+                                           float* bias, int32_t* clamp_min, int32_t* clamp_max);
+
+/* Tuning/testing knobs: key "kernel" = "auto" | "tiled" | "general";
+ * "tile" = "auto" | "4x16" | "2x32" | "1x32" | "2x16" | "1x16". */
+lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key,
+                                               const char* value);
+/* Name of the kernel variant the next run will launch (static string owned by the plan). */
+const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan);
+
+/* Replaces bconv2d::Eval (bconv2d.cc:550-564) -> BConv2DReference /
+ * BConv2DOptimizedBGEMM / BConv2DOptimizedIndirectBGEMM (core/bconv2d/ headers) with
+ * device-resident tensors: input int32 [B,H,W,ceil(Cin/32)], output per dst_type.
+ * Asynchronous on `stream`. */
+lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* input_dev,
+                                   void* output_dev, void* stream);
+/* Same with host tensors (interpreter arena): H2D, run, D2H, synchronous. */
+lce_hip_status lce_hip_bconv2d_run_host(lce_hip_bconv2d_plan* plan, const int32_t* input_host,
+                                        void* output_host);
+
+/* ------------------------------------------------------------------------------------
+ * LceBMaxPool2d (core/bmaxpool.h:24-88; tflite/kernels/bmaxpool.cc:20-98)
+ * ---------------------------------------------------------------------------------- */
+lce_hip_status lce_hip_bmaxpool_output_shape(int32_t in_height, int32_t in_width,
+                                             int32_t filter_height, int32_t filter_width,
+                                             int32_t stride_height, int32_t stride_width,
+                                             int32_t padding, int32_t* out_height,
+                                             int32_t* out_width);
+lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t in_height,
+                                int32_t in_width, int32_t words, int32_t filter_height,
+                                int32_t filter_width, int32_t stride_height, int32_t stride_width,
+                                int32_t padding, int32_t* output_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCE_HIP_H_ */

@@ -1,0 +1,173 @@
+// Host simulation driver -- TEST ONLY (see tests/hostsim/lce_device_intrinsics.h).
+// Runs the real kernel bodies of compute-engine_amd/csrc/lce_kernels.h on the CPU with
+// the real planner (lce_plan.cpp), mirroring the launch logic of lce_hip_api.hip.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "lce_dispatch.h"
+#include "lce_kernels.h"
+#include "lce_plan.h"
+
+using namespace lce;
+
+namespace {
+
+// Lanes of a wave executed one after the other (no wave collectives needed).
+template <typename F>
+void launch_sequential(int grid_x, int grid_y, int block, F&& body) {
+  lce_dev::ThreadCtx& c = lce_dev::g_ctx;
+  c.bar = nullptr;
+  c.xchg = nullptr;
+  c.bdim_x = block;
+  c.gdim_x = grid_x;
+  for (int by = 0; by < grid_y; ++by)
+    for (int bx = 0; bx < grid_x; ++bx)
+      for (int t = 0; t < block; ++t) {
+        c.bid_x = bx; c.bid_y = by; c.tid_x = t;
+        body();
+      }
+}
+
+// The 64 lanes of every wave run as 64 real threads so ballot/shuffle work.
+template <typename F>
+void launch_lockstep(int grid_x, int block, F&& body) {
+  for (int bx = 0; bx < grid_x; ++bx)
+    for (int w = 0; w < block / 64; ++w) {
+      std::barrier<> bar(64);
+      uint32_t xchg[64] = {0};
+      std::vector<std::thread> lanes;
+      for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l] {
+          lce_dev::ThreadCtx& c = lce_dev::g_ctx;
+          c.bar = &bar; c.xchg = xchg; c.bdim_x = block; c.gdim_x = grid_x;
+          c.bid_x = bx; c.bid_y = 0; c.tid_x = w * 64 + l;
+          body();
+        });
+      for (auto& t : lanes) t.join();
+    }
+}
+
+std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* hostsim_last_error() { return g_err.c_str(); }
+
+// kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
+int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, const float* post_mul,
+                    const float* post_bias, const int32_t* thresholds, const int32_t* input,
+                    void* output, int kernel_pref, int tm, int tn, int max_batch, char* name_out,
+                    int name_len) {
+  HostPlan h;
+  h.d = *desc;
+  std::string err = validate_and_infer(h);
+  if (!err.empty()) { g_err = err; return 1; }
+  fold_parameters(h, filter, post_mul, post_bias, thresholds);
+  h.kernel_pref = kernel_pref;
+  h.tile_pref = TileShape{tm, tn};
+  int chunk = max_batch_per_launch(h);
+  if (max_batch > 0) chunk = std::min(chunk, max_batch);
+  err = select_kernel(h, (int64_t)chunk * h.out_h * h.out_w);
+  if (!err.empty()) { g_err = err; return 2; }
+  if (name_out && name_len > 0) {
+    strncpy(name_out, h.kernel_name.c_str(), name_len - 1);
+    name_out[name_len - 1] = 0;
+  }
+  // the padded tables get the same slack as the device uploads
+  auto slack_u = [](std::vector<uint32_t> v) { v.resize(v.size() + 16, 0u); return v; };
+  const std::vector<uint32_t> packed = slack_u(h.packed), filt = slack_u(h.filter);
+  const float* zpc = h.zero_pad_cache.empty() ? nullptr : h.zero_pad_cache.data();
+
+  const size_t in_img_words = (size_t)h.d.in_height * h.d.in_width * h.cw;
+  const size_t out_row = h.d.dst_type == LCE_HIP_BITPACKED ? (size_t)h.wout : (size_t)h.d.channels_out;
+  const size_t out_img_bytes = (size_t)h.out_h * h.out_w * out_row * (h.d.dst_type == LCE_HIP_I8 ? 1 : 4);
+  for (int b0 = 0; b0 < h.d.batch; b0 += chunk) {
+    const int nb = std::min(chunk, h.d.batch - b0);
+    const ConvArgs A = make_conv_args(h, nb);
+    const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
+    void* out = (char*)output + (size_t)b0 * out_img_bytes;
+    if (h.use_tiled) {
+      tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
+      if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
+      const int64_t tasks = (int64_t)A.PT * A.NT;
+      const int wpb = 4;
+      launch_sequential((int)((tasks + wpb - 1) / wpb), 1, 64 * wpb, [&] {
+        fn(A, in, packed.data(), h.mul_p.data(), h.bias_p.data(), h.thr_p.data(), h.oob_corr.data(), zpc, out);
+      });
+    } else {
+      general_fn fn = find_general(h.d.dst_type);
+      launch_sequential((A.M + 255) / 256, (h.d.channels_out + 31) / 32, 256, [&] {
+        fn(A, in, filt.data(), h.mul.data(), h.bias.data(), h.thresholds.data(), zpc, out);
+      });
+    }
+  }
+  return 0;
+}
+
+// in_type: LCE_HIP_F32 / I8 / BOOL.  force_rows != 0 -> always the ballot kernel.
+int hostsim_bitpack(int in_type, const void* in, uint64_t rows, uint64_t cols, int32_t zero_point,
+                    uint32_t* out, int force_rows) {
+  if (in_type == LCE_HIP_BOOL) zero_point = 1;
+  const size_t esz = in_type == LCE_HIP_F32 ? 4 : 1;
+  const uint64_t wpr = (cols + 31) / 32, total_words = rows * wpr;
+  auto rows_kernel = [&](const void* src, uint64_t r, uint64_t c, uint32_t* dst) {
+    const uint32_t w = (uint32_t)((c + 31) / 32), segs = (uint32_t)((c + 63) / 64);
+    const uint64_t tasks = r * segs;
+    const int grid = (int)std::min<uint64_t>((tasks + 3) / 4, 3);  // small grid: exercises the stride loop
+    const FastDiv dv = make_fastdiv(segs);
+    launch_lockstep(grid, 256, [&] {
+      if (in_type == LCE_HIP_F32) bitpack_rows<float>((const float*)src, dst, (uint32_t)r, (uint32_t)c, w, 0, dv, segs, tasks);
+      else if (in_type == LCE_HIP_I8) bitpack_rows<int8_t>((const int8_t*)src, dst, (uint32_t)r, (uint32_t)c, w, zero_point, dv, segs, tasks);
+      else bitpack_rows<uint8_t>((const uint8_t*)src, dst, (uint32_t)r, (uint32_t)c, w, zero_point, dv, segs, tasks);
+    });
+  };
+  const bool flat = !force_rows && cols % 32 == 0 && total_words >= 32;
+  if (!flat) { rows_kernel(in, rows, cols, out); return 0; }
+  const uint64_t blocks32 = total_words / 32;
+  const int grid = (int)std::min<uint64_t>((blocks32 + 3) / 4, 2);
+  launch_lockstep(grid, 256, [&] {
+    if (in_type == LCE_HIP_F32) bitpack_f32_flat((const float*)in, out, blocks32);
+    else if (in_type == LCE_HIP_I8) bitpack_b8_flat<false>((const uint8_t*)in, out, blocks32, zero_point);
+    else bitpack_b8_flat<true>((const uint8_t*)in, out, blocks32, zero_point);
+  });
+  const uint64_t done = blocks32 * 32;
+  if (done < total_words)
+    rows_kernel((const char*)in + done * 32 * esz, 1, (total_words - done) * 32, out + done);
+  return 0;
+}
+
+int hostsim_unpack(int out_type, const uint32_t* in, uint64_t rows, uint64_t cols, float scale,
+                   int32_t zero_point, void* out) {
+  const uint32_t wpr = (uint32_t)((cols + 31) / 32);
+  const uint64_t total = rows * cols;
+  launch_sequential(2, 1, 256, [&] {
+    if (out_type == LCE_HIP_F32) unpack_rows<float>(in, (float*)out, total, (uint32_t)cols, wpr, 1.0f, -1.0f);
+    else if (out_type == LCE_HIP_I8) {
+      const int offset = (int)roundf(1.0f / scale);
+      unpack_rows<int8_t>(in, (int8_t*)out, total, (uint32_t)cols, wpr,
+                          (int8_t)std::min(127, zero_point + offset), (int8_t)std::max(-128, zero_point - offset));
+    } else unpack_rows<uint8_t>(in, (uint8_t*)out, total, (uint32_t)cols, wpr, (uint8_t)1, (uint8_t)0);
+  });
+  return 0;
+}
+
+int hostsim_bmaxpool(const uint32_t* in, int b, int h, int w, int c, int fh, int fw, int sh, int sw,
+                     int padding, uint32_t* out) {
+  const int oh = padding == LCE_HIP_PADDING_SAME ? (h + sh - 1) / sh : (h + sh - fh) / sh;
+  const int ow = padding == LCE_HIP_PADDING_SAME ? (w + sw - 1) / sw : (w + sw - fw) / sw;
+  const int ph = std::max(0, (oh - 1) * sh + fh - h) / 2, pw = std::max(0, (ow - 1) * sw + fw - w) / 2;
+  const uint64_t total = (uint64_t)b * oh * ow * c;
+  launch_sequential(2, 1, 256, [&] { bmaxpool_words(in, out, b, h, w, c, oh, ow, fh, fw, sh, sw, ph, pw, total); });
+  return 0;
+}
+
+uint32_t hostsim_fastdiv(uint32_t n, uint32_t d) { return fastdiv(n, make_fastdiv(d)); }
+
+}  // extern "C"

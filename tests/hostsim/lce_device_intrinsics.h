@@ -1,0 +1,99 @@
+// HOST replacement of compute-engine_amd/csrc/lce_device_intrinsics.h -- TEST ONLY.
+//
+// The CPU-only test suite compiles the real kernel bodies (lce_kernels.h) against this
+// header and executes them thread by thread, so index arithmetic, padding, grouping and
+// the fused output transforms are exercised without a GPU.  Nothing in the product
+// includes this file; it is not a fallback path (the shipped library is built only from
+// the gfx950 header and fails loudly without a device).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <barrier>
+#include <vector>
+
+#define LCE_DEVICE inline
+#define LCE_KERNEL inline
+#define __restrict__
+#define __launch_bounds__(...)
+
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+
+namespace lce_dev {
+
+struct u32x2 { uint32_t v[2]; uint32_t& operator[](int i) { return v[i]; } uint32_t operator[](int i) const { return v[i]; } };
+struct u32x4 { uint32_t v[4]; uint32_t& operator[](int i) { return v[i]; } uint32_t operator[](int i) const { return v[i]; } };
+struct f32x4 { float v[4]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
+
+constexpr int kWave = 64;
+
+struct ThreadCtx {
+  int tid_x = 0, bid_x = 0, bid_y = 0, bdim_x = 1, gdim_x = 1;
+  // wave collectives (only valid when the 64 lanes of a wave run as real threads)
+  std::barrier<>* bar = nullptr;
+  uint32_t* xchg = nullptr;  // 64 slots shared by the wave
+};
+inline thread_local ThreadCtx g_ctx;
+
+inline int thread_idx_x() { return g_ctx.tid_x; }
+inline int block_idx_x() { return g_ctx.bid_x; }
+inline int block_idx_y() { return g_ctx.bid_y; }
+inline int block_dim_x() { return g_ctx.bdim_x; }
+inline int grid_dim_x() { return g_ctx.gdim_x; }
+
+inline uint32_t uniform(uint32_t x) { return x; }
+inline int uniform(int x) { return x; }
+
+struct rsrc_t { const uint8_t* base; uint32_t bytes; };
+inline rsrc_t make_rsrc(const void* base, uint32_t bytes) { return rsrc_t{(const uint8_t*)base, bytes}; }
+constexpr uint32_t kOobOffset = 0x80000000u;
+
+template <typename V>
+inline V buf_load_impl(rsrc_t r, uint32_t off) {
+  V v;
+  memset(&v, 0, sizeof v);
+  // raw buffer, stride 0: the access is out of range iff off + size > num_records -> 0
+  if ((uint64_t)off + sizeof(V) <= (uint64_t)r.bytes) memcpy(&v, r.base + off, sizeof v);
+  return v;
+}
+inline uint32_t buf_load(rsrc_t r, uint32_t off, uint32_t*) { return buf_load_impl<uint32_t>(r, off); }
+inline u32x2 buf_load(rsrc_t r, uint32_t off, u32x2*) { return buf_load_impl<u32x2>(r, off); }
+inline u32x4 buf_load(rsrc_t r, uint32_t off, u32x4*) { return buf_load_impl<u32x4>(r, off); }
+
+inline uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline int popc(uint32_t x) { return __builtin_popcount(x); }
+inline float round_half_away(float y) { return roundf(y); }
+
+inline unsigned long long wave_ballot(bool p) {
+  if (!g_ctx.bar) return p ? ~0ull : 0ull;  // sequential mode: only used via wave_any
+  const int lane = g_ctx.tid_x & 63;
+  g_ctx.xchg[lane] = p ? 1u : 0u;
+  g_ctx.bar->arrive_and_wait();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l) m |= (unsigned long long)g_ctx.xchg[l] << l;
+  g_ctx.bar->arrive_and_wait();
+  return m;
+}
+// sequential mode: answering "true" is always safe -- the guarded code masks per lane
+inline bool wave_any(bool p) { return g_ctx.bar ? wave_ballot(p) != 0ull : true; }
+inline uint32_t shfl_xor(uint32_t v, int mask) {
+  const int lane = g_ctx.tid_x & 63;
+  g_ctx.xchg[lane] = v;
+  g_ctx.bar->arrive_and_wait();
+  const uint32_t r = g_ctx.xchg[lane ^ mask];
+  g_ctx.bar->arrive_and_wait();
+  return r;
+}
+
+inline void xor_popc_acc(int& c0, uint32_t w, uint32_t a0) { c0 += popc(a0 ^ w); }
+inline void xor_popc_acc(int& c0, int& c1, uint32_t w, uint32_t a0, uint32_t a1) {
+  c0 += popc(a0 ^ w); c1 += popc(a1 ^ w);
+}
+inline void xor_popc_acc(int& c0, int& c1, int& c2, int& c3, uint32_t w, uint32_t a0, uint32_t a1,
+                         uint32_t a2, uint32_t a3) {
+  c0 += popc(a0 ^ w); c1 += popc(a1 ^ w); c2 += popc(a2 ^ w); c3 += popc(a3 ^ w);
+}
+
+}  // namespace lce_dev

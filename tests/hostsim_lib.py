@@ -1,0 +1,102 @@
+"""ctypes binding of tests/hostsim/liblce_hostsim.so: the REAL kernel bodies
+(compute-engine_amd/csrc/lce_kernels.h) and the REAL planner (lce_plan.cpp) executed
+thread by thread on the CPU.  Test infrastructure only -- it lets the CPU-only suite check
+index / padding / grouping / epilogue logic before any GPU minute is spent."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import oracle_lib as O
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+_lib = None
+
+
+class Desc(C.Structure):
+    """lce_hip_bconv2d_desc (include/lce_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "in_height", "in_width", "channels_in", "filter_height", "filter_width",
+        "channels_out", "groups", "stride_height", "stride_width", "dilation_height",
+        "dilation_width", "padding", "pad_values", "activation", "dst_type", "semantics")] + [
+        ("out_scale", C.c_float), ("out_zero_point", C.c_int32)]
+
+
+def make_desc(spec: O.ConvSpec, dst_type: int, out_scale: float = 1.0, out_zero_point: int = 0) -> Desc:
+    return Desc(spec.batch, spec.in_h, spec.in_w, spec.channels_in, spec.filter_h, spec.filter_w,
+                spec.channels_out, spec.groups, spec.stride_h, spec.stride_w, spec.dilation_h,
+                spec.dilation_w, spec.padding, spec.pad_values, spec.activation, dst_type,
+                spec.semantics, float(out_scale), int(out_zero_point))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-C", _DIR], check=True, capture_output=True)
+        _lib = C.CDLL(os.path.join(_DIR, "liblce_hostsim.so"))
+        _lib.hostsim_last_error.restype = C.c_char_p
+        _lib.hostsim_fastdiv.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def bconv2d(spec: O.ConvSpec, dst_type: int, inp, filt, post_mul=None, post_bias=None,
+            thresholds=None, out_scale=1.0, out_zero_point=0, kernel="auto", tile=(0, 0),
+            max_batch=0):
+    inp = np.ascontiguousarray(inp, np.int32)
+    filt = np.ascontiguousarray(filt, np.int32)
+    mul = None if post_mul is None else np.ascontiguousarray(post_mul, np.float32)
+    bias = None if post_bias is None else np.ascontiguousarray(post_bias, np.float32)
+    thr = None if thresholds is None else np.ascontiguousarray(thresholds, np.int32)
+    dt = {O.DST_F32: np.float32, O.DST_I8: np.int8, O.DST_BITPACKED: np.int32}[dst_type]
+    out = np.full(spec.output_shape(dst_type), 0x55, dtype=np.uint8).astype(dt) if dt == np.int8 \
+        else np.full(spec.output_shape(dst_type), -7, dtype=dt)
+    name = C.create_string_buffer(128)
+    d = make_desc(spec, dst_type, out_scale, out_zero_point)
+    rc = lib().hostsim_bconv2d(C.byref(d), _p(filt), _p(mul), _p(bias), _p(thr), _p(inp), _p(out),
+                               {"auto": 0, "tiled": 1, "general": 2}[kernel], tile[0], tile[1],
+                               max_batch, name, 128)
+    if rc != 0:
+        raise RuntimeError(lib().hostsim_last_error().decode())
+    return out, name.value.decode()
+
+
+def bitpack(x: np.ndarray, zero_point: int = 0, force_rows: bool = False) -> np.ndarray:
+    x = np.ascontiguousarray(x)
+    cols = x.shape[-1]
+    rows = int(np.prod(x.shape[:-1], dtype=np.int64)) if x.ndim > 1 else 1
+    out = np.full(x.shape[:-1] + ((cols + 31) // 32,), -1, np.int32)
+    t = {np.dtype(np.float32): 0, np.dtype(np.int8): 1, np.dtype(np.bool_): 3, np.dtype(np.uint8): 3}[x.dtype]
+    lib().hostsim_bitpack(t, _p(x), C.c_uint64(rows), C.c_uint64(cols), C.c_int32(zero_point),
+                          _p(out), int(force_rows))
+    return out
+
+
+def unpack(words: np.ndarray, cols: int, dtype, scale=1.0, zero_point=0) -> np.ndarray:
+    words = np.ascontiguousarray(words, np.int32)
+    rows = int(np.prod(words.shape[:-1], dtype=np.int64)) if words.ndim > 1 else 1
+    out = np.empty(words.shape[:-1] + (cols,), dtype=dtype)
+    t = {np.dtype(np.float32): 0, np.dtype(np.int8): 1, np.dtype(np.bool_): 3}[np.dtype(dtype)]
+    lib().hostsim_unpack(t, _p(words), C.c_uint64(rows), C.c_uint64(cols), C.c_float(scale),
+                         C.c_int32(zero_point), _p(out))
+    return out
+
+
+def bmaxpool(x, fh, fw, sh, sw, padding):
+    x = np.ascontiguousarray(x, np.int32)
+    b, h, w, c = x.shape
+    oh = (h + sh - 1) // sh if padding == O.PADDING_SAME else (h + sh - fh) // sh
+    ow = (w + sw - 1) // sw if padding == O.PADDING_SAME else (w + sw - fw) // sw
+    out = np.empty((b, oh, ow, c), np.int32)
+    lib().hostsim_bmaxpool(_p(x), b, h, w, c, fh, fw, sh, sw, padding, _p(out))
+    return out
+
+
+def fastdiv(n: int, d: int) -> int:
+    return lib().hostsim_fastdiv(C.c_uint32(n), C.c_uint32(d))

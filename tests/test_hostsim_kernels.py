@@ -1,0 +1,175 @@
+"""CPU execution of the real kernel bodies + real planner against the oracle.
+
+These tests do not replace the GPU parity tests (tests/test_gpu_*.py): they only prove
+that the kernels' index arithmetic, padding, grouping, tiling and fused epilogues are
+right before GPU minutes are spent."""
+import itertools
+import zlib
+
+import numpy as np
+import pytest
+
+import hostsim_lib as H
+import oracle_lib as O
+import synth
+from test_oracle_vs_float_conv import CASES, PADS, _id, legal
+
+TILES = [(4, 16), (2, 32), (2, 16), (1, 32), (1, 16)]
+
+
+def test_fastdiv_exhaustive_small_and_edges():
+    rs = np.random.default_rng(0)
+    for d in list(range(1, 70)) + [112, 224, 1000, 3136, 65535, 65536, 2**20 + 7, 2**31 - 1]:
+        ns = np.concatenate([np.arange(0, 300), rs.integers(0, 2**31, 200), [2**31 - 1, 2**31 - 2, d - 1, d, d + 1]])
+        ns = ns[(ns >= 0) & (ns < 2**31)]
+        for n in ns:
+            assert H.fastdiv(int(n), d) == int(n) // d, (n, d)
+
+
+def _run_all_dst(spec, seed, kernel, tile, max_batch=0):
+    x, w, mul, bias = synth.conv_inputs(spec, seed)
+    zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
+    ran = []
+    # float
+    if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, kernel=kernel, tile=tile, max_batch=max_batch)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), name   # bit-exact floats
+        ran.append(name)
+    if zero_pad and spec.semantics == O.SEM_OPTIMIZED:
+        return ran
+    scale, zp = synth.int8_quant_params(seed)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
+    got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp,
+                          kernel=kernel, tile=tile, max_batch=max_batch)
+    assert np.array_equal(got, want), name
+    ran.append(name)
+    thr = O.thresholds_converter(spec, mul, bias)
+    thr[::5] = np.iinfo(np.int32).max
+    thr[1::7] = np.iinfo(np.int32).min
+    want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
+    if tile[1] in (0, 32):
+        got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, kernel=kernel, tile=tile,
+                              max_batch=max_batch)
+        assert np.array_equal(got, want), name
+        ran.append(name)
+    return ran
+
+
+def _spec(case, sem):
+    inp, flt, g, st, dil, pad, act = case
+    padding, pad_values = PADS[pad]
+    return O.ConvSpec(inp[0], inp[1], inp[2], inp[3], flt[0], flt[1], flt[2], g, st[0], st[1],
+                      dil[0], dil[1], padding, pad_values, act, sem)
+
+
+GRID = CASES[:72] + CASES[72::7]
+
+
+@pytest.mark.parametrize("case", GRID, ids=_id)
+def test_reference_grid_auto_and_general(case):
+    """The reference's own shape grid (bconv2d_test.cc:790-856), both registrations'
+    semantics, through the planner's automatic choice and through the general kernel."""
+    for sem in (O.SEM_REFERENCE, O.SEM_OPTIMIZED):
+        if not legal(case[0], case[1], case[2], case[5], sem):
+            continue
+        spec = _spec(case, sem)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        seed = zlib.crc32(_id(case).encode()) & 0xFFFF
+        _run_all_dst(spec, seed, "auto", (0, 0))
+        _run_all_dst(spec, seed, "general", (0, 0))
+
+
+@pytest.mark.parametrize("tile", TILES, ids=lambda t: "%dx%d" % t)
+@pytest.mark.parametrize("cin,cout,groups", [(64, 64, 1), (32, 40, 1), (96, 33, 1), (128, 64, 2),
+                                             (256, 128, 4), (20, 7, 1), (160, 96, 1)])
+@pytest.mark.parametrize("pad", ["VALID", "SAME", "ONE"])
+def test_every_tile_shape(tile, cin, cout, groups, pad):
+    """Every instantiated (TM, TN) x CH variant, ragged pixel counts (M not a multiple of
+    64*TM), ragged channel tiles, odd word counts, strides and dilation."""
+    if groups > 1 and (cout // groups) % tile[1]:
+        pytest.skip("tile would straddle groups; planner falls back (covered elsewhere)")
+    padding, pad_values = PADS[pad]
+    for sem, st, dil, act in [(O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_NONE),
+                              (O.SEM_OPTIMIZED, (2, 1), (1, 2), O.ACT_NONE),
+                              (O.SEM_REFERENCE, (1, 2), (2, 1), O.ACT_RELU)]:
+        if pad == "SAME" and sem == O.SEM_REFERENCE and cin % 2:
+            continue
+        spec = O.ConvSpec(3, 9, 11, cin, 3, 3, cout, groups, st[0], st[1], dil[0], dil[1], padding,
+                          pad_values, act, sem)
+        names = _run_all_dst(spec, seed=cin * 7 + cout, kernel="tiled", tile=tile)
+        assert all("TM=%d,TN=%d" % tile in n for n in names), names
+
+
+def test_batch_chunking_matches_single_launch():
+    spec = O.ConvSpec(5, 6, 7, 64, 3, 3, 32, padding=O.PADDING_SAME, pad_values=1)
+    _run_all_dst(spec, 11, "auto", (0, 0), max_batch=2)
+    _run_all_dst(spec, 11, "tiled", (1, 32), max_batch=1)
+
+
+@pytest.mark.parametrize("act", [O.ACT_NONE, O.ACT_RELU, O.ACT_RELU_N1_TO_1, O.ACT_RELU6])
+def test_all_fused_activations(act):
+    spec = O.ConvSpec(2, 5, 5, 64, 3, 3, 48, padding=O.PADDING_SAME, pad_values=1, activation=act)
+    _run_all_dst(spec, 5 + act, "auto", (0, 0))
+
+
+def test_int8_exact_ties_round_half_away():
+    """y = n + 0.5 exactly: the portable reference rounds half AWAY from zero
+    (output_transform.h:31-44 -> std::round), not half-to-even."""
+    spec = O.ConvSpec(1, 4, 4, 32, 1, 1, 16)
+    x, w, _, _ = synth.conv_inputs(spec, 3)
+    mul = np.full(16, -0.25, np.float32)        # folded mul = +0.25 -> y = acc/2*... quarter steps
+    bias = np.linspace(-8, 7, 16).astype(np.float32)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=1.0, out_zero_point=0)
+    got, _ = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=1.0, out_zero_point=0)
+    assert np.array_equal(got, want)
+    f = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+    assert np.any(np.abs(f - np.trunc(f)) == 0.5), "test must contain exact ties"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.bool_])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (2, 3), (3, 16), (8, 32), (10, 33), (15, 63), (64, 64),
+                                       (7, 128), (3, 200), (33, 32), (5, 1024), (70, 96)])
+def test_bitpack_kernels(dtype, rows, cols):
+    g = synth.rng(rows * 1000 + cols)
+    if dtype == np.float32:
+        x = g.uniform(-1.5, 1.5, (rows, cols)).astype(np.float32)
+        x[0, 0] = -0.0
+        if cols > 2:
+            x[0, 1] = np.nan
+        zps = [0]
+    elif dtype == np.int8:
+        x = g.integers(-128, 128, (rows, cols)).astype(np.int8)
+        zps = [-1000, -128, -1, 0, 23, 127, 128]
+    else:
+        x = g.integers(0, 2, (rows, cols)).astype(np.bool_)
+        zps = [1]
+    for zp in zps:
+        want = O.bitpack(x, zp if dtype == np.int8 else 0)
+        assert np.array_equal(H.bitpack(x, zp), want)
+        assert np.array_equal(H.bitpack(x, zp, force_rows=True), want)
+
+
+@pytest.mark.parametrize("cols", [1, 2, 31, 32, 33, 64, 68])
+def test_quantize_dequantize_round_trip(cols):
+    """tflite/tests/quantization_test.cc:75-130."""
+    g = synth.rng(cols)
+    shape = (1, 4, 4, cols)
+    signs = np.where(g.random(shape) < 0.5, -1.0, 1.0).astype(np.float32)
+    assert np.array_equal(H.unpack(H.bitpack(signs), cols, np.float32), signs)
+    assert np.array_equal(H.unpack(O.bitpack(signs), cols, np.float32), O.unpack(O.bitpack(signs), cols, np.float32))
+    n, zp = int(g.integers(1, 21)), int(g.integers(-20, 21))
+    q = (zp + n * signs).astype(np.int8)
+    back = H.unpack(H.bitpack(q, zp), cols, np.int8, scale=np.float32(1.0) / np.float32(n), zero_point=zp)
+    assert np.array_equal(back, q)
+    b = signs > 0
+    assert np.array_equal(H.unpack(H.bitpack(b), cols, np.bool_), b)
+
+
+@pytest.mark.parametrize("f,s,pad", [((2, 2), (2, 2), O.PADDING_SAME), ((3, 3), (2, 2), O.PADDING_SAME),
+                                     ((3, 2), (1, 2), O.PADDING_VALID), ((2, 3), (3, 1), O.PADDING_SAME)])
+def test_bmaxpool(f, s, pad):
+    g = synth.rng(99)
+    x = synth.random_words(g, (2, 9, 7, 3))
+    assert np.array_equal(H.bmaxpool(x, f[0], f[1], s[0], s[1], pad), O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
