@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native LceBconv2d hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: the LceBconv2d
+layer of BASELINE.json configs[1] -- 3x3, 256->256 channels, 56x56, SAME padding with
+pad_values=1, batch 256 PER GPU, float32 output through the fused output transform --
+with the bitpacked input, packed weights and output resident in HBM.  For N > 1 (launched
+by torch.distributed.run, one rank per GPU) the batch dimension is sharded: every rank
+runs its own 256 images, there is no data-path collective, RCCL is used
+only for the barrier and the max-over-ranks of the elapsed time.  `value` is whole-job
+binary MACs per second.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (bconv2d_tiled): algorithmic bytes per launch / mean launch
+                duration (events on the launch stream) vs the 8 TB/s HBM peak.  The kernel
+                is integer-VALU bound, not HBM bound, so the `alu` object gives
+                the fraction of the v_xor+v_bcnt VALU peak as well.
+  cpu_baseline  the CPU oracle (a port of the reference's portable C++ path) on the host
+                cores, on a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_BMAC_PEAK = 256 * 4 * 32 * 2.4e9 * 32 / 2         # 256 CU x 4 SIMD-32 x 2.4 GHz, 2 VALU ops / 32 bMAC
+
+L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_out=256)
+QUICKNET = [(56, 64), (28, 128), (14, 256), (7, 512)]  # (H=W, C): 4 layers each in QuickNet
+
+
+def algorithmic_bytes(spec, dst) -> int:
+    """input words + weights + params + output, each counted once."""
+    import oracle_lib as O
+    inp = spec.batch * spec.in_h * spec.in_w * spec.in_words * 4
+    wts = spec.channels_out * spec.filter_h * spec.filter_w * spec.filter_words * 4
+    if dst == O.DST_BITPACKED:
+        params = spec.channels_out * 4
+        out = spec.batch * spec.out_h * spec.out_w * spec.out_words * 4
+    else:
+        params = spec.channels_out * 8
+        out = spec.batch * spec.out_h * spec.out_w * spec.channels_out * (4 if dst == O.DST_F32 else 1)
+    return inp + wts + params + out
+
+
+def time_layer(amd, torch, spec, dst, steps, warmup, seed, dev, scale=1.0, zp=0):
+    """Returns (mean seconds per launch from stream events, kernel name)."""
+    import oracle_lib as O
+    import synth
+    one = O.ConvSpec(**{**{k: getattr(spec, k) for k in (
+        "in_h", "in_w", "channels_in", "filter_h", "filter_w", "channels_out", "groups", "stride_h",
+        "stride_w", "dilation_h", "dilation_w", "padding", "pad_values", "activation", "semantics")},
+        "batch": 1})
+    _, w, mul, bias = synth.conv_inputs(one, seed)
+    g = synth.rng(seed + 7)
+    x = torch.from_numpy(synth.random_words(g, spec.input_shape(), spec.channels_in)).to(dev)
+    p = amd.ConvParams(spec.batch, spec.in_h, spec.in_w, spec.channels_in, spec.filter_h, spec.filter_w,
+                       spec.channels_out, spec.groups, spec.stride_h, spec.stride_w, spec.dilation_h,
+                       spec.dilation_w, spec.padding, spec.pad_values, spec.activation, dst,
+                       amd.SEM_OPTIMIZED, float(scale), int(zp))
+    plan = amd.Bconv2dPlan(p)
+    thr = O.thresholds_converter(one, mul, bias) if dst == amd.BITPACKED else None
+    plan.set_weights(w, mul, bias, thr)
+    dt = {amd.F32: torch.float32, amd.I8: torch.int8, amd.BITPACKED: torch.int32}[dst]
+    out = torch.empty(plan.output_shape, dtype=dt, device=dev)
+    for _ in range(warmup):
+        plan.run(x, out)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        plan.run(x, out)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / 1e3 / steps, plan.kernel_name(), plan, x, out
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Time the CPU oracle (port of the reference's portable path) on the L0 layer."""
+    import oracle_lib as O
+    import synth
+    cores = os.cpu_count() or 1
+    lib_note = "oracle/liblce_oracle.so (-O3 -march=x86-64-v3 -ffp-contract=off, OpenMP)"
+    one = O.ConvSpec(batch=1, padding=O.PADDING_SAME, pad_values=1, **L0)
+    x1, w, mul, bias = synth.conv_inputs(one, 1)
+    t = time.perf_counter()
+    O.bconv2d(one, O.DST_F32, x1, w, mul, bias, threads=1)
+    t1 = time.perf_counter() - t
+    per_image_parallel = t1 / max(1, cores) * 1.3
+    n = int(max(cores, min(256, target_seconds / max(per_image_parallel, 1e-6))))
+    spec = O.ConvSpec(batch=n, padding=O.PADDING_SAME, pad_values=1, **L0)
+    x = synth.random_words(synth.rng(2), spec.input_shape(), spec.channels_in)
+    t = time.perf_counter()
+    O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=cores)
+    dt = time.perf_counter() - t
+    return {"value": spec.binary_macs / dt, "unit": "binary-MAC/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of 256 images of the same layer, float output, {dt:.1f} s wall; "
+                      f"1 image on 1 thread: {t1 * 1e3:.1f} ms; {lib_note}",
+            "single_thread_value": one.binary_macs / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import oracle_lib as O
+    amd = importlib.import_module("compute-engine_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    spec = O.ConvSpec(batch=args.batch, padding=O.PADDING_SAME, pad_values=1, **L0)
+    # warm up + per-launch kernel time from stream events
+    k_sec, kname, plan, x, out = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev)
+
+    # the contract's timed region: barrier + sync, exactly K steps, sync + barrier, MAX over ranks
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[dev.index])
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(x, out)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_bmacs = spec.binary_macs * args.steps * world
+    value = total_bmacs / elapsed
+    abytes = algorithmic_bytes(spec, O.DST_F32)
+
+    result = {
+        "metric": "binary-MACs/sec (LceBconv2d 3x3 256->256, 56x56, batch 256/GPU, f32 out)",
+        "value": value, "unit": "binary-MAC/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32 xor+popcount (int32 accumulate), f32 epilogue",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: LceBconv2d 3x3 s1 SAME(pad_values=1) 56x56x256->256, "
+                               "float32 output transform, device-resident bitpacked input",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"batch-shard x{world} (no data-path collective)"},
+        "layer_latency_ms": k_sec * 1e3,
+        "per_gpu_value": value / world,
+        "kernel": kname,
+    }
+    if rank == 0:
+        ach = abytes / k_sec / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                              "algorithmic_bytes_per_launch": abytes,
+                              "kernel_ms": k_sec * 1e3,
+                              "note": "integer-VALU bound kernel; see alu"}
+        result["alu"] = {"achieved": spec.binary_macs / k_sec, "peak": VALU_BMAC_PEAK,
+                         "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
+                         "model": "v_xor_b32 + v_bcnt_u32_b32 per 32 bMAC; 256 CU x 4 SIMD-32 x 2.4 GHz"}
+        if not args.no_extra and world == 1:
+            extra = {}
+            st, wu = max(5, args.steps // 5), 3
+            sc, zp = 0.125, 3
+            for nm, dst, od in (("l0_int8_out", amd.I8, O.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, O.DST_BITPACKED)):
+                s, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
+                extra[nm] = {"ms": s * 1e3, "bmac_per_s": spec.binary_macs / s, "kernel": kn,
+                             "GBps_algorithmic": algorithmic_bytes(spec, od) / s / 1e9}
+            tot = 0.0
+            for hw, c in QUICKNET:
+                sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                                channels_out=c, padding=O.PADDING_SAME, pad_values=1)
+                s, kn, *_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
+                tot += 4 * s
+                extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {
+                    "ms": s * 1e3, "bmac_per_s": sp.binary_macs / s, "kernel": kn,
+                    "GBps_algorithmic": algorithmic_bytes(sp, O.DST_F32) / s / 1e9,
+                    "hbm_frac": algorithmic_bytes(sp, O.DST_F32) / s / 1e9 / HBM_PEAK_GBS}
+            extra["quicknet_16_layers_ms"] = tot * 1e3
+            # LceQuantize stream: float32 56x56x256 feature map, batch 256
+            fx = torch.randn((args.batch, 56, 56, 256), device=dev)
+            ow = amd.bitpack(fx)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(st):
+                amd.bitpack(fx, out=ow)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            s = e0.elapsed_time(e1) / 1e3 / st
+            qb = fx.numel() * 4 + ow.numel() * 4
+            extra["lcequantize_f32_256x56x56x256"] = {"ms": s * 1e3, "GBps_algorithmic": qb / s / 1e9,
+                                                      "hbm_frac": qb / s / 1e9 / HBM_PEAK_GBS}
+            del fx, ow
+            result["extra"] = extra
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,261 @@
+"""MI355X-native LceBconv2d / LceQuantize hot path -- thin Python binding of the C ABI.
+
+The product is the C-ABI shared library ``csrc/liblce_hip.so`` (hand-written gfx950
+kernels, declared in ``include/lce_hip.h``) plus the C++ TFLite op glue in
+``csrc/tflite/``.  This module only loads the library with ``ctypes`` and passes raw
+device pointers to it (PyTorch is used by callers purely to own HBM buffers and
+streams).  There is no fallback of any kind: if the library is missing or there is no
+GPU, calls raise.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("compute-engine_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblce_hip.so")
+
+# enums of include/lce_hip.h
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_NO_DEVICE = range(5)
+F32, I8, BITPACKED, BOOL = range(4)
+PADDING_SAME, PADDING_VALID = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU_N1_TO_1, ACT_RELU6 = range(4)
+SEM_REFERENCE, SEM_OPTIMIZED = 0, 1
+
+# every symbol include/lce_hip.h declares (tests check the library exports them all)
+ABI_SYMBOLS = (
+    "lce_hip_abi_version", "lce_hip_last_error", "lce_hip_device_count", "lce_hip_set_device",
+    "lce_hip_malloc", "lce_hip_free", "lce_hip_memcpy_h2d", "lce_hip_memcpy_d2h", "lce_hip_memset",
+    "lce_hip_stream_create", "lce_hip_stream_destroy", "lce_hip_stream_synchronize",
+    "lce_hip_bitpacked_size", "lce_hip_bitpack", "lce_hip_unpack",
+    "lce_hip_bconv2d_plan_create", "lce_hip_bconv2d_plan_destroy", "lce_hip_bconv2d_plan_output_shape",
+    "lce_hip_bconv2d_plan_padding", "lce_hip_bconv2d_plan_set_weights", "lce_hip_bconv2d_plan_folded",
+    "lce_hip_bconv2d_plan_set_option", "lce_hip_bconv2d_plan_kernel_name", "lce_hip_bconv2d_run",
+    "lce_hip_bconv2d_run_host", "lce_hip_bmaxpool_output_shape", "lce_hip_bmaxpool",
+)
+
+
+class LceHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"lce_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class Bconv2dDesc(C.Structure):
+    """``lce_hip_bconv2d_desc``."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "in_height", "in_width", "channels_in", "filter_height", "filter_width",
+        "channels_out", "groups", "stride_height", "stride_width", "dilation_height",
+        "dilation_width", "padding", "pad_values", "activation", "dst_type", "semantics")] + [
+        ("out_scale", C.c_float), ("out_zero_point", C.c_int32)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load ``liblce_hip.so``; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `make -C compute-engine_amd/csrc` "
+                "(there is no Python or CPU fallback for the HIP kernels)")
+        l = C.CDLL(LIB_PATH)
+        l.lce_hip_last_error.restype = C.c_char_p
+        l.lce_hip_bconv2d_plan_kernel_name.restype = C.c_char_p
+        l.lce_hip_bconv2d_plan_kernel_name.argtypes = [C.c_void_p]
+        l.lce_hip_bconv2d_plan_destroy.restype = None
+        l.lce_hip_bconv2d_plan_destroy.argtypes = [C.c_void_p]
+        l.lce_hip_bconv2d_plan_create.argtypes = [C.POINTER(Bconv2dDesc), C.POINTER(C.c_void_p)]
+        l.lce_hip_bconv2d_plan_output_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        l.lce_hip_bconv2d_plan_padding.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.lce_hip_bconv2d_plan_set_weights.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        l.lce_hip_bconv2d_plan_folded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.lce_hip_bconv2d_plan_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        l.lce_hip_bconv2d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.lce_hip_bconv2d_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.lce_hip_bitpack.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int32,
+                                      C.c_void_p, C.c_void_p]
+        l.lce_hip_unpack.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
+                                     C.c_int32, C.c_void_p, C.c_void_p]
+        l.lce_hip_bmaxpool.argtypes = [C.c_void_p] + [C.c_int32] * 9 + [C.c_void_p, C.c_void_p]
+        l.lce_hip_bmaxpool_output_shape.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_int32)] * 2
+        _lib = l
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise LceHipError(code, lib().lce_hip_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return lib().lce_hip_device_count()
+
+
+def bitpacked_size(n: int) -> int:
+    return (n + 31) // 32
+
+
+def _host_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class ConvParams:
+    """The LceBconv2d attributes (tflite/kernels/bconv2d.cc:94-124) plus tensor metadata."""
+    batch: int
+    in_height: int
+    in_width: int
+    channels_in: int
+    filter_height: int
+    filter_width: int
+    channels_out: int
+    groups: int = 1
+    stride_height: int = 1
+    stride_width: int = 1
+    dilation_height: int = 1
+    dilation_width: int = 1
+    padding: int = PADDING_VALID
+    pad_values: int = 0
+    activation: int = ACT_NONE
+    dst_type: int = F32
+    semantics: int = SEM_OPTIMIZED
+    out_scale: float = 1.0
+    out_zero_point: int = 0
+
+    def desc(self) -> Bconv2dDesc:
+        return Bconv2dDesc(self.batch, self.in_height, self.in_width, self.channels_in,
+                           self.filter_height, self.filter_width, self.channels_out, self.groups,
+                           self.stride_height, self.stride_width, self.dilation_height,
+                           self.dilation_width, self.padding, self.pad_values, self.activation,
+                           self.dst_type, self.semantics, float(self.out_scale),
+                           int(self.out_zero_point))
+
+
+class Bconv2dPlan:
+    """Owns one ``lce_hip_bconv2d_plan`` (Prepare + OneTimeSetup of one LceBconv2d node)."""
+
+    def __init__(self, params: ConvParams):
+        self.params = params
+        self._h = C.c_void_p()
+        d = params.desc()
+        check(lib().lce_hip_bconv2d_plan_create(C.byref(d), C.byref(self._h)))
+        dims = (C.c_int32 * 4)()
+        check(lib().lce_hip_bconv2d_plan_output_shape(self._h, dims))
+        self.output_shape = tuple(dims)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().lce_hip_bconv2d_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def padding(self):
+        ph, pw = C.c_int32(), C.c_int32()
+        check(lib().lce_hip_bconv2d_plan_padding(self._h, C.byref(ph), C.byref(pw)))
+        return ph.value, pw.value
+
+    def set_weights(self, filter_ohwi, post_mul=None, post_bias=None, thresholds=None):
+        """Host numpy arrays: int32 OHWI filter words, float32 [Cout] x2, int32 [Cout]."""
+        import numpy as np
+        f = np.ascontiguousarray(filter_ohwi, np.int32)
+        m = None if post_mul is None else np.ascontiguousarray(post_mul, np.float32)
+        b = None if post_bias is None else np.ascontiguousarray(post_bias, np.float32)
+        t = None if thresholds is None else np.ascontiguousarray(thresholds, np.int32)
+        check(lib().lce_hip_bconv2d_plan_set_weights(self._h, _host_ptr(f), _host_ptr(m),
+                                                     _host_ptr(b), _host_ptr(t)))
+
+    def folded(self):
+        import numpy as np
+        n = self.params.channels_out
+        mul, bias = np.empty(n, np.float32), np.empty(n, np.float32)
+        lo, hi = C.c_int32(), C.c_int32()
+        check(lib().lce_hip_bconv2d_plan_folded(self._h, _host_ptr(mul), _host_ptr(bias),
+                                                C.byref(lo), C.byref(hi)))
+        return mul, bias, lo.value, hi.value
+
+    def set_option(self, key: str, value: str):
+        check(lib().lce_hip_bconv2d_plan_set_option(self._h, key.encode(), value.encode()))
+
+    def kernel_name(self) -> str:
+        return lib().lce_hip_bconv2d_plan_kernel_name(self._h).decode()
+
+    def run_ptr(self, input_dev: int, output_dev: int, stream: int = 0):
+        check(lib().lce_hip_bconv2d_run(self._h, C.c_void_p(input_dev), C.c_void_p(output_dev),
+                                        C.c_void_p(stream)))
+
+    def run(self, x, out=None, stream: int | None = None):
+        """x: CUDA int32 tensor [B,H,W,ceil(Cin/32)]; returns / fills the output tensor."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.int32 and x.is_contiguous()
+        if out is None:
+            dt = {F32: torch.float32, I8: torch.int8, BITPACKED: torch.int32}[self.params.dst_type]
+            out = torch.empty(self.output_shape, dtype=dt, device=x.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        self.run_ptr(x.data_ptr(), out.data_ptr(), stream)
+        return out
+
+    def run_host(self, x_np):
+        import numpy as np
+        x = np.ascontiguousarray(x_np, np.int32)
+        dt = {F32: np.float32, I8: np.int8, BITPACKED: np.int32}[self.params.dst_type]
+        out = np.empty(self.output_shape, dt)
+        check(lib().lce_hip_bconv2d_run_host(self._h, _host_ptr(x), _host_ptr(out)))
+        return out
+
+
+def bitpack(x, zero_point: int = 0, out=None, stream: int | None = None):
+    """LceQuantize on a CUDA tensor (float32 / int8 / bool), packing the last axis."""
+    import torch
+    assert x.is_cuda and x.is_contiguous()
+    t = {torch.float32: F32, torch.int8: I8, torch.bool: BOOL}[x.dtype]
+    cols = x.shape[-1]
+    rows = x.numel() // cols if cols else 0
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (bitpacked_size(cols),), dtype=torch.int32, device=x.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+    check(lib().lce_hip_bitpack(t, C.c_void_p(x.data_ptr()), rows, cols, int(zero_point),
+                                C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    return out
+
+
+def unpack(words, channels: int, dtype, scale: float = 1.0, zero_point: int = 0, stream: int | None = None):
+    """LceDequantize on a CUDA int32 tensor."""
+    import torch
+    assert words.is_cuda and words.dtype == torch.int32 and words.is_contiguous()
+    t = {torch.float32: F32, torch.int8: I8, torch.bool: BOOL}[dtype]
+    rows = words.numel() // words.shape[-1]
+    out = torch.empty(tuple(words.shape[:-1]) + (channels,), dtype=dtype, device=words.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(words.device).cuda_stream
+    check(lib().lce_hip_unpack(t, C.c_void_p(words.data_ptr()), rows, channels, float(scale),
+                               int(zero_point), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    return out
+
+
+def bmaxpool(x, filter_height, filter_width, stride_height, stride_width, padding, stream: int | None = None):
+    """LceBMaxPool2d on a CUDA int32 tensor [B,H,W,words]."""
+    import torch
+    assert x.is_cuda and x.dtype == torch.int32 and x.is_contiguous() and x.dim() == 4
+    b, h, w, c = x.shape
+    oh, ow = C.c_int32(), C.c_int32()
+    check(lib().lce_hip_bmaxpool_output_shape(h, w, filter_height, filter_width, stride_height,
+                                              stride_width, padding, C.byref(oh), C.byref(ow)))
+    out = torch.empty((b, oh.value, ow.value, c), dtype=torch.int32, device=x.device)
+    if stream is None:
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+    check(lib().lce_hip_bmaxpool(C.c_void_p(x.data_ptr()), b, h, w, c, filter_height, filter_width,
+                                 stride_height, stride_width, padding, C.c_void_p(out.data_ptr()),
+                                 C.c_void_p(stream)))
+    return out

@@ -1,0 +1,128 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/lce_hip.h declares, does Prepare-style validation / shape inference / parameter
+folding without a GPU, and FAILS LOUDLY (no fallback) when asked to compute without one."""
+import ctypes as C
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+from lce_amd import amd
+from test_oracle_vs_float_conv import CASES, PADS, legal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "lce_hip.h")).read()
+    declared = set(re.findall(r"\b(lce_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(amd.ABI_SYMBOLS), declared ^ set(amd.ABI_SYMBOLS)
+    lib = amd.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.lce_hip_abi_version() == 1
+
+
+def _params(spec: O.ConvSpec, dst, **kw):
+    return amd.ConvParams(spec.batch, spec.in_h, spec.in_w, spec.channels_in, spec.filter_h,
+                          spec.filter_w, spec.channels_out, spec.groups, spec.stride_h, spec.stride_w,
+                          spec.dilation_h, spec.dilation_w, spec.padding, spec.pad_values,
+                          spec.activation, dst, spec.semantics, **kw)
+
+
+def test_shape_inference_matches_oracle_on_reference_grid():
+    seen = 0
+    for case in CASES[::5]:
+        inp, flt, g, st, dil, pad, act = case
+        if not legal(inp, flt, g, pad, O.SEM_REFERENCE):
+            continue
+        padding, pv = PADS[pad]
+        spec = O.ConvSpec(inp[0], inp[1], inp[2], inp[3], flt[0], flt[1], flt[2], g, st[0], st[1],
+                          dil[0], dil[1], padding, pv, act, O.SEM_REFERENCE)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            with pytest.raises(amd.LceHipError):
+                amd.Bconv2dPlan(_params(spec, amd.F32))
+            continue
+        for dst in (amd.F32, amd.I8, amd.BITPACKED):
+            plan = amd.Bconv2dPlan(_params(spec, dst))
+            assert plan.output_shape == spec.output_shape(dst)
+            assert plan.padding() == (spec.pad_h, spec.pad_w)
+            plan.close()
+            seen += 1
+    assert seen > 100
+
+
+@pytest.mark.parametrize("dst,act", itertools.product((amd.F32, amd.I8), (0, 1, 2, 3)))
+def test_folding_matches_oracle(dst, act):
+    """OneTimeSetup (tflite/kernels/bconv2d.cc:324-392), bit for bit."""
+    spec = O.ConvSpec(1, 6, 6, 96, 3, 3, 40, padding=O.PADDING_SAME, pad_values=1, activation=act)
+    _, filt, mul, bias = synth.conv_inputs(spec, 17 + act, negative_mul_fraction=0.25)
+    scale, zp = synth.int8_quant_params(5)
+    plan = amd.Bconv2dPlan(_params(spec, dst, out_scale=float(scale), out_zero_point=zp))
+    plan.set_weights(filt, mul, bias)
+    got = plan.folded()
+    want = O.fold_output_transform(spec, dst, mul, bias, float(scale), zp)
+    assert np.array_equal(got[0].view(np.int32), want[0].view(np.int32))
+    assert np.array_equal(got[1].view(np.int32), want[1].view(np.int32))
+    assert got[2:] == want[2:]
+    a = spec.backtransform_add          # NONE [0,2a], RELU [0,a], RELU6 [a-6,a], N1_TO_1 [a-1,a+1]
+    assert got[2:] == {0: (0, 2 * a), 1: (0, a), 3: (a - 6, a), 2: (a - 1, a + 1)}[act]
+
+
+def test_prepare_rejections_match_reference_messages():
+    """bconv2d.cc:109-112,173-200 and the death tests bconv2d_test.cc:858-917."""
+    base = dict(batch=1, in_height=16, in_width=16, channels_in=64, filter_height=3, filter_width=3,
+                channels_out=128, padding=amd.PADDING_SAME, pad_values=0)
+    for kw in (dict(dst_type=amd.F32, activation=amd.ACT_RELU, semantics=amd.SEM_OPTIMIZED),
+               dict(dst_type=amd.BITPACKED, semantics=amd.SEM_OPTIMIZED),
+               dict(dst_type=amd.I8, semantics=amd.SEM_OPTIMIZED)):
+        with pytest.raises(amd.LceHipError, match="Zero-padding is only supported by"):
+            amd.Bconv2dPlan(amd.ConvParams(**base, **kw))
+    # the reference registration accepts all three as long as channels_in is even
+    for dst in (amd.F32, amd.I8, amd.BITPACKED):
+        amd.Bconv2dPlan(amd.ConvParams(**base, dst_type=dst, semantics=amd.SEM_REFERENCE)).close()
+    odd = dict(base, channels_in=33)
+    with pytest.raises(amd.LceHipError, match="Zero-padding is only supported by"):
+        amd.Bconv2dPlan(amd.ConvParams(**odd, semantics=amd.SEM_REFERENCE))
+    with pytest.raises(amd.LceHipError, match="pad_values must be 0 or 1"):
+        amd.Bconv2dPlan(amd.ConvParams(**dict(base, pad_values=2)))
+    with pytest.raises(amd.LceHipError):      # group size must be a multiple of 32 (:180-185)
+        amd.Bconv2dPlan(amd.ConvParams(**dict(base, groups=4, pad_values=1)))
+    with pytest.raises(amd.LceHipError):      # channels_out % groups (:186)
+        amd.Bconv2dPlan(amd.ConvParams(**dict(base, groups=2, channels_out=127, pad_values=1)))
+
+
+def test_kernel_selection_is_host_side_and_named():
+    spec = O.ConvSpec(256, 56, 56, 256, 3, 3, 256, padding=O.PADDING_SAME, pad_values=1)
+    _, filt, mul, bias = synth.conv_inputs(O.ConvSpec(1, 3, 3, 256, 3, 3, 256), 1)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(filt, mul, bias)
+    assert plan.kernel_name().startswith("bconv2d_tiled<f32,TM=")
+    plan.set_option("kernel", "general")
+    assert plan.kernel_name() == "bconv2d_general<f32>"
+    plan.set_option("kernel", "tiled")
+    plan.set_option("tile", "1x32")
+    assert plan.kernel_name() == "bconv2d_tiled<f32,TM=1,TN=32,CH=4>"
+    with pytest.raises(amd.LceHipError):
+        plan.set_option("tile", "3x7")
+
+
+@pytest.mark.skipif(amd.device_count() > 0, reason="this test is about the GPU-less container")
+def test_compute_fails_loudly_without_a_gpu():
+    """No CPU fallback: the product must not quietly compute on the host."""
+    spec = O.ConvSpec(1, 4, 4, 64, 3, 3, 16)
+    x, filt, mul, bias = synth.conv_inputs(spec, 1)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(filt, mul, bias)
+    with pytest.raises(amd.LceHipError) as e:
+        plan.run_host(x)
+    assert e.value.code == amd.ERR_NO_DEVICE and "no CPU fallback" in e.value.message
+    buf = np.zeros(64, np.float32)
+    out = np.zeros(2, np.int32)
+    rc = amd.lib().lce_hip_bitpack(amd.F32, buf.ctypes.data_as(C.c_void_p), 1, 64, 0,
+                                   out.ctypes.data_as(C.c_void_p), None)
+    assert rc == amd.ERR_NO_DEVICE

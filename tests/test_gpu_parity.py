@@ -1,0 +1,354 @@
+"""GPU parity tests: the hand-written gfx950 kernels, called through the C ABI
+(include/lce_hip.h), against the CPU oracle on the same seeded inputs, against the
+committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties.
+
+Bars: int8 and bitpacked outputs bit-exact; float outputs bit-exact too (the north star
+asks for 1e-5; VALID / SAME-one / SAME-zero all reproduce the reference's rounding
+sequence exactly, so the tests ask for equality of the bit patterns)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import oracle_lib as O
+import synth
+from lce_amd import amd
+from test_oracle_vs_float_conv import CASES, PADS, _id, legal
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TILES = ["4x16", "2x32", "2x16", "1x32", "1x16"]
+
+
+def _params(spec, dst, **kw):
+    return amd.ConvParams(spec.batch, spec.in_h, spec.in_w, spec.channels_in, spec.filter_h,
+                          spec.filter_w, spec.channels_out, spec.groups, spec.stride_h, spec.stride_w,
+                          spec.dilation_h, spec.dilation_w, spec.padding, spec.pad_values,
+                          spec.activation, dst, spec.semantics, **kw)
+
+
+def _gpu_conv(spec, dst, x, w, mul=None, bias=None, thr=None, scale=1.0, zp=0, kernel="auto", tile="auto",
+              poison=True):
+    plan = amd.Bconv2dPlan(_params(spec, dst, out_scale=float(scale), out_zero_point=int(zp)))
+    plan.set_weights(w, mul, bias, thr)
+    plan.set_option("kernel", kernel)
+    plan.set_option("tile", tile)
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    dt = {amd.F32: torch.float32, amd.I8: torch.int8, amd.BITPACKED: torch.int32}[dst]
+    out = torch.full(plan.output_shape, 0x5A if dst == amd.I8 else -7, dtype=dt, device=DEV)
+    plan.run(xd, out)
+    torch.cuda.synchronize()
+    name = plan.kernel_name()
+    return out.cpu().numpy(), name
+
+
+def _check_all_dst(spec, seed, kernel="auto", tile="auto"):
+    x, w, mul, bias = synth.conv_inputs(spec, seed)
+    zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
+    names = []
+    if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel, tile=tile)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), n
+        names.append(n)
+    if zero_pad and spec.semantics == O.SEM_OPTIMIZED:
+        return names
+    scale, zp = synth.int8_quant_params(seed)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
+    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel, tile=tile)
+    assert np.array_equal(got, want), n
+    names.append(n)
+    if tile in ("auto", "2x32", "1x32"):
+        thr = O.thresholds_converter(spec, mul, bias)
+        thr[::5] = np.iinfo(np.int32).max
+        thr[1::7] = np.iinfo(np.int32).min
+        want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
+        got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, kernel=kernel, tile=tile)
+        assert np.array_equal(got, want), n
+        names.append(n)
+    return names
+
+
+def test_native_library_is_the_thing_under_test():
+    assert amd.device_count() >= 1
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ------------------------------------------------------------------------------------ LceQuantize
+
+@pytest.mark.parametrize("name,x,zp,want", list(G.bitpack_cases()), ids=lambda v: v if isinstance(v, str) else "")
+def test_bitpack_golden(name, x, zp, want):
+    got = amd.bitpack(torch.from_numpy(x).to(DEV), zp).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 8, 10, 15, 64])
+@pytest.mark.parametrize("cols", [1, 3, 16, 32, 33, 63, 64, 128])
+def test_bitpack_reference_grid(rows, cols):
+    """core/bitpacking/tests/bitpack_test.cc:19-110: every bit, padding bits zero."""
+    g = synth.rng(rows * 131 + cols)
+    f = g.uniform(-1.5, 1.5, (rows, cols)).astype(np.float32)
+    assert np.array_equal(amd.bitpack(torch.from_numpy(f).to(DEV)).cpu().numpy(), O.bitpack(f))
+    q = g.integers(-128, 128, (rows, cols)).astype(np.int8)
+    for zp in (-1000, -1, 0, 23, 127, 128):
+        assert np.array_equal(amd.bitpack(torch.from_numpy(q).to(DEV), zp).cpu().numpy(), O.bitpack(q, zp))
+
+
+@pytest.mark.parametrize("shape", [(1, 56, 56, 256), (3, 28, 28, 128), (2, 7, 7, 96), (5, 1000), (4097, 32), (1, 31)])
+def test_bitpack_streams(shape):
+    g = synth.rng(sum(shape))
+    f = g.standard_normal(shape).astype(np.float32)
+    assert np.array_equal(amd.bitpack(torch.from_numpy(f).to(DEV)).cpu().numpy(), O.bitpack(f))
+    q = g.integers(-128, 128, shape).astype(np.int8)
+    assert np.array_equal(amd.bitpack(torch.from_numpy(q).to(DEV), 3).cpu().numpy(), O.bitpack(q, 3))
+    b = g.integers(0, 2, shape).astype(np.bool_)
+    assert np.array_equal(amd.bitpack(torch.from_numpy(b).to(DEV)).cpu().numpy(), O.bitpack(b))
+
+
+def test_bitpack_one_hot_bit_order():
+    """core/bitpacking/tests/bitpack_aarch64_test.cc:17-56 (LSB-first order)."""
+    n = 32 * 4 * 3
+    for dtype, zp in ((np.float32, 0), (np.int8, -42)):
+        x = np.full((n, n), zp + 5, dtype)
+        x[np.arange(n), np.arange(n)] = zp - 5
+        words = amd.bitpack(torch.from_numpy(x).to(DEV), zp).cpu().numpy().view(np.uint32)
+        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(n, -1)
+        assert np.array_equal(bits, np.eye(n, dtype=bits.dtype))
+
+
+@pytest.mark.parametrize("cols", [1, 2, 31, 32, 33, 64, 68])
+def test_quantize_dequantize_round_trip(cols):
+    """tflite/tests/quantization_test.cc:75-130."""
+    g = synth.rng(cols)
+    signs = np.where(g.random((1, 4, 4, cols)) < 0.5, -1.0, 1.0).astype(np.float32)
+    w = amd.bitpack(torch.from_numpy(signs).to(DEV))
+    assert np.array_equal(amd.unpack(w, cols, torch.float32).cpu().numpy(), signs)
+    n, zp = int(g.integers(1, 21)), int(g.integers(-20, 21))
+    q = (zp + n * signs).astype(np.int8)
+    wq = amd.bitpack(torch.from_numpy(q).to(DEV), zp)
+    back = amd.unpack(wq, cols, torch.int8, scale=float(np.float32(1.0) / np.float32(n)), zero_point=zp)
+    assert np.array_equal(back.cpu().numpy(), q)
+    b = signs > 0
+    assert np.array_equal(amd.unpack(amd.bitpack(torch.from_numpy(b).to(DEV)), cols, torch.bool).cpu().numpy(), b)
+
+
+def test_bitpack_empty_and_errors():
+    e = torch.empty((0, 32), dtype=torch.float32, device=DEV)
+    assert amd.bitpack(e).shape == (0, 1)
+    with pytest.raises(amd.LceHipError):
+        amd.bitpack(torch.zeros((1, 32), device=DEV), zero_point=3)   # float needs zero_point 0
+
+
+# ------------------------------------------------------------------------------------ LceBconv2d
+
+@pytest.mark.parametrize("name,spec,d", list(G.conv_cases()), ids=lambda v: v if isinstance(v, str) else "")
+def test_conv_golden(name, spec, d):
+    scale, zp = float(d["int8_scale_zp"][0]), int(d["int8_scale_zp"][1])
+    x, w, mul, bias = d["input"], d["filter"], d["post_mul"], d["post_bias"]
+    for kernel in ("auto", "general"):
+        got, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel)
+        assert np.array_equal(got.view(np.int32), d["out_f32"].view(np.int32))
+        if "out_i8" in d:
+            got, _ = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel)
+            assert np.array_equal(got, d["out_i8"])
+            got, _ = _gpu_conv(spec, amd.BITPACKED, x, w, thr=d["thresholds"], kernel=kernel)
+            assert np.array_equal(got, d["out_bitpacked"])
+
+
+GRID = CASES[:72] + CASES[72::5]
+
+
+@pytest.mark.parametrize("case", GRID, ids=_id)
+def test_conv_reference_grid(case):
+    """The reference's op-test grid (tflite/tests/bconv2d_test.cc:790-856) for both
+    registrations' semantics, all three output types."""
+    inp, flt, g, st, dil, pad, act = case
+    for sem in (O.SEM_REFERENCE, O.SEM_OPTIMIZED):
+        if not legal(inp, flt, g, pad, sem):
+            continue
+        padding, pv = PADS[pad]
+        spec = O.ConvSpec(inp[0], inp[1], inp[2], inp[3], flt[0], flt[1], flt[2], g, st[0], st[1],
+                          dil[0], dil[1], padding, pv, act, sem)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF)
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("cin,cout,groups", [(64, 64, 1), (32, 40, 1), (96, 33, 1), (128, 64, 2),
+                                             (256, 128, 4), (20, 7, 1), (160, 96, 1), (512, 64, 1)])
+@pytest.mark.parametrize("pad", ["VALID", "SAME", "ONE"])
+def test_conv_every_tile_shape(tile, cin, cout, groups, pad):
+    tn = int(tile.split("x")[1])
+    if groups > 1 and (cout // groups) % tn:
+        pytest.skip("tile would straddle groups")
+    padding, pv = PADS[pad]
+    for sem, st, dil, act in [(O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_NONE),
+                              (O.SEM_OPTIMIZED, (2, 1), (1, 2), O.ACT_NONE),
+                              (O.SEM_REFERENCE, (1, 2), (2, 1), O.ACT_RELU)]:
+        if pad == "SAME" and sem == O.SEM_REFERENCE and cin % 2:
+            continue
+        spec = O.ConvSpec(3, 9, 11, cin, 3, 3, cout, groups, st[0], st[1], dil[0], dil[1], padding, pv, act, sem)
+        names = _check_all_dst(spec, cin * 7 + cout, kernel="tiled", tile=tile)
+        assert all(("TM=%s,TN=%s" % tuple(tile.split("x"))) in n for n in names), names
+
+
+def test_conv_accumulator_overflow_shape():
+    """bconv2d_test.cc:813-828: 5x5x3072 would overflow 16-bit accumulators."""
+    for pad in ("VALID", "ONE"):
+        padding, pv = PADS[pad]
+        spec = O.ConvSpec(1, 6, 6, 3072, 5, 5, 4, padding=padding, pad_values=pv, activation=O.ACT_RELU)
+        _check_all_dst(spec, 77)
+
+
+@pytest.mark.parametrize("act", [O.ACT_NONE, O.ACT_RELU, O.ACT_RELU_N1_TO_1, O.ACT_RELU6])
+def test_conv_fused_activations(act):
+    spec = O.ConvSpec(2, 14, 14, 256, 3, 3, 256, padding=O.PADDING_SAME, pad_values=1, activation=act)
+    _check_all_dst(spec, 5 + act)
+
+
+def test_conv_int8_exact_ties():
+    spec = O.ConvSpec(1, 4, 4, 32, 1, 1, 16)
+    x, w, _, _ = synth.conv_inputs(spec, 3)
+    mul = np.full(16, -0.25, np.float32)
+    bias = np.linspace(-8, 7, 16).astype(np.float32)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias)
+    for kernel in ("auto", "general"):
+        got, _ = _gpu_conv(spec, amd.I8, x, w, mul, bias, kernel=kernel)
+        assert np.array_equal(got, want)
+
+
+def test_conv_adversarial_words():
+    """All-zero / all-one activations and weights (SURVEY 8(d) adversarial fixtures)."""
+    spec = O.ConvSpec(1, 8, 8, 160, 3, 3, 33, padding=O.PADDING_SAME, pad_values=1)
+    _, _, mul, bias = synth.conv_inputs(spec, 9)
+    for xv, wv in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+        x = np.full(spec.input_shape(), xv, np.int32)
+        w = np.full(spec.filter_shape(), wv, np.int32)
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        got, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
+def test_run_host_matches_device_run():
+    spec = O.ConvSpec(2, 14, 14, 128, 3, 3, 128, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 21)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    a = plan.run_host(x)
+    b = plan.run(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+    assert np.array_equal(a, b) and np.array_equal(a.view(np.int32), want.view(np.int32))
+
+
+def test_plan_reuse_and_reweight():
+    """Prepare may run again with new constants (bconv2d.cc:295-297)."""
+    spec = O.ConvSpec(1, 7, 7, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    for seed in (1, 2):
+        x, w, mul, bias = synth.conv_inputs(spec, seed)
+        plan.set_weights(w, mul, bias)
+        got = plan.run(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
+# ------------------------------------------------------------------------------------ full size (BASELINE configs)
+
+L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_out=256,
+          padding=O.PADDING_SAME, pad_values=1)
+
+
+@pytest.mark.parametrize("dst", [amd.F32, amd.I8, amd.BITPACKED])
+def test_l0_batch256_properties(dst):
+    """BASELINE config 2: 3x3 256->256 on 56x56, batch 256.
+    (a) a seeded 4-image subset is bit-exact vs the CPU oracle;
+    (b) batch independence: image i of the batched run == the same image run alone;
+    (c) the tiled kernel and the independently written general kernel agree on a
+        checksum of all 256 images;
+    (d) permuting the batch permutes the output."""
+    B = 256
+    spec = O.ConvSpec(batch=B, **L0)
+    one = O.ConvSpec(batch=1, **L0)
+    x, w, mul, bias = synth.conv_inputs(spec, 256)
+    thr = O.thresholds_converter(spec, mul, bias)
+    scale, zp = synth.int8_quant_params(256)
+    kw = dict(mul=mul, bias=bias) if dst != amd.BITPACKED else dict(thr=thr)
+    if dst == amd.I8:
+        kw.update(scale=scale, zp=zp)
+    got, name = _gpu_conv(spec, dst, x, w, **kw)
+    assert name.startswith("bconv2d_tiled")
+    # (a)
+    subset = [0, 97, 200, 255]
+    sub_spec = O.ConvSpec(batch=len(subset), **L0)
+    odst = {amd.F32: O.DST_F32, amd.I8: O.DST_I8, amd.BITPACKED: O.DST_BITPACKED}[dst]
+    want = O.bconv2d(sub_spec, odst, x[subset], w, mul, bias, thresholds=thr, out_scale=float(scale),
+                     out_zero_point=zp, threads=8)
+    assert np.array_equal(got[subset].view(np.uint8), want.view(np.uint8))
+    # (b)
+    alone, _ = _gpu_conv(one, dst, x[97:98], w, **kw)
+    assert np.array_equal(alone[0].view(np.uint8), got[97].view(np.uint8))
+    # (c)
+    gen, gname = _gpu_conv(spec, dst, x, w, kernel="general", **kw)
+    assert gname.startswith("bconv2d_general")
+    assert zlib.crc32(gen.tobytes()) == zlib.crc32(got.tobytes())
+    # (d)
+    perm = synth.rng(1).permutation(B)
+    permuted, _ = _gpu_conv(spec, dst, x[perm], w, **kw)
+    assert np.array_equal(permuted.view(np.uint8), got[perm].view(np.uint8))
+
+
+QUICKNET_LAYERS = [(56, 64), (28, 128), (14, 256), (7, 512)]
+
+
+@pytest.mark.parametrize("hw,c", QUICKNET_LAYERS)
+def test_quicknet_layer_shapes_batch256(hw, c):
+    """BASELINE config 3 layer shapes at batch 256: tiled vs general kernel agreement on
+    everything + oracle on a 3-image subset."""
+    B = 256
+    kwargs = dict(in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=c,
+                  padding=O.PADDING_SAME, pad_values=1)
+    spec = O.ConvSpec(batch=B, **kwargs)
+    x, w, mul, bias = synth.conv_inputs(spec, hw)
+    got, name = _gpu_conv(spec, amd.F32, x, w, mul, bias)
+    gen, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel="general")
+    assert np.array_equal(got.view(np.int32), gen.view(np.int32)), name
+    subset = [0, 128, 255]
+    want = O.bconv2d(O.ConvSpec(batch=3, **kwargs), O.DST_F32, x[subset], w, mul, bias, threads=8)
+    assert np.array_equal(got[subset].view(np.int32), want.view(np.int32))
+
+
+def test_birealnet_style_int8_stack():
+    """BASELINE config 5 flavour: 1x1 and strided 3x3 layers with int8 output and a RELU
+    clamp, chained through LceQuantize on the device (int8 -> bitpacked -> bconv)."""
+    g = synth.rng(55)
+    B, H, C = 32, 28, 128
+    act = g.integers(-128, 128, (B, H, H, C)).astype(np.int8)
+    in_zp = 5
+    xw_gpu = amd.bitpack(torch.from_numpy(act).to(DEV), in_zp)
+    xw = O.bitpack(act, in_zp)
+    assert np.array_equal(xw_gpu.cpu().numpy(), xw)
+    for (k, s, cout) in ((1, 1, 128), (3, 2, 256), (1, 1, 64)):
+        spec = O.ConvSpec(B, H, H, C, k, k, cout, stride_h=s, stride_w=s, padding=O.PADDING_SAME,
+                          pad_values=1, activation=O.ACT_RELU)
+        _, w, mul, bias = synth.conv_inputs(spec, k * 10 + s)
+        scale, zp = synth.int8_quant_params(k * 10 + s)
+        want = O.bconv2d(spec, O.DST_I8, xw, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=8)
+        plan = amd.Bconv2dPlan(_params(spec, amd.I8, out_scale=float(scale), out_zero_point=zp))
+        plan.set_weights(w, mul, bias)
+        got = plan.run(xw_gpu).cpu().numpy()
+        assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------ LceBMaxPool2d
+
+@pytest.mark.parametrize("f,s,pad", [((2, 2), (2, 2), O.PADDING_SAME), ((3, 3), (2, 2), O.PADDING_SAME),
+                                     ((3, 2), (1, 2), O.PADDING_VALID), ((2, 3), (3, 1), O.PADDING_SAME)])
+def test_bmaxpool(f, s, pad):
+    x = synth.random_words(synth.rng(99), (4, 19, 17, 3))
+    got = amd.bmaxpool(torch.from_numpy(x).to(DEV), f[0], f[1], s[0], s[1], pad).cpu().numpy()
+    assert np.array_equal(got, O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Times every tiled-kernel variant on the BASELINE layer shapes (GPU box only).
+Prints one JSON line per (layer, dst, tile)."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import bench  # noqa: E402
+
+amd = importlib.import_module("compute-engine_amd")
+dev = torch.device("cuda:0")
+B = int(os.environ.get("SWEEP_BATCH", "256"))
+steps = int(os.environ.get("SWEEP_STEPS", "10"))
+layers = [("L0_56x56x256", 56, 256)] + [(f"qn_{hw}x{hw}x{c}", hw, c) for hw, c in bench.QUICKNET]
+dsts = [("f32", amd.F32, O.DST_F32), ("i8", amd.I8, O.DST_I8), ("bp", amd.BITPACKED, O.DST_BITPACKED)]
+tiles = ["4x16", "2x32", "2x16", "1x32", "1x16"]
+only = set(sys.argv[1:])
+for lname, hw, c in layers:
+    spec = O.ConvSpec(batch=B, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=c,
+                      padding=O.PADDING_SAME, pad_values=1)
+    for dname, dst, od in dsts:
+        if only and dname not in only and lname not in only:
+            continue
+        for tile in tiles:
+            if dst == amd.BITPACKED and not tile.endswith("32"):
+                continue
+            os.environ["LCE_SWEEP_TILE"] = tile
+            import synth
+            one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                             channels_out=c, padding=O.PADDING_SAME, pad_values=1)
+            _, w, mul, bias = synth.conv_inputs(one, 3)
+            x = torch.from_numpy(synth.random_words(synth.rng(4), spec.input_shape(), c)).to(dev)
+            p = amd.ConvParams(B, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
+                               out_scale=0.125, out_zero_point=3)
+            plan = amd.Bconv2dPlan(p)
+            plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
+            plan.set_option("kernel", "tiled")
+            plan.set_option("tile", tile)
+            out = plan.run(x)
+            for _ in range(2):
+                plan.run(x, out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                plan.run(x, out)
+            e1.record()
+            torch.cuda.synchronize()
+            s = e0.elapsed_time(e1) / 1e3 / steps
+            print(json.dumps({"layer": lname, "dst": dname, "tile": tile, "kernel": plan.kernel_name(),
+                              "ms": round(s * 1e3, 4), "Tbmac_per_s": round(spec.binary_macs / s / 1e12, 2),
+                              "alu_frac": round(spec.binary_macs / s / bench.VALU_BMAC_PEAK, 3),
+                              "GBps": round(bench.algorithmic_bytes(spec, od) / s / 1e9, 1)}), flush=True)
+            del plan, out, x
