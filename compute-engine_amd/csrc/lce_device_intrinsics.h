@@ -59,6 +59,16 @@ LCE_DEVICE unsigned long long wave_ballot(bool p) { return __ballot(p); }
 LCE_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
 LCE_DEVICE float round_half_away(float y) { return roundf(y); }  // std::round semantics
 
+// a * b + c with TWO roundings, as the reference's portable C++ computes it
+// (core/bconv2d/output_transform.h:105).  hipcc contracts `a * b + c` -- and even
+// __fadd_rn(__fmul_rn(a, b), c) -- into v_fma_f32 / v_pk_fma_f32 under its default
+// -ffp-contract=fast; the empty asm makes the product opaque so it cannot be fused.
+LCE_DEVICE float mul_then_add(float a, float b, float c) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p + c;
+}
+
 // acc_i += popcount(a_i ^ w) for TM independent activations against ONE weight word.
 // Hand-written so that (1) the weight word stays in an SGPR (VOP2 src0), (2) the
 // accumulate is the free addend of v_bcnt_u32_b32 instead of a separate v_add (hipcc

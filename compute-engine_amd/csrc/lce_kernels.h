@@ -34,12 +34,12 @@ LCE_DEVICE uint32_t fastdiv(uint32_t n, FastDiv d) {
 // ---------------------------------------------------------------------------------
 
 // :99-106 -- x = accum << 1, clamp in int32, then float(x) * mul + bias as TWO
-// roundings (__fmul_rn/__fadd_rn are never contracted into an FMA).
+// roundings (mul_then_add keeps the product out of reach of FMA contraction).
 LCE_DEVICE float ot_float(int acc, int cmin, int cmax, float mul, float bias) {
   int x = acc << 1;
   x = x < cmax ? x : cmax;
   x = x > cmin ? x : cmin;
-  return __fadd_rn(__fmul_rn((float)x, mul), bias);
+  return mul_then_add((float)x, mul, bias);
 }
 
 // :17-27,31-44,133-143 -- std::round (half away from zero), saturate to int8.

@@ -18,7 +18,6 @@
 #define __restrict__
 #define __launch_bounds__(...)
 
-inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 
 namespace lce_dev {
@@ -65,6 +64,7 @@ inline u32x4 buf_load(rsrc_t r, uint32_t off, u32x4*) { return buf_load_impl<u32
 inline uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline int popc(uint32_t x) { return __builtin_popcount(x); }
 inline float round_half_away(float y) { return roundf(y); }
+inline float mul_then_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
 
 inline unsigned long long wave_ballot(bool p) {
   if (!g_ctx.bar) return p ? ~0ull : 0ull;  // sequential mode: only used via wave_any

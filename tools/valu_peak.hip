@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <vector>
 
-template <int ACCS>
+// MODE 0: xor+bcnt pair (the bconv inner product); 1: v_xor_b32 only; 2: v_bcnt_u32_b32 only;
+// 3: v_add_u32 only; 4: v_xor_b32 + v_add_u32 pair (two full-rate ops, for comparison)
+template <int ACCS, int MODE = 0>
 __global__ __launch_bounds__(256) void xor_bcnt_loop(uint32_t* out, const uint32_t* seed, int iters) {
   uint32_t a[ACCS];
   int acc[ACCS];
@@ -21,7 +23,11 @@ __global__ __launch_bounds__(256) void xor_bcnt_loop(uint32_t* out, const uint32
 #pragma unroll
       for (int i = 0; i < ACCS; ++i) {
         uint32_t t;
-        asm volatile("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i]), "=&v"(t) : "s"(w), "v"(a[i]));
+        if (MODE == 0) asm volatile("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i]), "=&v"(t) : "s"(w), "v"(a[i]));
+        else if (MODE == 1) asm volatile("v_xor_b32 %0, %2, %0\n\tv_xor_b32 %0, %3, %0" : "+v"(acc[i]), "=&v"(t) : "s"(w), "v"(a[i]));
+        else if (MODE == 2) asm volatile("v_bcnt_u32_b32 %0, %3, %0\n\tv_bcnt_u32_b32 %0, %3, %0" : "+v"(acc[i]), "=&v"(t) : "s"(w), "v"(a[i]));
+        else if (MODE == 3) asm volatile("v_add_u32 %0, %3, %0\n\tv_add_u32 %0, %2, %0" : "+v"(acc[i]), "=&v"(t) : "s"(w), "v"(a[i]));
+        else asm volatile("v_xor_b32 %1, %2, %3\n\tv_add_u32 %0, %1, %0" : "+v"(acc[i]), "=&v"(t) : "s"(w), "v"(a[i]));
       }
     }
   }
@@ -31,7 +37,7 @@ __global__ __launch_bounds__(256) void xor_bcnt_loop(uint32_t* out, const uint32
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int ACCS>
+template <int ACCS, int MODE = 0>
 void run(int blocks_per_cu, const char* label) {
   const int iters = 4000;
   const int blocks = 256 * blocks_per_cu;
@@ -41,10 +47,10 @@ void run(int blocks_per_cu, const char* label) {
   hipMemset(seed, 1, 64);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  xor_bcnt_loop<ACCS><<<blocks, 256>>>(out, seed, 10);
+  xor_bcnt_loop<ACCS, MODE><<<blocks, 256>>>(out, seed, 10);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  xor_bcnt_loop<ACCS><<<blocks, 256>>>(out, seed, iters);
+  xor_bcnt_loop<ACCS, MODE><<<blocks, 256>>>(out, seed, iters);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -62,5 +68,9 @@ int main() {
   run<8>(8, "8 blocks/CU");
   run<16>(4, "16 accs, 4 blocks/CU");
   run<4>(8, "4 accs, 8 blocks/CU");
+  run<8, 1>(8, "MODE1 v_xor_b32 x2");
+  run<8, 2>(8, "MODE2 v_bcnt_u32_b32 x2");
+  run<8, 3>(8, "MODE3 v_add_u32 x2");
+  run<8, 4>(8, "MODE4 v_xor_b32 + v_add_u32");
   return 0;
 }
