@@ -1,0 +1,492 @@
+// TFLite custom-op glue for the MI355X build of Larq Compute Engine's binary ops.
+//
+// Same entry points, registration contract and error behaviour as the reference's
+// tflite/kernels/{bconv2d.cc, quantization.cc, bmaxpool.cc, lce_ops_register.h}
+// (paths relative to /root/reference/larq_compute_engine/): C++ functions in namespace
+// compute_engine::tflite returning a function-local static TfLiteRegistration with
+// {init, free, prepare, invoke}.  Underneath, instead of the CPU kernels, every op calls
+// the C ABI in include/lce_hip.h.  Interpreter tensors are host memory, so invoke stages
+// them through HBM (lce_hip_*_run_host / memcpy); device-resident chaining is available
+// through the C ABI directly.
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../../include/lce_hip.h"
+#include "flexbuffer_map.h"
+#include "lce_ops_register.h"
+#include "tflite_abi.h"
+
+namespace compute_engine {
+namespace tflite {
+namespace {
+
+// --- small helpers in the spirit of tensorflow/lite/kernels/kernel_util.h -----------
+inline const TfLiteTensor* GetInput(TfLiteContext* c, const TfLiteNode* n, int i) {
+  const int idx = n->inputs->data[i];
+  return idx == kTfLiteOptionalTensor ? nullptr : &c->tensors[idx];
+}
+inline TfLiteTensor* GetOutput(TfLiteContext* c, const TfLiteNode* n, int i) {
+  return &c->tensors[n->outputs->data[i]];
+}
+inline int NumDimensions(const TfLiteTensor* t) { return t->dims->size; }
+inline int SizeOfDimension(const TfLiteTensor* t, int d) { return t->dims->data[d]; }
+inline int BitpackedSize(int n) { return (n + 31) / 32; }  // core/bitpacking/bitpack.h:24-26
+
+#define LCE_ENSURE(ctx, cond)                                                          \
+  do {                                                                                 \
+    if (!(cond)) {                                                                     \
+      (ctx)->ReportError((ctx), "%s:%d %s was not true.", __FILE__, __LINE__, #cond);   \
+      return kTfLiteError;                                                             \
+    }                                                                                  \
+  } while (0)
+#define LCE_ENSURE_EQ(ctx, a, b)                                                       \
+  do {                                                                                 \
+    if ((a) != (b)) {                                                                  \
+      (ctx)->ReportError((ctx), "%s:%d %s != %s (%d != %d)", __FILE__, __LINE__, #a, #b, \
+                         (int)(a), (int)(b));                                          \
+      return kTfLiteError;                                                             \
+    }                                                                                  \
+  } while (0)
+#define LCE_ENSURE_MSG(ctx, cond, msg)                                                 \
+  do {                                                                                 \
+    if (!(cond)) {                                                                     \
+      (ctx)->ReportError((ctx), "%s:%d %s", __FILE__, __LINE__, (msg));                 \
+      return kTfLiteError;                                                             \
+    }                                                                                  \
+  } while (0)
+#define LCE_ENSURE_HIP(ctx, expr)                                                      \
+  do {                                                                                 \
+    if ((expr) != LCE_HIP_OK) {                                                        \
+      (ctx)->ReportError((ctx), "%s:%d %s", __FILE__, __LINE__, lce_hip_last_error());  \
+      return kTfLiteError;                                                             \
+    }                                                                                  \
+  } while (0)
+
+// RAII device scratch used by the ops that stage host tensors themselves
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  ~DeviceBuffer() { if (ptr) lce_hip_free(ptr); }
+  lce_hip_status ensure(size_t n) {
+    if (n <= bytes) return LCE_HIP_OK;
+    if (ptr) lce_hip_free(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    lce_hip_status s = lce_hip_malloc(&ptr, n);
+    if (s == LCE_HIP_OK) bytes = n;
+    return s;
+  }
+};
+
+size_t NumElements(const TfLiteTensor* t) {
+  size_t n = 1;
+  for (int i = 0; i < t->dims->size; ++i) n *= (size_t)t->dims->data[i];
+  return n;
+}
+
+}  // namespace
+
+// =====================================================================================
+// LceBconv2d  (reference: tflite/kernels/bconv2d.cc)
+// =====================================================================================
+namespace bconv2d {
+
+enum class KernelType { kReference, kOptimizedBGEMM, kOptimizedIndirectBGEMM };  // bconv2d.cc:31-40
+
+struct OpData {  // bconv2d.cc:44-74
+  // attributes
+  int32_t stride_height = 0, stride_width = 0;
+  int32_t dilation_height_factor = 0, dilation_width_factor = 0;
+  int32_t padding = 0;  // tflite schema enum: SAME = 0, VALID = 1
+  int32_t pad_values = 0;
+  int32_t channels_in = 0;
+  int32_t fused_activation_function = 0;
+  // inferred in Prepare
+  int32_t groups = 1;
+  lce_hip_bconv2d_plan* plan = nullptr;
+  bool successfully_initialized = false;
+  bool one_time_setup_complete = false;
+  ~OpData() { if (plan) lce_hip_bconv2d_plan_destroy(plan); }
+};
+
+void* Init(TfLiteContext* context, const char* buffer, size_t length) {  // bconv2d.cc:85-131
+  auto* op = new (std::nothrow) OpData{};
+  if (!op) return nullptr;
+  const lce_flex::Map m(reinterpret_cast<const uint8_t*>(buffer), length);
+  static const char* const kRequired[] = {"stride_height", "stride_width", "dilation_height_factor",
+                                          "dilation_width_factor", "padding", "pad_values",
+                                          "channels_in", "fused_activation_function"};
+  for (const char* key : kRequired) {
+    if (!m.valid() || m.IsNull(key)) {  // LCE_ENSURE_PARAM, bconv2d.cc:76-83,96-103
+      context->ReportError(context, "%s:%d !m[\"%s\"].IsNull() was not true.", __FILE__, __LINE__, key);
+      return op;
+    }
+  }
+  op->stride_height = m.AsInt32("stride_height");
+  op->stride_width = m.AsInt32("stride_width");
+  op->dilation_height_factor = m.AsInt32("dilation_height_factor");
+  op->dilation_width_factor = m.AsInt32("dilation_width_factor");
+  op->padding = m.AsInt32("padding");
+  op->pad_values = m.AsInt32("pad_values");
+  if (op->pad_values != 0 && op->pad_values != 1) {  // :109-112
+    context->ReportError(context, "Attribute pad_values must be 0 or 1.");
+    return op;
+  }
+  op->channels_in = m.AsInt32("channels_in");
+  // ConvertActivation (tflite/kernels/utils.h:10-25): anything unknown becomes NONE
+  const int act = m.AsInt32("fused_activation_function");
+  op->fused_activation_function = (act >= LCE_HIP_ACT_NONE && act <= LCE_HIP_ACT_RELU6) ? act : LCE_HIP_ACT_NONE;
+  // Init cannot return an error; Prepare checks this flag (:126-129)
+  op->successfully_initialized = true;
+  return op;
+}
+
+void Free(TfLiteContext*, void* buffer) { delete reinterpret_cast<OpData*>(buffer); }  // :133-135
+
+template <KernelType kernel_type>
+TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bconv2d.cc:137-300
+  auto* op = reinterpret_cast<OpData*>(node->user_data);
+  if (!op || !op->successfully_initialized) return kTfLiteError;
+
+  LCE_ENSURE_EQ(context, node->inputs->size, 5);
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  const TfLiteTensor* filter = GetInput(context, node, 1);
+  const TfLiteTensor* post_activation_multiplier = GetInput(context, node, 2);
+  const TfLiteTensor* post_activation_bias = GetInput(context, node, 3);
+  const TfLiteTensor* thresholds = GetInput(context, node, 4);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  LCE_ENSURE(context, input != nullptr && filter != nullptr);
+
+  LCE_ENSURE_EQ(context, NumDimensions(input), 4);
+  LCE_ENSURE_EQ(context, NumDimensions(filter), 4);
+  LCE_ENSURE_EQ(context, input->type, kTfLiteInt32);
+  LCE_ENSURE_EQ(context, filter->type, kTfLiteInt32);
+  LCE_ENSURE_MSG(context,
+                 output->type == kTfLiteInt32 || output->type == kTfLiteInt8 || output->type == kTfLiteFloat32,
+                 "Supported output types are int8, int32, and float32.");
+
+  const int32_t channels_out = SizeOfDimension(filter, 0);
+  // groups are inferred from the filter's packed depth (:169-186)
+  if (SizeOfDimension(filter, 3) == BitpackedSize(op->channels_in)) {
+    op->groups = 1;
+  } else {
+    LCE_ENSURE_MSG(context, kernel_type != KernelType::kOptimizedBGEMM,
+                   "Grouped binary convolutions are not supported with this kernel.");
+    LCE_ENSURE(context, SizeOfDimension(filter, 3) > 0);
+    LCE_ENSURE_EQ(context, BitpackedSize(op->channels_in) % SizeOfDimension(filter, 3), 0);
+    const int32_t groups = BitpackedSize(op->channels_in) / SizeOfDimension(filter, 3);
+    const int32_t group_size = op->channels_in / groups;
+    LCE_ENSURE_EQ(context, group_size % 32, 0);
+    LCE_ENSURE_EQ(context, channels_out % groups, 0);
+    op->groups = groups;
+  }
+  LCE_ENSURE_EQ(context, SizeOfDimension(input, 3), BitpackedSize(op->channels_in));
+
+  const bool is_ref = kernel_type == KernelType::kReference;
+  if (op->padding == LCE_HIP_PADDING_SAME && op->pad_values == 0) {  // :188-200
+    LCE_ENSURE_MSG(context,
+                   (is_ref && op->channels_in % 2 == 0) ||
+                       (!is_ref && output->type == kTfLiteFloat32 &&
+                        op->fused_activation_function == LCE_HIP_ACT_NONE),
+                   "Zero-padding is only supported by the reference kernel with an even "
+                   "number of input channels, or when using "
+                   "float output with no fused activation function.");
+  }
+
+  if (output->type == kTfLiteInt32) {  // :212-227
+    LCE_ENSURE(context, thresholds != nullptr);
+    LCE_ENSURE_EQ(context, NumDimensions(thresholds), 1);
+    LCE_ENSURE_EQ(context, thresholds->type, kTfLiteInt32);
+    LCE_ENSURE_EQ(context, SizeOfDimension(thresholds, 0), channels_out);
+  } else {
+    LCE_ENSURE(context, post_activation_multiplier != nullptr && post_activation_bias != nullptr);
+    LCE_ENSURE_EQ(context, post_activation_multiplier->type, kTfLiteFloat32);
+    LCE_ENSURE_EQ(context, post_activation_bias->type, kTfLiteFloat32);
+    LCE_ENSURE_EQ(context, NumDimensions(post_activation_multiplier), 1);
+    LCE_ENSURE_EQ(context, NumDimensions(post_activation_bias), 1);
+    LCE_ENSURE_EQ(context, SizeOfDimension(post_activation_multiplier, 0), channels_out);
+    LCE_ENSURE_EQ(context, SizeOfDimension(post_activation_bias, 0), channels_out);
+  }
+  if (output->type == kTfLiteInt8) {
+    LCE_ENSURE_EQ(context, output->quantization.type, kTfLiteAffineQuantization);  // :229-232
+  }
+  if (kernel_type == KernelType::kOptimizedIndirectBGEMM) {
+    LCE_ENSURE_MSG(context, input->allocation_type != kTfLiteDynamic,
+                   "The input tensor must not have dynamic allocation type");  // :234-238
+  }
+
+  // shape inference + the remaining checks live behind the C ABI (host-only, no GPU needed)
+  lce_hip_bconv2d_desc d;
+  memset(&d, 0, sizeof d);
+  d.batch = SizeOfDimension(input, 0);
+  d.in_height = SizeOfDimension(input, 1);
+  d.in_width = SizeOfDimension(input, 2);
+  d.channels_in = op->channels_in;
+  d.filter_height = SizeOfDimension(filter, 1);
+  d.filter_width = SizeOfDimension(filter, 2);
+  d.channels_out = channels_out;
+  d.groups = op->groups;
+  d.stride_height = op->stride_height;
+  d.stride_width = op->stride_width;
+  d.dilation_height = op->dilation_height_factor;
+  d.dilation_width = op->dilation_width_factor;
+  d.padding = op->padding;
+  d.pad_values = op->pad_values;
+  d.activation = op->fused_activation_function;
+  d.dst_type = output->type == kTfLiteFloat32 ? LCE_HIP_F32 : output->type == kTfLiteInt8 ? LCE_HIP_I8 : LCE_HIP_BITPACKED;
+  d.semantics = is_ref ? LCE_HIP_SEM_REFERENCE : LCE_HIP_SEM_OPTIMIZED;
+  d.out_scale = output->type == kTfLiteInt8 ? output->params.scale : 1.0f;
+  d.out_zero_point = output->type == kTfLiteInt8 ? output->params.zero_point : 0;
+  if (op->plan) {
+    lce_hip_bconv2d_plan_destroy(op->plan);
+    op->plan = nullptr;
+  }
+  LCE_ENSURE_HIP(context, lce_hip_bconv2d_plan_create(&d, &op->plan));
+
+  int32_t dims[4];
+  LCE_ENSURE_HIP(context, lce_hip_bconv2d_plan_output_shape(op->plan, dims));
+  TfLiteIntArray* output_shape = TfLiteIntArrayCreate(4);  // ResizeTensor takes ownership (:241-248)
+  for (int i = 0; i < 4; ++i) output_shape->data[i] = dims[i];
+  if (context->ResizeTensor(context, output, output_shape) != kTfLiteOk) return kTfLiteError;
+
+  // No im2col temporary: the GPU kernel is an implicit GEMM (the reference allocates
+  // [B,OH,OW,KH*KW*Cw] here, :250-293).
+  // Prepare may run again after a resize: redo the one-time setup (:295-297).
+  op->one_time_setup_complete = false;
+  return kTfLiteOk;
+}
+
+TfLiteStatus OneTimeSetup(TfLiteContext* context, TfLiteNode* node, OpData* op) {  // :324-392
+  const TfLiteTensor* filter = GetInput(context, node, 1);
+  const TfLiteTensor* mul = GetInput(context, node, 2);
+  const TfLiteTensor* bias = GetInput(context, node, 3);
+  const TfLiteTensor* thr = GetInput(context, node, 4);
+  LCE_ENSURE_HIP(context, lce_hip_bconv2d_plan_set_weights(op->plan, filter->data.i32,
+                                                           mul ? mul->data.f : nullptr,
+                                                           bias ? bias->data.f : nullptr,
+                                                           thr ? thr->data.i32 : nullptr));
+  op->one_time_setup_complete = true;
+  return kTfLiteOk;
+}
+
+template <KernelType kernel_type>
+TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // :550-564
+  auto* op = reinterpret_cast<OpData*>(node->user_data);
+  if (!op || !op->plan) return kTfLiteError;
+  if (!op->one_time_setup_complete) {
+    if (OneTimeSetup(context, node, op) != kTfLiteOk) return kTfLiteError;
+  }
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  if (output->type != kTfLiteFloat32 && output->type != kTfLiteInt8 && output->type != kTfLiteInt32)
+    return kTfLiteError;
+  LCE_ENSURE_HIP(context, lce_hip_bconv2d_run_host(op->plan, input->data.i32, output->data.data));
+  return kTfLiteOk;
+}
+
+}  // namespace bconv2d
+
+TfLiteRegistration* Register_BCONV_2D_REF() {  // bconv2d.cc:568-574
+  static TfLiteRegistration r = {bconv2d::Init, bconv2d::Free,
+                                 bconv2d::Prepare<bconv2d::KernelType::kReference>,
+                                 bconv2d::Eval<bconv2d::KernelType::kReference>};
+  return &r;
+}
+TfLiteRegistration* Register_BCONV_2D_OPT_BGEMM() {  // :576-582
+  static TfLiteRegistration r = {bconv2d::Init, bconv2d::Free,
+                                 bconv2d::Prepare<bconv2d::KernelType::kOptimizedBGEMM>,
+                                 bconv2d::Eval<bconv2d::KernelType::kOptimizedBGEMM>};
+  return &r;
+}
+TfLiteRegistration* Register_BCONV_2D_OPT_INDIRECT_BGEMM() {  // :584-590
+  static TfLiteRegistration r = {bconv2d::Init, bconv2d::Free,
+                                 bconv2d::Prepare<bconv2d::KernelType::kOptimizedIndirectBGEMM>,
+                                 bconv2d::Eval<bconv2d::KernelType::kOptimizedIndirectBGEMM>};
+  return &r;
+}
+// The reference picks OPT_BGEMM whenever TFLITE_WITH_RUY is defined, which its Bazel build
+// always does (bconv2d.cc:592-599, .bazelrc:20-21); that is the semantics kept here.
+TfLiteRegistration* Register_BCONV_2D() { return Register_BCONV_2D_OPT_BGEMM(); }
+
+// =====================================================================================
+// LceQuantize / LceDequantize  (reference: tflite/kernels/quantization.cc)
+// =====================================================================================
+namespace {
+
+struct StagePair {
+  DeviceBuffer in, out;
+};
+StagePair& stage() {
+  static thread_local StagePair s;
+  return s;
+}
+
+TfLiteStatus QuantizePrepare(TfLiteContext* context, TfLiteNode* node) {  // quantization.cc:19-41
+  LCE_ENSURE_EQ(context, node->inputs->size, 1);
+  LCE_ENSURE_EQ(context, node->outputs->size, 1);
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  LCE_ENSURE(context, input->type == kTfLiteFloat32 || input->type == kTfLiteInt8 || input->type == kTfLiteBool);
+  LCE_ENSURE_EQ(context, output->type, kTfLiteInt32);
+  const int num_dims = NumDimensions(input);
+  LCE_ENSURE_EQ(context, num_dims, NumDimensions(output));
+  TfLiteIntArray* output_dims = TfLiteIntArrayCopy(input->dims);
+  output_dims->data[num_dims - 1] = BitpackedSize(SizeOfDimension(input, num_dims - 1));
+  return context->ResizeTensor(context, output, output_dims);
+}
+
+TfLiteStatus QuantizeEval(TfLiteContext* context, TfLiteNode* node) {  // quantization.cc:76-114
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  lce_hip_dtype t;
+  size_t esz;
+  int32_t zp = 0;
+  if (input->type == kTfLiteFloat32) { t = LCE_HIP_F32; esz = 4; }
+  else if (input->type == kTfLiteInt8) { t = LCE_HIP_I8; esz = 1; zp = input->params.zero_point; }
+  else if (input->type == kTfLiteBool) { t = LCE_HIP_BOOL; esz = sizeof(bool); zp = 1; }
+  else return kTfLiteError;
+  const int nd = NumDimensions(input);
+  const size_t cols = (size_t)SizeOfDimension(input, nd - 1);
+  const size_t total = NumElements(input);
+  if (total == 0) return kTfLiteOk;
+  const size_t rows = total / cols;
+  const size_t out_bytes = rows * (size_t)BitpackedSize((int)cols) * 4;
+  StagePair& s = stage();
+  LCE_ENSURE_HIP(context, s.in.ensure(total * esz));
+  LCE_ENSURE_HIP(context, s.out.ensure(out_bytes));
+  LCE_ENSURE_HIP(context, lce_hip_memcpy_h2d(s.in.ptr, input->data.data, total * esz, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_bitpack(t, s.in.ptr, rows, cols, zp, (int32_t*)s.out.ptr, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_memcpy_d2h(output->data.data, s.out.ptr, out_bytes, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_stream_synchronize(nullptr));
+  return kTfLiteOk;
+}
+
+TfLiteStatus DequantizePrepare(TfLiteContext* context, TfLiteNode* node) {  // quantization.cc:43-74
+  LCE_ENSURE_EQ(context, node->inputs->size, 1);
+  LCE_ENSURE_EQ(context, node->outputs->size, 1);
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  LCE_ENSURE_EQ(context, input->type, kTfLiteInt32);
+  LCE_ENSURE(context, output->type == kTfLiteFloat32 || output->type == kTfLiteInt8 || output->type == kTfLiteBool);
+  const int num_dims = NumDimensions(input);
+  LCE_ENSURE_EQ(context, num_dims, NumDimensions(output));
+  for (int i = 0; i < num_dims - 1; ++i) LCE_ENSURE_EQ(context, SizeOfDimension(output, i), SizeOfDimension(input, i));
+  LCE_ENSURE_EQ(context, SizeOfDimension(input, num_dims - 1), BitpackedSize(SizeOfDimension(output, num_dims - 1)));
+  return kTfLiteOk;  // no resize: the unpacked channel count cannot be inferred (:69-71)
+}
+
+TfLiteStatus DequantizeEval(TfLiteContext* context, TfLiteNode* node) {  // quantization.cc:116-147
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  lce_hip_dtype t;
+  size_t esz;
+  if (output->type == kTfLiteFloat32) { t = LCE_HIP_F32; esz = 4; }
+  else if (output->type == kTfLiteInt8) { t = LCE_HIP_I8; esz = 1; }
+  else if (output->type == kTfLiteBool) { t = LCE_HIP_BOOL; esz = sizeof(bool); }
+  else return kTfLiteError;
+  const int nd = NumDimensions(output);
+  const size_t cols = (size_t)SizeOfDimension(output, nd - 1);
+  const size_t total = NumElements(output);
+  if (total == 0) return kTfLiteOk;
+  const size_t rows = total / cols;
+  const size_t in_bytes = rows * (size_t)BitpackedSize((int)cols) * 4;
+  StagePair& s = stage();
+  LCE_ENSURE_HIP(context, s.in.ensure(in_bytes));
+  LCE_ENSURE_HIP(context, s.out.ensure(total * esz));
+  LCE_ENSURE_HIP(context, lce_hip_memcpy_h2d(s.in.ptr, input->data.data, in_bytes, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_unpack(t, (const int32_t*)s.in.ptr, rows, cols, output->params.scale,
+                                         output->params.zero_point, s.out.ptr, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_memcpy_d2h(output->data.data, s.out.ptr, total * esz, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_stream_synchronize(nullptr));
+  return kTfLiteOk;
+}
+
+}  // namespace
+
+TfLiteRegistration* Register_QUANTIZE() {  // quantization.cc:149-153
+  static TfLiteRegistration r = {nullptr, nullptr, QuantizePrepare, QuantizeEval};
+  return &r;
+}
+TfLiteRegistration* Register_DEQUANTIZE() {  // quantization.cc:155-159
+  static TfLiteRegistration r = {nullptr, nullptr, DequantizePrepare, DequantizeEval};
+  return &r;
+}
+
+// =====================================================================================
+// LceBMaxPool2d  (reference: tflite/kernels/bmaxpool.cc)
+// =====================================================================================
+namespace bmaxpool {
+
+struct PoolParams {  // core/bmaxpool.h:15-22
+  int32_t filter_height = 0, filter_width = 0, stride_height = 0, stride_width = 0, padding = 0;
+};
+
+void* Init(TfLiteContext*, const char* buffer, size_t length) {  // bmaxpool.cc:20-35
+  auto* p = new (std::nothrow) PoolParams{};
+  if (!p) return nullptr;
+  const lce_flex::Map m(reinterpret_cast<const uint8_t*>(buffer), length);
+  p->filter_height = m.AsInt32("filter_height");
+  p->filter_width = m.AsInt32("filter_width");
+  p->stride_height = m.AsInt32("stride_height");
+  p->stride_width = m.AsInt32("stride_width");
+  p->padding = m.AsInt32("padding");
+  return p;
+}
+void Free(TfLiteContext*, void* buffer) { delete reinterpret_cast<PoolParams*>(buffer); }
+
+TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bmaxpool.cc:41-77
+  auto* p = reinterpret_cast<PoolParams*>(node->user_data);
+  LCE_ENSURE(context, p != nullptr);
+  LCE_ENSURE_EQ(context, node->inputs->size, 1);
+  LCE_ENSURE_EQ(context, node->outputs->size, 1);
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  LCE_ENSURE_EQ(context, NumDimensions(input), 4);
+  LCE_ENSURE_EQ(context, input->type, kTfLiteInt32);
+  LCE_ENSURE_EQ(context, output->type, kTfLiteInt32);
+  LCE_ENSURE(context, p->stride_height != 0);
+  LCE_ENSURE(context, p->stride_width != 0);
+  LCE_ENSURE(context, p->filter_height != 0);
+  LCE_ENSURE(context, p->filter_width != 0);
+  int32_t oh = 0, ow = 0;
+  LCE_ENSURE_HIP(context, lce_hip_bmaxpool_output_shape(SizeOfDimension(input, 1), SizeOfDimension(input, 2),
+                                                        p->filter_height, p->filter_width, p->stride_height,
+                                                        p->stride_width, p->padding, &oh, &ow));
+  TfLiteIntArray* out = TfLiteIntArrayCreate(4);
+  out->data[0] = SizeOfDimension(input, 0);
+  out->data[1] = oh;
+  out->data[2] = ow;
+  out->data[3] = SizeOfDimension(input, 3);
+  return context->ResizeTensor(context, output, out);
+}
+
+TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // bmaxpool.cc:79-91
+  auto* p = reinterpret_cast<PoolParams*>(node->user_data);
+  const TfLiteTensor* input = GetInput(context, node, 0);
+  TfLiteTensor* output = GetOutput(context, node, 0);
+  const size_t in_bytes = NumElements(input) * 4, out_bytes = NumElements(output) * 4;
+  if (in_bytes == 0 || out_bytes == 0) return kTfLiteOk;
+  StagePair& s = stage();
+  LCE_ENSURE_HIP(context, s.in.ensure(in_bytes));
+  LCE_ENSURE_HIP(context, s.out.ensure(out_bytes));
+  LCE_ENSURE_HIP(context, lce_hip_memcpy_h2d(s.in.ptr, input->data.data, in_bytes, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_bmaxpool((const int32_t*)s.in.ptr, SizeOfDimension(input, 0), SizeOfDimension(input, 1),
+                                           SizeOfDimension(input, 2), SizeOfDimension(input, 3), p->filter_height,
+                                           p->filter_width, p->stride_height, p->stride_width, p->padding,
+                                           (int32_t*)s.out.ptr, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_memcpy_d2h(output->data.data, s.out.ptr, out_bytes, nullptr));
+  LCE_ENSURE_HIP(context, lce_hip_stream_synchronize(nullptr));
+  return kTfLiteOk;
+}
+
+}  // namespace bmaxpool
+
+TfLiteRegistration* Register_BMAXPOOL_2D() {  // bmaxpool.cc:95-99
+  static TfLiteRegistration r = {bmaxpool::Init, bmaxpool::Free, bmaxpool::Prepare, bmaxpool::Eval};
+  return &r;
+}
+
+}  // namespace tflite
+}  // namespace compute_engine

@@ -1,0 +1,48 @@
+// Drop-in for the reference's tflite/kernels/lce_ops_register.h: forward declarations of
+// the LCE custom-op registrations plus RegisterLCECustomOps().  Same names, same
+// arguments, same op strings ("LceQuantize", "LceDequantize", "LceBconv2d",
+// "LceBMaxPool2d"); the registrations run on the MI355X through include/lce_hip.h.
+#ifndef COMPUTE_ENGINE_AMD_TFLITE_LCE_OPS_REGISTER_H_
+#define COMPUTE_ENGINE_AMD_TFLITE_LCE_OPS_REGISTER_H_
+
+#include <cstdio>
+
+#include "tflite_abi.h"
+
+namespace compute_engine {
+namespace tflite {
+
+TfLiteRegistration* Register_QUANTIZE();
+TfLiteRegistration* Register_DEQUANTIZE();
+TfLiteRegistration* Register_BCONV_2D();
+TfLiteRegistration* Register_BCONV_2D_REF();
+TfLiteRegistration* Register_BCONV_2D_OPT_BGEMM();           // declared by the reference's tests (bconv2d_test.cc:191)
+TfLiteRegistration* Register_BCONV_2D_OPT_INDIRECT_BGEMM();
+TfLiteRegistration* Register_BMAXPOOL_2D();
+
+// lce_ops_register.h:25-53.  `Resolver` is ::tflite::MutableOpResolver in a TFLite build;
+// any type with AddCustom(const char*, const TfLiteRegistration*) works.
+template <typename Resolver>
+inline void RegisterLCECustomOps(Resolver* resolver, const bool use_reference_bconv = false,
+                                 const bool use_indirect_bgemm = false) {
+  if (use_reference_bconv && use_indirect_bgemm) {
+    std::fprintf(stderr,
+                 "WARNING: 'use_reference_bconv' and `use_indirect_bgemm` are both set to true. "
+                 "use_indirect_bgemm==true will have no effect.\n");
+  }
+  resolver->AddCustom("LceQuantize", Register_QUANTIZE());
+  resolver->AddCustom("LceDequantize", Register_DEQUANTIZE());
+  if (use_reference_bconv) {
+    resolver->AddCustom("LceBconv2d", Register_BCONV_2D_REF());
+  } else if (use_indirect_bgemm) {
+    resolver->AddCustom("LceBconv2d", Register_BCONV_2D_OPT_INDIRECT_BGEMM());
+  } else {
+    resolver->AddCustom("LceBconv2d", Register_BCONV_2D());
+  }
+  resolver->AddCustom("LceBMaxPool2d", Register_BMAXPOOL_2D());
+}
+
+}  // namespace tflite
+}  // namespace compute_engine
+
+#endif  // COMPUTE_ENGINE_AMD_TFLITE_LCE_OPS_REGISTER_H_

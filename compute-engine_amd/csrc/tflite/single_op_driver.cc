@@ -1,0 +1,234 @@
+// A tiny stand-in for the part of the TFLite interpreter that drives ONE custom-op node:
+// resolver lookup -> init(options) -> prepare -> invoke -> free, with a tensor arena,
+// ResizeTensor / AddTensors / ReportError callbacks and the TfLiteIntArray helpers.  It
+// plays the role TFLite's SingleOpModel plays in the reference's op tests
+// (tflite/tests/bconv2d_op_model.h:24-59) so that the Register_* surface can be exercised
+// without TensorFlow, and exposes a plain C interface for ctypes.  Test tooling: a real
+// deployment links lce_ops.cc into TFLite instead.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "flexbuffer_map.h"
+#include "lce_ops_register.h"
+#include "tflite_abi.h"
+
+extern "C" {
+// tensorflow/lite/core/c/common.cc equivalents (malloc-based, like TFLite's)
+TfLiteIntArray* TfLiteIntArrayCreate(int size) {
+  TfLiteIntArray* a = (TfLiteIntArray*)malloc(sizeof(TfLiteIntArray) + sizeof(int) * (size_t)(size > 0 ? size : 0));
+  if (a) a->size = size;
+  return a;
+}
+TfLiteIntArray* TfLiteIntArrayCopy(const TfLiteIntArray* src) {
+  if (!src) return nullptr;
+  TfLiteIntArray* a = TfLiteIntArrayCreate(src->size);
+  if (a) memcpy(a->data, src->data, sizeof(int) * (size_t)src->size);
+  return a;
+}
+void TfLiteIntArrayFree(TfLiteIntArray* a) { free(a); }
+}
+
+namespace {
+
+size_t type_size(TfLiteType t) {
+  switch (t) {
+    case kTfLiteFloat32: case kTfLiteInt32: return 4;
+    case kTfLiteInt8: case kTfLiteUInt8: return 1;
+    case kTfLiteBool: return sizeof(bool);
+    case kTfLiteInt64: return 8;
+    default: return 0;
+  }
+}
+
+struct Resolver {  // the AddCustom half of ::tflite::MutableOpResolver
+  std::map<std::string, const TfLiteRegistration*> ops;
+  void AddCustom(const char* name, const TfLiteRegistration* r) { ops[name] = r; }
+};
+
+struct Model {
+  TfLiteContext ctx{};
+  std::vector<TfLiteTensor> tensors;
+  std::vector<std::vector<char>> storage;
+  std::vector<TfLiteAffineQuantization> quant;
+  TfLiteNode node{};
+  const TfLiteRegistration* reg = nullptr;
+  std::string log;
+  bool inited = false;
+
+  static Model* self(TfLiteContext* c) { return (Model*)c->impl_; }
+
+  static TfLiteStatus Resize(TfLiteContext* c, TfLiteTensor* t, TfLiteIntArray* dims) {
+    Model* m = self(c);
+    size_t n = type_size(t->type);
+    for (int i = 0; i < dims->size; ++i) n *= (size_t)(dims->data[i] > 0 ? dims->data[i] : 0);
+    const size_t idx = (size_t)(t - m->tensors.data());
+    m->storage[idx].assign(n + 16, 0);   // LCE_EXTRA_BYTES of slack (core/types.h:35-38)
+    t->data.raw = m->storage[idx].data();
+    t->bytes = n;
+    TfLiteIntArrayFree(t->dims);
+    t->dims = dims;  // takes ownership, like the interpreter
+    return kTfLiteOk;
+  }
+  static void Report(TfLiteContext* c, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    Model* m = self(c);
+    m->log += buf;
+    m->log += "\n";
+  }
+  static TfLiteStatus AddTensors(TfLiteContext* c, int n, int* first) {
+    Model* m = self(c);
+    if (first) *first = (int)m->tensors.size();
+    for (int i = 0; i < n; ++i) m->add(kTfLiteNoType, 0, nullptr, kTfLiteArenaRw);
+    return kTfLiteOk;
+  }
+
+  Model() {
+    tensors.reserve(64);
+    storage.reserve(64);
+    quant.reserve(64);
+    ctx.impl_ = this;
+    ctx.ResizeTensor = Resize;
+    ctx.ReportError = Report;
+    ctx.AddTensors = AddTensors;
+    ctx.recommended_num_threads = 1;
+  }
+  ~Model() {
+    if (reg && reg->free && inited) reg->free(&ctx, node.user_data);
+    for (auto& t : tensors) TfLiteIntArrayFree(t.dims);
+    TfLiteIntArrayFree(node.inputs);
+    TfLiteIntArrayFree(node.outputs);
+    TfLiteIntArrayFree(node.temporaries);
+    for (auto& q : quant) { free(q.scale); TfLiteIntArrayFree(q.zero_point); }
+  }
+
+  int add(TfLiteType type, int rank, const int* dims, TfLiteAllocationType alloc) {
+    if (tensors.size() >= 64) return -1;
+    TfLiteTensor t;
+    memset(&t, 0, sizeof t);
+    t.type = type;
+    t.dims = TfLiteIntArrayCreate(rank);
+    size_t n = type_size(type);
+    for (int i = 0; i < rank; ++i) { t.dims->data[i] = dims[i]; n *= (size_t)dims[i]; }
+    t.allocation_type = alloc;
+    t.bytes = n;
+    tensors.push_back(t);
+    storage.emplace_back(n + 16, 0);
+    tensors.back().data.raw = storage.back().data();
+    ctx.tensors = tensors.data();
+    ctx.tensors_size = tensors.size();
+    return (int)tensors.size() - 1;
+  }
+};
+
+TfLiteIntArray* make_array(const int* v, int n) {
+  TfLiteIntArray* a = TfLiteIntArrayCreate(n);
+  for (int i = 0; i < n; ++i) a->data[i] = v[i];
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+// variant: for "LceBconv2d" 0 = Register_BCONV_2D (default), 1 = _REF, 2 = _OPT_BGEMM,
+// 3 = _OPT_INDIRECT_BGEMM; otherwise ignored.  With use_resolver != 0 the registration is
+// looked up through RegisterLCECustomOps(resolver, use_reference_bconv, use_indirect_bgemm)
+// where the two flags are bit 0 / bit 1 of `variant`.
+void* lce_driver_create(const char* op_name, int variant, int use_resolver) {
+  using namespace compute_engine::tflite;
+  Model* m = new Model();
+  if (use_resolver) {
+    Resolver r;
+    RegisterLCECustomOps(&r, (variant & 1) != 0, (variant & 2) != 0);
+    auto it = r.ops.find(op_name);
+    m->reg = it == r.ops.end() ? nullptr : it->second;
+  } else if (!strcmp(op_name, "LceBconv2d")) {
+    m->reg = variant == 1 ? Register_BCONV_2D_REF() : variant == 2 ? Register_BCONV_2D_OPT_BGEMM()
+             : variant == 3 ? Register_BCONV_2D_OPT_INDIRECT_BGEMM() : Register_BCONV_2D();
+  } else if (!strcmp(op_name, "LceQuantize")) m->reg = Register_QUANTIZE();
+  else if (!strcmp(op_name, "LceDequantize")) m->reg = Register_DEQUANTIZE();
+  else if (!strcmp(op_name, "LceBMaxPool2d")) m->reg = Register_BMAXPOOL_2D();
+  if (!m->reg) { delete m; return nullptr; }
+  return m;
+}
+
+void lce_driver_destroy(void* h) { delete (Model*)h; }
+
+// type: TfLiteType value; allocation: TfLiteAllocationType value.  Returns the tensor index.
+int lce_driver_add_tensor(void* h, int type, int rank, const int* dims, int allocation, float scale,
+                          int zero_point, int affine_quantized) {
+  Model* m = (Model*)h;
+  const int idx = m->add((TfLiteType)type, rank, dims, (TfLiteAllocationType)allocation);
+  if (idx < 0) return idx;
+  TfLiteTensor& t = m->tensors[idx];
+  t.params.scale = scale;
+  t.params.zero_point = zero_point;
+  if (affine_quantized) {
+    TfLiteAffineQuantization q;
+    q.scale = (TfLiteFloatArray*)malloc(sizeof(TfLiteFloatArray) + sizeof(float));
+    q.scale->size = 1; q.scale->data[0] = scale;
+    q.zero_point = TfLiteIntArrayCreate(1); q.zero_point->data[0] = zero_point;
+    q.quantized_dimension = 0;
+    m->quant.push_back(q);
+    t.quantization.type = kTfLiteAffineQuantization;
+    t.quantization.params = &m->quant.back();
+  }
+  return idx;
+}
+
+int lce_driver_set_data(void* h, int tensor, const void* data, size_t bytes) {
+  Model* m = (Model*)h;
+  if (tensor < 0 || (size_t)tensor >= m->tensors.size() || bytes > m->tensors[tensor].bytes) return 1;
+  memcpy(m->tensors[tensor].data.raw, data, bytes);
+  return 0;
+}
+
+// inputs may contain -1 (kTfLiteOptionalTensor).  Calls init() with the flexbuffer options.
+int lce_driver_set_node(void* h, const int* inputs, int n_in, const int* outputs, int n_out,
+                        const char* options, size_t options_len) {
+  Model* m = (Model*)h;
+  m->node.inputs = make_array(inputs, n_in);
+  m->node.outputs = make_array(outputs, n_out);
+  m->node.temporaries = TfLiteIntArrayCreate(0);
+  m->node.custom_initial_data = options;
+  m->node.custom_initial_data_size = (int)options_len;
+  m->node.user_data = m->reg->init ? m->reg->init(&m->ctx, options, options_len) : nullptr;
+  m->inited = true;
+  return 0;
+}
+
+int lce_driver_prepare(void* h) { Model* m = (Model*)h; return (int)m->reg->prepare(&m->ctx, &m->node); }
+int lce_driver_invoke(void* h) { Model* m = (Model*)h; return (int)m->reg->invoke(&m->ctx, &m->node); }
+
+int lce_driver_tensor_rank(void* h, int tensor) { return ((Model*)h)->tensors[tensor].dims->size; }
+int lce_driver_tensor_dim(void* h, int tensor, int d) { return ((Model*)h)->tensors[tensor].dims->data[d]; }
+size_t lce_driver_tensor_bytes(void* h, int tensor) { return ((Model*)h)->tensors[tensor].bytes; }
+int lce_driver_get_data(void* h, int tensor, void* dst, size_t bytes) {
+  Model* m = (Model*)h;
+  if (bytes > m->tensors[tensor].bytes) return 1;
+  memcpy(dst, m->tensors[tensor].data.raw, bytes);
+  return 0;
+}
+const char* lce_driver_log(void* h) { return ((Model*)h)->log.c_str(); }
+int lce_driver_num_temporaries(void* h) { return ((Model*)h)->node.temporaries ? ((Model*)h)->node.temporaries->size : 0; }
+
+// flexbuffer KAT hook: parse a custom-options buffer and look one key up
+int lce_driver_flex_lookup(const char* buf, size_t len, const char* key, int* is_null, int* value) {
+  const lce_flex::Map m((const uint8_t*)buf, len);
+  if (!m.valid()) return 1;
+  *is_null = m.IsNull(key) ? 1 : 0;
+  *value = m.AsInt32(key);
+  return 0;
+}
+
+}  // extern "C"

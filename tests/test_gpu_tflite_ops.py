@@ -1,0 +1,103 @@
+"""GPU end-to-end tests of the TFLite custom-op surface: Init -> Prepare -> Invoke through
+Register_BCONV_2D{,_REF,_OPT_BGEMM,_OPT_INDIRECT_BGEMM}, Register_QUANTIZE,
+Register_DEQUANTIZE, Register_BMAXPOOL_2D with host (interpreter-arena) tensors, checked
+against the oracle.  This is the shape of the reference's own op tests
+(tflite/tests/bconv2d_test.cc, quantization_test.cc, bmaxpool_test.cc)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import flexbuf
+import oracle_lib as O
+import synth
+import tflite_driver as T
+from test_oracle_vs_float_conv import CASES, PADS, _id, legal
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {T.BCONV_REF: O.SEM_REFERENCE, T.BCONV_OPT_BGEMM: O.SEM_OPTIMIZED,
+            T.BCONV_OPT_INDIRECT: O.SEM_OPTIMIZED, T.BCONV_DEFAULT: O.SEM_OPTIMIZED}
+
+
+@pytest.mark.parametrize("case", CASES[:72:3] + CASES[72::23], ids=_id)
+def test_bconv2d_op_all_registrations(case):
+    inp, flt, g, st, dil, pad, act = case
+    padding, pv = PADS[pad]
+    for variant, sem in VARIANTS.items():
+        if not legal(inp, flt, g, pad, sem):
+            continue
+        if g > 1 and variant in (T.BCONV_OPT_BGEMM, T.BCONV_DEFAULT):
+            continue          # rejected by Prepare (bconv2d.cc:173-175), tested on the host side
+        spec = O.ConvSpec(inp[0], inp[1], inp[2], inp[3], flt[0], flt[1], flt[2], g, st[0], st[1], dil[0],
+                          dil[1], padding, pv, act, sem)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        seed = zlib.crc32(_id(case).encode()) & 0xFFFF
+        x, w, mul, bias = synth.conv_inputs(spec, seed)
+        thr = O.thresholds_optest(spec, mul, bias)
+        scale, zp = synth.int8_quant_params(seed)
+        zero_pad = pad == "SAME"
+        for dst in (O.DST_F32, O.DST_I8, O.DST_BITPACKED):
+            if zero_pad and sem == O.SEM_OPTIMIZED and (dst != O.DST_F32 or act != O.ACT_NONE):
+                continue
+            m, xi, oi = T.build_bconv2d(spec, dst, w, mul, bias, thr, variant, out_scale=float(scale), out_zero_point=zp)
+            assert m.prepare() == 0, m.log
+            m.set_data(xi, x)
+            assert m.invoke() == 0, m.log
+            want = O.bconv2d(spec, dst, x, w, mul, bias, thresholds=thr, out_scale=float(scale), out_zero_point=zp)
+            assert np.array_equal(m.get(oi).view(np.uint8), want.view(np.uint8)), (variant, dst)
+            # second invoke with new input: constants are folded once, results still right
+            x2 = synth.random_words(synth.rng(seed + 1), spec.input_shape(), spec.channels_in)
+            m.set_data(xi, x2)
+            assert m.invoke() == 0, m.log
+            want2 = O.bconv2d(spec, dst, x2, w, mul, bias, thresholds=thr, out_scale=float(scale), out_zero_point=zp)
+            assert np.array_equal(m.get(oi).view(np.uint8), want2.view(np.uint8))
+
+
+@pytest.mark.parametrize("ttype,dtype", [(T.FLOAT32, np.float32), (T.INT8, np.int8), (T.BOOL, np.bool_)])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (1, 4, 4, 1), (1, 4, 4, 2), (1, 4, 4, 31), (1, 4, 4, 32),
+                                   (1, 4, 4, 33), (1, 4, 4, 64), (1, 4, 4, 68)])
+def test_quantize_dequantize_ops_round_trip(ttype, dtype, shape):
+    """tflite/tests/quantization_test.cc:75-130."""
+    g = synth.rng(sum(shape))
+    signs = np.where(g.random(shape) < 0.5, -1.0, 1.0).astype(np.float32)
+    n, zp = int(g.integers(1, 21)), int(g.integers(-20, 21))
+    scale = float(np.float32(1.0) / np.float32(n))
+    data = {np.float32: signs, np.int8: (zp + n * signs).astype(np.int8), np.bool_: signs > 0}[dtype]
+    q = T.SingleOpModel("LceQuantize")
+    qi = q.add_tensor(ttype, shape, data, scale=scale if dtype == np.int8 else 0.0, zero_point=zp if dtype == np.int8 else 0)
+    qo = q.add_tensor(T.INT32, (0,) * 4)
+    q.set_node([qi], [qo])
+    assert q.prepare() == 0 and q.invoke() == 0, q.log
+    packed = q.get(qo)
+    assert np.array_equal(packed, O.bitpack(data, zp if dtype == np.int8 else 0))
+    d = T.SingleOpModel("LceDequantize")
+    di = d.add_tensor(T.INT32, packed.shape, packed)
+    do = d.add_tensor(ttype, shape, scale=scale if dtype == np.int8 else 0.0, zero_point=zp if dtype == np.int8 else 0)
+    d.set_node([di], [do])
+    assert d.prepare() == 0 and d.invoke() == 0, d.log
+    assert np.array_equal(d.get(do), data)
+
+
+def test_bmaxpool_op():
+    x = synth.random_words(synth.rng(7), (2, 9, 11, 3))
+    for fh, fw, sh, sw, pad in ((2, 2, 2, 2, 0), (3, 3, 2, 2, 0), (3, 2, 1, 2, 1)):
+        m = T.SingleOpModel("LceBMaxPool2d")
+        i = m.add_tensor(T.INT32, x.shape, x)
+        o = m.add_tensor(T.INT32, (0,) * 4)
+        m.set_node([i], [o], flexbuf.bmaxpool_options(fh, fw, sh, sw, pad))
+        assert m.prepare() == 0 and m.invoke() == 0, m.log
+        assert np.array_equal(m.get(o), O.bmaxpool(x, fh, fw, sh, sw, pad))
+
+
+def test_prepare_again_after_resize_redoes_setup():
+    """bconv2d.cc:295-297."""
+    spec = O.ConvSpec(2, 6, 6, 64, 3, 3, 32, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 9)
+    m, xi, oi = T.build_bconv2d(spec, O.DST_F32, w, mul, bias, None)
+    for _ in range(2):
+        assert m.prepare() == 0, m.log
+        m.set_data(xi, x)
+        assert m.invoke() == 0, m.log
+        assert np.array_equal(m.get(oi), O.bconv2d(spec, O.DST_F32, x, w, mul, bias))
