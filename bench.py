@@ -126,6 +126,7 @@ def main():
     import torch
     import oracle_lib as O
     amd = importlib.import_module("compute-engine_amd")
+    shard = importlib.import_module("compute-engine_amd.batch_shard")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -140,7 +141,10 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    spec = O.ConvSpec(batch=args.batch, padding=O.PADDING_SAME, pad_values=1, **L0)
+    # weak scaling: the global batch grows with N, every rank owns a contiguous slab of it
+    global_batch = args.batch * world
+    _, my_batch = shard.shard_range(global_batch, world, rank)
+    spec = O.ConvSpec(batch=my_batch, padding=O.PADDING_SAME, pad_values=1, **L0)
     # warm up + per-launch kernel time from stream events
     k_sec, kname, plan, x, out = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev)
 
@@ -157,10 +161,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
     total_bmacs = spec.binary_macs * args.steps * world
     value = total_bmacs / elapsed
