@@ -98,4 +98,43 @@ LCE_DEVICE void xor_popc_acc(int& c0, int& c1, int& c2, int& c3, uint32_t w, uin
       : "s"(w), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
 }
 
+
+// ---- matrix-core path -------------------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// D(32x32) += A(32x64) * B(64x32) with FP4 (E2M1) operands and unit block scales
+// (v_mfma_scale_f32_32x32x64_f8f6f4, cbsz = blgp = 4, E8M0 scale 0x7F = 2^0).
+// Operand layout (verified on gfx950 by tools/probes/mfma_fp4_probe.hip): lane l supplies
+// row/column (l & 31) and the 32 K-values 32*(l >> 5) + j in nibble j (LSB first) of its
+// 16 bytes; D: column = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) for register r.
+// Products of +-1 / 0 accumulate exactly in fp32 (|sum| < 2^24).
+LCE_DEVICE f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
+  i32x8 va = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
+  i32x8 vb = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+LCE_DEVICE f32x16 f32x16_zero() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+// All LDS of a kernel lives in ONE dynamic array (16-byte aligned carve base).
+LCE_DEVICE uint8_t* lds_base() {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lce_lds[];
+  return lce_lds;
+}
+// Asynchronous global -> LDS copy (buffer_load_dwordx4 ... lds): every lane fetches 16 bytes
+// at its own buffer offset; the wave's 64 x 16 bytes land CONTIGUOUSLY at lds_dst + 16*lane
+// (lds_dst is wave-uniform).  No VGPR round trip, no ds_write.  Completion is tracked by
+// vmcnt; block_sync() (= __syncthreads) waits for it.
+LCE_DEVICE void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, byte_off, 0, 0, 0);
+}
+LCE_DEVICE void block_sync() { __syncthreads(); }
+LCE_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+LCE_DEVICE float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
 }  // namespace lce_dev

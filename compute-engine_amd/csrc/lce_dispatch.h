@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/lce_hip.h"
 #include "lce_kernels.h"
+#include "lce_kernels_mfma.h"
 
 namespace lce {
 
@@ -48,5 +49,29 @@ inline general_fn find_general(int dst) {
   }
 }
 
+
+
+typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const uint8_t*, const float*,
+                        const float*, const float*, const float*, void*);
+
+template <int DST>
+mfma_fn mfma_by_tile(int bm, int bn) {
+  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4>;
+  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2>;
+  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2>;
+  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4>;
+  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2>;
+  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2>;
+  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2>;
+  return nullptr;
+}
+
+inline mfma_fn find_mfma(int dst, int bm, int bn) {
+  switch (dst) {
+    case LCE_HIP_F32: return mfma_by_tile<kDstFloat>(bm, bn);
+    case LCE_HIP_I8: return mfma_by_tile<kDstInt8>(bm, bn);
+    default: return mfma_by_tile<kDstBitpacked>(bm, bn);
+  }
+}
 
 }  // namespace lce

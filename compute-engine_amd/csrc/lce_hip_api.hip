@@ -85,6 +85,10 @@ struct lce_hip_bconv2d_plan {
   DevBuf<uint32_t> d_packed, d_filter;
   DevBuf<float> d_mul, d_bias, d_zpc;
   DevBuf<int32_t> d_thr, d_oobc;
+  DevBuf<uint8_t> d_wq;
+  DevBuf<float> d_thrq;
+  void* workspace = nullptr;       // FP4 expanded activations (matrix-core engine)
+  size_t workspace_bytes = 0;
   // staging for run_host
   void* stage_in = nullptr;
   void* stage_out = nullptr;
@@ -92,6 +96,7 @@ struct lce_hip_bconv2d_plan {
   ~lce_hip_bconv2d_plan() {
     if (stage_in) (void)hipFree(stage_in);
     if (stage_out) (void)hipFree(stage_out);
+    if (workspace) (void)hipFree(workspace);
   }
 };
 
@@ -102,6 +107,8 @@ using lce::tiled_fn;
 using lce::general_fn;
 using lce::find_tiled;
 using lce::find_general;
+using lce::find_mfma;
+using lce::mfma_fn;
 
 size_t out_elem_bytes(int dst) { return dst == LCE_HIP_I8 ? 1 : 4; }
 
@@ -109,7 +116,8 @@ lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
   lce::HostPlan& h = plan->host;
   const int64_t pixels = (int64_t)batch_chunk * h.out_h * h.out_w;
   if (plan->selected_for_pixels == pixels && !h.kernel_name.empty() &&
-      (!h.use_tiled || !h.packed.empty() || !h.have_weights))
+      (!h.use_tiled || !h.packed.empty() || !h.have_weights) &&
+      (!h.use_mfma || !h.wq.empty() || !h.have_weights))
     return LCE_HIP_OK;
   const std::string err = lce::select_kernel(h, pixels);
   if (!err.empty()) return fail(LCE_HIP_ERR_UNSUPPORTED, "%s", err.c_str());
@@ -121,7 +129,15 @@ lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
 lce_hip_status ensure_uploaded(lce_hip_bconv2d_plan* plan) {
   if (plan->device_current) return LCE_HIP_OK;
   lce::HostPlan& h = plan->host;
-  if (h.use_tiled) {
+  if (h.use_mfma) {
+    LCE_HIP_TRY(plan->d_wq.upload(h.wq));
+    LCE_HIP_TRY(plan->d_mul.upload(h.mul_q));
+    LCE_HIP_TRY(plan->d_bias.upload(h.bias_q));
+    LCE_HIP_TRY(plan->d_thrq.upload(h.thr_q));
+    plan->d_packed.release();
+    plan->d_filter.release();
+    plan->d_oobc.release();
+  } else if (h.use_tiled) {
     LCE_HIP_TRY(plan->d_packed.upload(h.packed));
     LCE_HIP_TRY(plan->d_mul.upload(h.mul_p));
     LCE_HIP_TRY(plan->d_bias.upload(h.bias_p));
@@ -356,7 +372,12 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key, const char* value) {
   if (!plan || !key || !value) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: null argument");
   lce::HostPlan& h = plan->host;
-  if (!strcmp(key, "kernel")) {
+  if (!strcmp(key, "engine")) {
+    if (!strcmp(value, "auto")) h.engine_pref = 0;
+    else if (!strcmp(value, "valu")) h.engine_pref = 1;
+    else if (!strcmp(value, "mfma")) h.engine_pref = 2;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma");
+  } else if (!strcmp(key, "kernel")) {
     if (!strcmp(value, "auto")) h.kernel_pref = 0;
     else if (!strcmp(value, "tiled")) h.kernel_pref = 1;
     else if (!strcmp(value, "general")) h.kernel_pref = 2;
@@ -364,15 +385,21 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
   } else if (!strcmp(key, "tile")) {
     int tm = 0, tn = 0;
     if (!strcmp(value, "auto")) { h.tile_pref = lce::TileShape{0, 0}; }
-    else if (sscanf(value, "%dx%d", &tm, &tn) == 2 && (tm == 1 || tm == 2 || tm == 4) &&
-             (tn == 16 || tn == 32) && !(tm == 4 && tn == 32)) { h.tile_pref = lce::TileShape{tm, tn}; }
-    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: tile must be auto|4x16|2x32|2x16|1x32|1x16");
+    else if (sscanf(value, "%dx%d", &tm, &tn) == 2 &&
+             ((tn <= 32 && lce::find_tiled(LCE_HIP_F32, tm, tn, 1)) || lce::mfma_cfg_by_tile(tm, tn))) {
+      h.tile_pref = lce::TileShape{tm, tn};
+    } else {
+      return fail(LCE_HIP_ERR_INVALID, "plan_set_option: tile must be auto, a xor-popcount tile "
+                  "(4x16|2x32|2x16|1x32|1x16) or, with engine=mfma, a block tile "
+                  "(256x256|256x128|512x64|128x256|128x128|256x64|128x64)");
+    }
   } else {
     return fail(LCE_HIP_ERR_INVALID, "plan_set_option: unknown key '%s'", key);
   }
   plan->selected_for_pixels = -1;
   plan->device_current = false;
   h.packed.clear();
+  h.wq.clear();
   return LCE_HIP_OK;
 }
 
@@ -402,7 +429,27 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
     ConvArgs A = lce::make_conv_args(h, nb);
     const uint32_t* in = (const uint32_t*)input_dev + (size_t)b0 * in_img_words;
     void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
-    if (h.use_tiled) {
+    if (h.use_mfma) {
+      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn());
+      if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
+      const size_t ws = lce::mfma_workspace_bytes(h, nb);
+      if (plan->workspace_bytes < ws) {
+        if (plan->workspace) (void)hipFree(plan->workspace);
+        plan->workspace = nullptr;
+        plan->workspace_bytes = 0;
+        LCE_HIP_TRY(hipMalloc(&plan->workspace, ws + 256));
+        plan->workspace_bytes = ws;
+      }
+      const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
+      const uint64_t chunks = (uint64_t)ws / 16;
+      lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
+      LCE_HIP_TRY(hipGetLastError());
+      const int bm = h.mfma.bm(), bn = h.mfma.bn();
+      const dim3 grid((unsigned)((A.M + bm - 1) / bm), (unsigned)(h.npad / bn));
+      hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), (size_t)h.mfma.lds_bytes(), st, A, G,
+                         (const uint8_t*)plan->workspace, plan->d_wq.ptr, plan->d_mul.ptr, plan->d_bias.ptr,
+                         plan->d_thrq.ptr, plan->d_zpc.ptr, out);
+    } else if (h.use_tiled) {
       tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const int64_t tasks = (int64_t)A.PT * A.NT;

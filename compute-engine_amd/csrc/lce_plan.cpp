@@ -166,6 +166,7 @@ void fold_parameters(HostPlan& p, const int32_t* filter_ohwi, const float* post_
   }
   p.have_weights = true;
   p.packed.clear();  // force a repack on the next select_kernel
+  p.wq.clear();
 }
 
 bool tiled_supports(const HostPlan& p, int tn) {
@@ -202,10 +203,143 @@ static void pack_for_tile(HostPlan& p) {
   std::copy(p.thresholds.begin(), p.thresholds.end(), p.thr_p.begin());
 }
 
+// ------------------------------------------------------------------------------------
+// matrix-core engine
+// ------------------------------------------------------------------------------------
+bool mfma_supported(const HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  if (d.groups != 1) return false;                       // one K range for all channels
+  if (p.backtransform_add >= (1 << 23)) return false;    // fp32 accumulation must stay exact
+  const int cpad = ceil_div(d.channels_in, 64) * 64;
+  const int64_t hp = std::max<int64_t>(p.pad_h + d.in_height,
+                                       (int64_t)(p.out_h - 1) * d.stride_height + (d.filter_height - 1) * d.dilation_height + 1);
+  const int64_t wp = std::max<int64_t>(p.pad_w + d.in_width,
+                                       (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
+  if (hp * wp * (cpad / 2) >= (1ll << 31)) return false; // one padded image must fit a buffer resource
+  if (hp * wp * (cpad / 32) >= (1ll << 31)) return false;
+  return true;
+}
+
+static const MfmaCfg kMfmaCfgs[] = {
+    {4, 2, 2, 4},  // 256 x 256, 8 waves
+    {4, 2, 2, 2},  // 256 x 128, 8 waves
+    {8, 1, 2, 2},  // 512 x  64, 8 waves
+    {2, 2, 2, 4},  // 128 x 256, 4 waves
+    {2, 2, 2, 2},  // 128 x 128, 4 waves
+    {4, 1, 2, 2},  // 256 x  64, 4 waves
+    {2, 1, 2, 2},  // 128 x  64, 2 waves
+};
+const MfmaCfg* mfma_cfg_by_tile(int bm, int bn) {
+  for (const MfmaCfg& c : kMfmaCfgs)
+    if (c.bm() == bm && c.bn() == bn) return &c;
+  return nullptr;
+}
+
+static void pack_for_mfma(HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const int taps = d.filter_height * d.filter_width, n = d.channels_out;
+  const int bn = p.mfma.bn();
+  p.cpad = ceil_div(d.channels_in, 64) * 64;
+  p.npad = ceil_div(n, bn) * bn;
+  const int kch = p.cpad / 64, ks_total = taps * kch;
+  p.wq.assign((size_t)ks_total * p.npad * 32, 0);
+  for (int oc = 0; oc < n; ++oc)
+    for (int t = 0; t < taps; ++t)
+      for (int c = 0; c < d.channels_in; ++c) {
+        const uint32_t w = p.filter[((size_t)oc * taps + t) * p.cwg + c / 32];
+        const uint8_t nib = ((w >> (c % 32)) & 1u) ? 0xA : 0x2;  // bit 1 = -1, bit 0 = +1
+        const int ks = t * kch + c / 64, j = c % 64;
+        uint8_t& byte = p.wq[((size_t)ks * p.npad + oc) * 32 + j / 2];
+        byte |= (uint8_t)(nib << (4 * (j & 1)));
+      }
+  p.mul_q.assign(p.npad, 0.0f);
+  p.bias_q.assign(p.npad, 0.0f);
+  std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
+  std::copy(p.bias.begin(), p.bias.end(), p.bias_q.begin());
+  // bit = (accum > thr)  <=>  d < K_bt - 2*thr; clamp so the float is exact, keep the
+  // always / never cases (|d| <= K_bt)
+  const int64_t a = p.backtransform_add;
+  p.thr_q.assign(p.npad, -(float)(a + 1));  // padded channels: never
+  for (size_t i = 0; i < p.thresholds.size(); ++i) {
+    int64_t t = a - 2 * (int64_t)p.thresholds[i];
+    t = std::max<int64_t>(-(a + 1), std::min<int64_t>(a + 1, t));
+    p.thr_q[i] = (float)t;
+  }
+}
+
+static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
+  const int n = p.d.channels_out;
+  // candidates by how well BN fits the channel count, then prefer the biggest block that
+  // still yields ~2 blocks per CU
+  const int bn_want = n > 128 ? 256 : n > 64 ? 128 : 64;
+  const MfmaCfg* best = nullptr;
+  for (const MfmaCfg& c : kMfmaCfgs) {
+    if (c.bn() != bn_want) continue;
+    const int64_t blocks = ((pixels + c.bm() - 1) / c.bm()) * ceil_div(n, c.bn());
+    if (!best) best = &c;                 // largest first in the table
+    if (blocks >= 512) { best = &c; break; }
+    best = &c;                            // otherwise keep shrinking
+  }
+  return best ? *best : kMfmaCfgs[4];
+}
+
+size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk) {
+  return (size_t)batch_chunk * p.hp * p.wp * (p.cpad / 2);
+}
+
+MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  MfmaArgs G{};
+  G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
+  G.Hp = p.hp; G.Wp = p.wp; G.PH = p.pad_h; G.PW = p.pad_w;
+  G.Kc = p.cpad / 2; G.CPW = p.cpad / 32; G.KCH = p.cpad / 64;
+  G.Npad = p.npad;
+  G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
+  G.x_bytes = (uint32_t)mfma_workspace_bytes(p, batch_chunk);
+  G.w_bytes = (uint32_t)p.wq.size();
+  G.div_cpw = make_fastdiv((uint32_t)G.CPW);
+  G.div_wp = make_fastdiv((uint32_t)G.Wp);
+  G.div_hp = make_fastdiv((uint32_t)G.Hp);
+  G.a_bt = (float)p.backtransform_add;
+  G.cmin = (float)p.clamp_min;
+  G.cmax = (float)p.clamp_max;
+  return G;
+}
+
 std::string select_kernel(HostPlan& p, int64_t pixels) {
   const lce_hip_bconv2d_desc& d = p.d;
   const bool bp = d.dst_type == LCE_HIP_BITPACKED;
   p.ch = (p.cwg % 4 == 0) ? 4 : (p.cwg % 2 == 0) ? 2 : 1;
+
+  // ---- engine: matrix cores vs xor-popcount VALU ----
+  p.use_mfma = false;
+  if (p.engine_pref == 2 && !mfma_supported(p))
+    return "bconv2d: the matrix-core engine cannot run this convolution (grouped, or too deep)";
+  if (p.engine_pref == 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
+                             mfma_supported(p) && pixels * d.channels_out >= (1 << 16))) {
+    p.use_mfma = true;
+    p.use_tiled = false;
+    MfmaCfg want = choose_mfma_cfg(p, pixels);
+    if (p.engine_pref == 2 && p.tile_pref.tm != 0) {
+      const MfmaCfg* forced = mfma_cfg_by_tile(p.tile_pref.tm, p.tile_pref.tn);
+      if (!forced) return "bconv2d: no matrix-core kernel instance for the requested block tile";
+      want = *forced;
+    }
+    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
+    p.mfma = want;
+    p.cpad = ceil_div(d.channels_in, 64) * 64;
+    p.npad = ceil_div(d.channels_out, want.bn()) * want.bn();
+    p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height,
+                                  (int64_t)(p.out_h - 1) * d.stride_height + (d.filter_height - 1) * d.dilation_height + 1);
+    p.wp = (int)std::max<int64_t>(p.pad_w + d.in_width,
+                                  (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
+    if (repack && p.have_weights) pack_for_mfma(p);
+    char nm[96];
+    snprintf(nm, sizeof nm, "bconv2d_mfma<%s,%dx%d>",
+             d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", want.bm(), want.bn());
+    p.kernel_name = nm;
+    return "";
+  }
 
   TileShape chosen{0, 0};
   if (p.kernel_pref != 2) {
@@ -264,6 +398,16 @@ int max_batch_per_launch(const HostPlan& p) {
   int64_t by_bytes = ((1ll << 31) - 1) / per_image_bytes;
   int64_t by_pixels = ((1ll << 31) - 64 * 4 - 1) / per_image_pixels;
   int64_t b = std::min(by_bytes, by_pixels);
+  if (p.engine_pref != 1 && mfma_supported(p)) {
+    // the FP4 workspace is 4x the bitpacked input (plus the halo) and is indexed in
+    // 16-byte chunks by a 32-bit counter
+    const int cpad = ceil_div(p.d.channels_in, 64) * 64;
+    const int64_t hp = std::max<int64_t>(p.pad_h + p.d.in_height,
+                                         (int64_t)(p.out_h - 1) * p.d.stride_height + (p.d.filter_height - 1) * p.d.dilation_height + 1);
+    const int64_t wp = std::max<int64_t>(p.pad_w + p.d.in_width,
+                                         (int64_t)(p.out_w - 1) * p.d.stride_width + (p.d.filter_width - 1) * p.d.dilation_width + 1);
+    b = std::min<int64_t>(b, (int64_t)(((1ll << 31) - 1) / (hp * wp * (cpad / 2))));
+  }
   b = std::max<int64_t>(1, std::min<int64_t>(b, p.d.batch));
   return (int)b;
 }

@@ -17,6 +17,17 @@ struct TileShape {
   int tm, tn;
 };
 
+// Block shape of the matrix-core kernel: wgm x wgn waves, each wm x wn MFMA tiles of 32x32.
+struct MfmaCfg {
+  int wgm, wgn, wm, wn;
+  int bm() const { return 32 * wm * wgm; }
+  int bn() const { return 32 * wn * wgn; }
+  int threads() const { return 64 * wgm * wgn; }
+  int lds_bytes() const { return 2 * (bm() + bn()) * 32; }
+};
+// The instantiated shapes, by block tile (pixels x channels).
+const MfmaCfg* mfma_cfg_by_tile(int bm, int bn);
+
 struct HostPlan {
   lce_hip_bconv2d_desc d{};
   // inferred by Prepare (tflite/kernels/bconv2d.cc:203-210)
@@ -42,6 +53,14 @@ struct HostPlan {
   int nt = 0;                              // channel tiles
   std::string kernel_name;
 
+  // matrix-core engine (lce_kernels_mfma.h)
+  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma
+  bool use_mfma = false;
+  MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
+  int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count
+  std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
+  std::vector<float> mul_q, bias_q, thr_q; // Npad entries
+
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
   std::vector<float> mul_p, bias_p;        // NT*TN, padded
@@ -66,6 +85,11 @@ std::string select_kernel(HostPlan& p, int64_t pixels);
 
 // Largest batch chunk one launch may take (buffer resources bind < 2 GiB).
 int max_batch_per_launch(const HostPlan& p);
+
+// Matrix-core engine: can it run this convolution, and its launch constants.
+bool mfma_supported(const HostPlan& p);
+MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
+size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 
 ConvArgs make_conv_args(const HostPlan& p, int batch_chunk);
 

@@ -52,6 +52,32 @@ void launch_lockstep(int grid_x, int block, F&& body) {
     }
 }
 
+// A whole 256-thread block in lock step: 4 waves x 64 real threads, a block barrier, shared
+// LDS and a per-wave exchange area for the MFMA emulation.
+template <typename F>
+void launch_block_lockstep(int grid_x, int grid_y, int block, size_t lds_bytes, F&& body) {
+  for (int by = 0; by < grid_y; ++by)
+    for (int bx = 0; bx < grid_x; ++bx) {
+      std::vector<uint8_t> lds(lds_bytes + 64, 0);
+      std::barrier<> block_bar(block);
+      std::vector<std::barrier<>*> wave_bar;
+      for (int w = 0; w < block / 64; ++w) wave_bar.push_back(new std::barrier<>(64));
+      std::vector<uint32_t> xchg((block / 64) * 64, 0), mx((block / 64) * 64 * 8, 0);
+      std::vector<std::thread> th;
+      for (int t = 0; t < block; ++t)
+        th.emplace_back([&, t] {
+          lce_dev::ThreadCtx& c = lce_dev::g_ctx;
+          const int w = t / 64;
+          c.bar = wave_bar[w]; c.xchg = xchg.data() + w * 64; c.mfma_xchg = mx.data() + w * 64 * 8;
+          c.block_bar = &block_bar; c.lds = lds.data();
+          c.bdim_x = block; c.gdim_x = grid_x; c.bid_x = bx; c.bid_y = by; c.tid_x = t;
+          body();
+        });
+      for (auto& x : th) x.join();
+      for (auto* b : wave_bar) delete b;
+    }
+}
+
 std::string g_err;
 
 }  // namespace
@@ -61,15 +87,17 @@ extern "C" {
 const char* hostsim_last_error() { return g_err.c_str(); }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
+// engine_pref: 0 auto, 1 valu, 2 mfma
 int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, const float* post_mul,
                     const float* post_bias, const int32_t* thresholds, const int32_t* input,
                     void* output, int kernel_pref, int tm, int tn, int max_batch, char* name_out,
-                    int name_len) {
+                    int name_len, int engine_pref) {
   HostPlan h;
   h.d = *desc;
   std::string err = validate_and_infer(h);
   if (!err.empty()) { g_err = err; return 1; }
   fold_parameters(h, filter, post_mul, post_bias, thresholds);
+  h.engine_pref = engine_pref;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};
   int chunk = max_batch_per_launch(h);
@@ -93,7 +121,20 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     const ConvArgs A = make_conv_args(h, nb);
     const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
-    if (h.use_tiled) {
+    if (h.use_mfma) {
+      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn());
+      if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
+      const MfmaArgs G = make_mfma_args(h, nb);
+      const size_t ws = mfma_workspace_bytes(h, nb);
+      std::vector<lce_dev::u32x4> work(ws / 16 + 16);
+      std::vector<uint8_t> wq = h.wq;
+      wq.resize(wq.size() + 64, 0);
+      launch_sequential(3, 1, 256, [&] { expand_fp4(in, work.data(), G, (uint64_t)ws / 16); });
+      const int bm = h.mfma.bm(), bn = h.mfma.bn();
+      launch_block_lockstep((A.M + bm - 1) / bm, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.lds_bytes(), [&] {
+        fn(A, G, (const uint8_t*)work.data(), wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
+      });
+    } else if (h.use_tiled) {
       tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const int64_t tasks = (int64_t)A.PT * A.NT;

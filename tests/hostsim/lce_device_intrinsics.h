@@ -28,8 +28,14 @@ struct f32x4 { float v[4]; float& operator[](int i) { return v[i]; } float opera
 
 constexpr int kWave = 64;
 
+struct f32x16 { float v[16]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
+
 struct ThreadCtx {
   int tid_x = 0, bid_x = 0, bid_y = 0, bdim_x = 1, gdim_x = 1;
+  // block-level state (lock-step block mode): LDS, block barrier, per-wave MFMA exchange
+  uint8_t* lds = nullptr;
+  std::barrier<>* block_bar = nullptr;
+  uint32_t* mfma_xchg = nullptr;  // per wave: 64 lanes x 8 dwords (a[4], b[4])
   // wave collectives (only valid when the 64 lanes of a wave run as real threads)
   std::barrier<>* bar = nullptr;
   uint32_t* xchg = nullptr;  // 64 slots shared by the wave
@@ -95,5 +101,39 @@ inline void xor_popc_acc(int& c0, int& c1, int& c2, int& c3, uint32_t w, uint32_
                          uint32_t a2, uint32_t a3) {
   c0 += popc(a0 ^ w); c1 += popc(a1 ^ w); c2 += popc(a2 ^ w); c3 += popc(a3 ^ w);
 }
+
+
+// ---- matrix-core path (lock-step block mode only) ----------------------------------
+// FP4 E2M1 code -> value for the codes the kernels use (0 -> 0, 0x2 -> +1, 0xA -> -1).
+inline int fp4_pm1(uint32_t nib) { return nib == 0x2 ? 1 : nib == 0xA ? -1 : 0; }
+inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
+  const int lane = g_ctx.tid_x & 63;
+  uint32_t* x = g_ctx.mfma_xchg;
+  for (int i = 0; i < 4; ++i) { x[lane * 8 + i] = a[i]; x[lane * 8 + 4 + i] = b[i]; }
+  g_ctx.bar->arrive_and_wait();
+  const int col = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    int sum = 0;
+    for (int k = 0; k < 64; ++k) {
+      const int j = k & 31, src_a = row + 32 * (k >> 5), src_b = col + 32 * (k >> 5);
+      const uint32_t na = (x[src_a * 8 + j / 8] >> (4 * (j % 8))) & 0xF;
+      const uint32_t nb = (x[src_b * 8 + 4 + j / 8] >> (4 * (j % 8))) & 0xF;
+      sum += fp4_pm1(na) * fp4_pm1(nb);
+    }
+    c[r] += (float)sum;
+  }
+  g_ctx.bar->arrive_and_wait();
+  return c;
+}
+inline f32x16 f32x16_zero() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.0f; return z; }
+inline uint8_t* lds_base() { return g_ctx.lds; }
+inline void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
+  const u32x4 v = buf_load_impl<u32x4>(r, byte_off);
+  memcpy(lds_dst + 16 * (g_ctx.tid_x & 63), &v, 16);
+}
+inline void block_sync() { g_ctx.block_bar->arrive_and_wait(); }
+inline void sched_fence() {}
+inline float med3(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 }  // namespace lce_dev

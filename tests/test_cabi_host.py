@@ -101,7 +101,9 @@ def test_kernel_selection_is_host_side_and_named():
     _, filt, mul, bias = synth.conv_inputs(O.ConvSpec(1, 3, 3, 256, 3, 3, 256), 1)
     plan = amd.Bconv2dPlan(_params(spec, amd.F32))
     plan.set_weights(filt, mul, bias)
-    assert plan.kernel_name().startswith("bconv2d_tiled<f32,TM=")
+    assert plan.kernel_name().startswith("bconv2d_mfma<f32,")         # auto: matrix-core engine
+    plan.set_option("engine", "valu")
+    assert plan.kernel_name().startswith("bconv2d_tiled<f32,TM=")     # xor-popcount engine
     plan.set_option("kernel", "general")
     assert plan.kernel_name() == "bconv2d_general<f32>"
     plan.set_option("kernel", "tiled")
@@ -109,6 +111,14 @@ def test_kernel_selection_is_host_side_and_named():
     assert plan.kernel_name() == "bconv2d_tiled<f32,TM=1,TN=32,CH=4>"
     with pytest.raises(amd.LceHipError):
         plan.set_option("tile", "3x7")
+    plan.set_option("kernel", "auto")
+    plan.set_option("engine", "mfma")
+    plan.set_option("tile", "128x128")
+    assert plan.kernel_name() == "bconv2d_mfma<f32,128x128>"
+    grouped = amd.Bconv2dPlan(amd.ConvParams(1, 8, 8, 128, 3, 3, 64, groups=2))
+    grouped.set_option("engine", "mfma")
+    assert grouped.kernel_name() == ""                              # refused: grouped convolution
+    assert "matrix-core engine cannot run" in amd.lib().lce_hip_last_error().decode()
 
 
 @pytest.mark.skipif(amd.device_count() > 0, reason="this test is about the GPU-less container")

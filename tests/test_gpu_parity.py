@@ -32,9 +32,10 @@ def _params(spec, dst, **kw):
 
 
 def _gpu_conv(spec, dst, x, w, mul=None, bias=None, thr=None, scale=1.0, zp=0, kernel="auto", tile="auto",
-              poison=True):
+              poison=True, engine="valu"):
     plan = amd.Bconv2dPlan(_params(spec, dst, out_scale=float(scale), out_zero_point=int(zp)))
     plan.set_weights(w, mul, bias, thr)
+    plan.set_option("engine", engine)
     plan.set_option("kernel", kernel)
     plan.set_option("tile", tile)
     xd = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
@@ -46,28 +47,28 @@ def _gpu_conv(spec, dst, x, w, mul=None, bias=None, thr=None, scale=1.0, zp=0, k
     return out.cpu().numpy(), name
 
 
-def _check_all_dst(spec, seed, kernel="auto", tile="auto"):
-    x, w, mul, bias = synth.conv_inputs(spec, seed)
+def _check_all_dst(spec, seed, kernel="auto", tile="auto", engine="valu"):
+    x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2 if engine == "mfma" else 0.0)
     zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
     names = []
     if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
         want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
-        got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel, tile=tile)
+        got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel, tile=tile, engine=engine)
         assert np.array_equal(got.view(np.int32), want.view(np.int32)), n
         names.append(n)
     if zero_pad and spec.semantics == O.SEM_OPTIMIZED:
         return names
     scale, zp = synth.int8_quant_params(seed)
     want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
-    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel, tile=tile)
+    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel, tile=tile, engine=engine)
     assert np.array_equal(got, want), n
     names.append(n)
-    if tile in ("auto", "2x32", "1x32"):
+    if tile in ("auto", "2x32", "1x32") or engine == "mfma":
         thr = O.thresholds_converter(spec, mul, bias)
         thr[::5] = np.iinfo(np.int32).max
         thr[1::7] = np.iinfo(np.int32).min
         want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
-        got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, kernel=kernel, tile=tile)
+        got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, kernel=kernel, tile=tile, engine=engine)
         assert np.array_equal(got, want), n
         names.append(n)
     return names
@@ -178,6 +179,37 @@ def test_conv_reference_grid(case):
         _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF)
 
 
+@pytest.mark.parametrize("case", [c for c in GRID if c[2] == 1], ids=_id)
+def test_conv_reference_grid_mfma_engine(case):
+    """Same grid through the FP4 matrix-core engine (groups == 1 only)."""
+    inp, flt, g, st, dil, pad, act = case
+    for sem in (O.SEM_REFERENCE, O.SEM_OPTIMIZED):
+        if not legal(inp, flt, g, pad, sem):
+            continue
+        padding, pv = PADS[pad]
+        spec = O.ConvSpec(inp[0], inp[1], inp[2], inp[3], flt[0], flt[1], flt[2], g, st[0], st[1],
+                          dil[0], dil[1], padding, pv, act, sem)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        names = _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF, engine="mfma")
+        assert all(n.startswith("bconv2d_mfma") for n in names)
+
+
+@pytest.mark.parametrize("tile", ["256x256", "256x128", "512x64", "128x256", "128x128", "256x64", "128x64"])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 40), (96, 33), (20, 7), (160, 96), (256, 130), (512, 256)])
+@pytest.mark.parametrize("pad", ["VALID", "SAME", "ONE"])
+def test_conv_every_mfma_tile(tile, cin, cout, pad):
+    padding, pv = PADS[pad]
+    for sem, st, dil, act in [(O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_NONE),
+                              (O.SEM_OPTIMIZED, (2, 1), (1, 2), O.ACT_NONE),
+                              (O.SEM_REFERENCE, (1, 2), (2, 1), O.ACT_RELU)]:
+        if pad == "SAME" and sem == O.SEM_REFERENCE and cin % 2:
+            continue
+        spec = O.ConvSpec(3, 9, 11, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pv, act, sem)
+        names = _check_all_dst(spec, cin * 7 + cout, tile=tile, engine="mfma")
+        assert all(("," + tile + ">") in n for n in names), names
+
+
 @pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("cin,cout,groups", [(64, 64, 1), (32, 40, 1), (96, 33, 1), (128, 64, 2),
                                              (256, 128, 4), (20, 7, 1), (160, 96, 1), (512, 64, 1)])
@@ -263,8 +295,9 @@ L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_ou
           padding=O.PADDING_SAME, pad_values=1)
 
 
+@pytest.mark.parametrize("engine", ["valu", "mfma"])
 @pytest.mark.parametrize("dst", [amd.F32, amd.I8, amd.BITPACKED])
-def test_l0_batch256_properties(dst):
+def test_l0_batch256_properties(dst, engine):
     """BASELINE config 2: 3x3 256->256 on 56x56, batch 256.
     (a) a seeded 4-image subset is bit-exact vs the CPU oracle;
     (b) batch independence: image i of the batched run == the same image run alone;
@@ -280,8 +313,9 @@ def test_l0_batch256_properties(dst):
     kw = dict(mul=mul, bias=bias) if dst != amd.BITPACKED else dict(thr=thr)
     if dst == amd.I8:
         kw.update(scale=scale, zp=zp)
+    kw["engine"] = engine
     got, name = _gpu_conv(spec, dst, x, w, **kw)
-    assert name.startswith("bconv2d_tiled")
+    assert name.startswith("bconv2d_tiled" if engine == "valu" else "bconv2d_mfma")
     # (a)
     subset = [0, 97, 200, 255]
     sub_spec = O.ConvSpec(batch=len(subset), **L0)
@@ -293,7 +327,7 @@ def test_l0_batch256_properties(dst):
     alone, _ = _gpu_conv(one, dst, x[97:98], w, **kw)
     assert np.array_equal(alone[0].view(np.uint8), got[97].view(np.uint8))
     # (c)
-    gen, gname = _gpu_conv(spec, dst, x, w, kernel="general", **kw)
+    gen, gname = _gpu_conv(spec, dst, x, w, kernel="general", **{**kw, "engine": "valu"})
     assert gname.startswith("bconv2d_general")
     assert zlib.crc32(gen.tobytes()) == zlib.crc32(got.tobytes())
     # (d)
@@ -317,6 +351,8 @@ def test_quicknet_layer_shapes_batch256(hw, c):
     got, name = _gpu_conv(spec, amd.F32, x, w, mul, bias)
     gen, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel="general")
     assert np.array_equal(got.view(np.int32), gen.view(np.int32)), name
+    mf, mname = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine="mfma")
+    assert mname.startswith("bconv2d_mfma") and np.array_equal(mf.view(np.int32), gen.view(np.int32)), mname
     subset = [0, 128, 255]
     want = O.bconv2d(O.ConvSpec(batch=3, **kwargs), O.DST_F32, x[subset], w, mul, bias, threads=8)
     assert np.array_equal(got[subset].view(np.int32), want.view(np.int32))

@@ -173,3 +173,80 @@ def test_bmaxpool(f, s, pad):
     g = synth.rng(99)
     x = synth.random_words(g, (2, 9, 7, 3))
     assert np.array_equal(H.bmaxpool(x, f[0], f[1], s[0], s[1], pad), O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
+
+
+# ------------------------------------------------------------------------------------ matrix-core engine
+
+MFMA_TILES = [(256, 256), (256, 128), (512, 64), (128, 256), (128, 128), (256, 64), (128, 64)]
+
+
+def _run_all_dst_mfma(spec, seed, tile=(0, 0), max_batch=0):
+    x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2)
+    zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
+    names = []
+    if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, tile=tile, max_batch=max_batch, engine="mfma")
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+        names.append(name)
+    if zero_pad and spec.semantics == O.SEM_OPTIMIZED:
+        return names
+    scale, zp = synth.int8_quant_params(seed)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
+    got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp,
+                          tile=tile, max_batch=max_batch, engine="mfma")
+    assert np.array_equal(got, want), name
+    names.append(name)
+    thr = O.thresholds_converter(spec, mul, bias)
+    thr[::5] = np.iinfo(np.int32).max
+    thr[1::7] = np.iinfo(np.int32).min
+    thr[2::11] = -1
+    want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
+    got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, tile=tile, max_batch=max_batch, engine="mfma")
+    assert np.array_equal(got, want), name
+    names.append(name)
+    return names
+
+
+@pytest.mark.parametrize("tile", MFMA_TILES, ids=lambda t: "%dx%d" % t)
+@pytest.mark.parametrize("cin,cout,pad", [(64, 64, "ONE"), (96, 33, "SAME"), (20, 7, "VALID"), (160, 130, "ONE")])
+def test_mfma_engine_every_tile(tile, cin, cout, pad):
+    """The FP4 matrix-core engine (expand_fp4 + bconv2d_mfma, MFMA emulated lane-exactly in
+    the host simulation) against the oracle: ragged pixel/channel tiles, channel counts
+    that are not multiples of 64, strides, dilation, both zero-padding semantics."""
+    padding, pad_values = PADS[pad]
+    combos = {"ONE": [(O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_NONE)],
+              "SAME": [(O.SEM_OPTIMIZED, (2, 1), (1, 2), O.ACT_NONE), (O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_RELU)],
+              "VALID": [(O.SEM_REFERENCE, (1, 2), (2, 1), O.ACT_RELU)]}[pad]
+    for sem, st, dil, act in combos:
+        spec = O.ConvSpec(2, 6, 7, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pad_values, act, sem)
+        names = _run_all_dst_mfma(spec, seed=cin * 3 + cout, tile=tile)
+        assert all("bconv2d_mfma" in n and ",%dx%d>" % tile in n for n in names), names
+
+
+def test_mfma_engine_reference_grid_sample():
+    n = 0
+    for case in CASES[:72:12] + CASES[72::160]:
+        for sem in (O.SEM_REFERENCE, O.SEM_OPTIMIZED):
+            if case[2] != 1 or not legal(case[0], case[1], case[2], case[5], sem):
+                continue
+            spec = _spec(case, sem)
+            if spec.out_h <= 0 or spec.out_w <= 0:
+                continue
+            _run_all_dst_mfma(spec, zlib.crc32(_id(case).encode()) & 0xFFFF)
+            n += 1
+    assert n >= 10
+
+
+def test_mfma_engine_batch_chunking_and_pointwise():
+    spec = O.ConvSpec(5, 6, 7, 64, 1, 1, 32)
+    _run_all_dst_mfma(spec, 11, max_batch=2)
+    spec = O.ConvSpec(3, 6, 7, 128, 3, 3, 48, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU6)
+    _run_all_dst_mfma(spec, 12, max_batch=1)
+
+
+def test_mfma_engine_refuses_grouped():
+    spec = O.ConvSpec(1, 6, 6, 128, 3, 3, 64, groups=2)
+    x, w, mul, bias = synth.conv_inputs(spec, 1)
+    with pytest.raises(RuntimeError, match="matrix-core engine cannot run"):
+        H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="mfma")

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Prints VGPR/AGPR/SGPR/scratch/occupancy for every kernel of the product library."""
+import re
+import subprocess
+import sys
+
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Icompute-engine_amd/csrc",
+       "-Rpass-analysis=kernel-resource-usage", "-c", "compute-engine_amd/csrc/lce_hip_api.hip", "-o", "/dev/null"]
+txt = subprocess.run(cmd, capture_output=True, text=True).stderr
+cur, rows = None, {}
+for line in txt.splitlines():
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+        cur = m.group(1)
+        rows[cur] = {}
+        continue
+    m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+) \[-R", line)
+    if m and cur:
+        rows[cur][m.group(1).strip()] = int(m.group(2))
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
+for k, v in rows.items():
+    name = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+    if flt and flt not in name:
+        continue
+    print("%-46s VGPR %4d AGPR %4d SGPR %4d scratch %5d occ %d" % (
+        name, v.get("VGPRs", 0), v.get("AGPRs", 0), v.get("TotalSGPRs", 0), v.get("ScratchSize", 0), v.get("Occupancy", 0)) + " sgpr-spill %d" % v.get("SGPRs Spill", 0))
