@@ -134,7 +134,38 @@ LCE_DEVICE void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off)
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, byte_off, 0, 0, 0);
 }
 LCE_DEVICE void block_sync() { __syncthreads(); }
+// Barrier that does NOT drain the VM counter: LDS-DMA copies issued for later pipeline
+// stages stay in flight across it.  Pair with wait_vmcnt<N>() for the stage being consumed.
+// (The waits use the s_waitcnt BUILTIN, not inline asm, so that hipcc's own wait-count
+//  bookkeeping sees them; with asm it re-waits conservatively in front of the MFMAs.)
+// gfx9 s_waitcnt immediate: vmcnt = [15:14]:[3:0], expcnt = [6:4], lgkmcnt = [11:8].
+LCE_DEVICE void block_barrier_keep_vm() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+}
+template <int N>
+LCE_DEVICE void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((((N >> 4) & 3) << 14) | (0xF << 8) | (0x7 << 4) | (N & 0xF));
+}
+// Orders a wave's own LDS writes before its own later LDS reads (and vice versa) when the
+// accesses go through differently-typed pointers: wait for the LDS queue, and stop the
+// compiler from moving LDS accesses across.
+LCE_DEVICE void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 LCE_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Pins an accumulator tile at this point of the program: the MFMAs that produce it cannot
+// be sunk below (hipcc otherwise moves the register-only MFMAs of a K-step past the NEXT
+// step's barrier, which serialises LDS latency and matrix work).
+LCE_DEVICE void pin(f32x16& c) { asm volatile("" : "+v"(c)); }
+// Ask the scheduler for the issue pattern {1 MFMA, 1 LDS read} x n inside the current region.
+template <int N>
+LCE_DEVICE void interleave_mfma_ldsread() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+  }
+}
 LCE_DEVICE float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 }  // namespace lce_dev

@@ -61,13 +61,13 @@ struct ConvArgs {
 struct MfmaArgs {
   int32_t H, W, Cw, Cin;   // source (bitpacked) tensor
   int32_t Hp, Wp, PH, PW;  // spatially padded FP4 workspace; input (0,0) sits at (PH,PW)
-  int32_t Kc;              // bytes per workspace pixel = Cpad / 2
-  int32_t CPW;             // 16-byte chunks per workspace pixel = Cpad / 32
+  uint32_t NPIX;           // workspace pixels of this launch = batch * Hp * Wp
+  int32_t CPW;             // 16-byte word planes of the workspace = Cpad / 32
   int32_t KCH;             // K-steps (of 64 channels) per filter tap = Cpad / 64
   int32_t Npad;            // output channels padded to the block tile
   int32_t zero_border;     // 1: border pixels are 0 (exact SAME-zero), 0: +1 (one-padding)
   uint32_t x_bytes, w_bytes;
-  FastDiv div_cpw, div_wp, div_hp;
+  FastDiv div_npix, div_wp, div_hp;
   float a_bt;              // KH*KW*Cin as float (back-transform constant)
   float cmin, cmax;        // output-transform clamps as floats (exact integers)
 };

@@ -11,8 +11,10 @@
 // engine is bit-exact to the xor-popcount one and ~5x higher in ceiling.
 //
 // Pipeline of one call:
-//   1. expand_fp4: bitpacked activations [B,H,W,Cw] -> FP4, spatially PADDED workspace
-//      [B,Hp,Wp,Cpad/2 bytes]; border pixels hold +1 (pad_values 1) or 0 (exact SAME-zero
+//   1. expand_fp4: bitpacked activations [B,H,W,Cw] -> FP4, spatially PADDED workspace laid
+//      out as word planes [Cpad/32][B,Hp,Wp][16 bytes] (one 16-byte element = the 32 channels
+//      of one input word), so that 64 consecutive pixels of one K-half are one contiguous
+//      KiB; border pixels hold +1 (pad_values 1) or 0 (exact SAME-zero
 //      padding: an outside tap then contributes 0 to <a,w>, which is what
 //      reference.h:100-103 adds as (Cin/G)/2 in popcount units); channels >= Cin hold 0.
 //      After this no kernel needs a bounds check.
@@ -48,8 +50,8 @@ expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaA
   const uint64_t stride = (uint64_t)grid_dim_x() * (uint64_t)block_dim_x();
   for (uint64_t e = (uint64_t)block_idx_x() * (uint64_t)block_dim_x() + (uint64_t)thread_idx_x();
        e < total; e += stride) {
-    const uint32_t pix = fastdiv((uint32_t)e, G.div_cpw);   // total < 2^31 (planner chunks the batch)
-    const int cc = (int)((uint32_t)e - pix * (uint32_t)G.CPW);
+    const int cc = (int)fastdiv((uint32_t)e, G.div_npix);   // word plane; total < 2^31 (planner chunks the batch)
+    const uint32_t pix = (uint32_t)e - (uint32_t)cc * G.NPIX;
     const uint32_t rowp = fastdiv(pix, G.div_wp);           // b * Hp + yp
     const int xp = (int)(pix - rowp * (uint32_t)G.Wp);
     const uint32_t b = fastdiv(rowp, G.div_hp);
@@ -74,13 +76,16 @@ expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaA
 
 // ---------------------------------------------------------------------------------
 // Step 2: the GEMM.
-//   xp : FP4 workspace, pixel (b, yp, xp) at ((b*Hp + yp)*Wp + xp) * Kc bytes
-//   wq : FP4 weights [KS][Npad][32 bytes]  (K-step major, so a block's B tile is one
-//        contiguous BN*32-byte run)
+//   xp : FP4 workspace, 16-byte element (plane cc, pixel (b, yp, xp)) at
+//        (cc * NPIX + (b*Hp + yp)*Wp + xp) * 16 bytes; K-step kc uses planes 2kc, 2kc+1
+//   wq : FP4 weights [KS][2 halves][Npad][16 bytes]
 //   thrf : bitpacked output: per-channel float t with  bit = (d < t)   (= accum > threshold)
 // ---------------------------------------------------------------------------------
-template <int DST, int WGM, int WGN, int WM, int WN>
-LCE_KERNEL void __launch_bounds__(64 * WGM * WGN)
+struct StepSteady { static constexpr bool value = true; };
+struct StepTail { static constexpr bool value = false; };
+
+template <int DST, int WGM, int WGN, int WM, int WN, int STAGES = 4>
+LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
              const uint8_t* __restrict__ wq, const float* __restrict__ mul,
              const float* __restrict__ bias, const float* __restrict__ thrf,
@@ -91,8 +96,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   constexpr int A_BYTES = BM * 32, B_BYTES = BN * 32, STAGE = A_BYTES + B_BYTES;
   // LDS image of a stage: A as [k-half][row][16 B], B as [k-half][channel][16 B]; a wave
   // fills it in 1-KiB pieces (64 rows of one half) with one LDS-DMA instruction each.
-  constexpr int A_PIECES = BM / 32, PIECES = (BM + BN) / 32;
-  constexpr int NP = (PIECES + NWAVES - 1) / NWAVES;  // pieces per wave per K-step
+  constexpr int A_PIECES = BM / 32;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tiles are filled in 64-row pieces");
 
   uint8_t* lds = lds_base();
@@ -106,30 +110,33 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
 
   // ---- this wave's share of the staging work ------------------------------------------
-  uint32_t src[NP];   // byte offset in xp (A piece, at tap (0,0) chunk 0) or in wq (B piece, K-step 0)
-  int dst[NP];        // LDS byte offset of the piece inside a stage (wave-uniform)
-  bool is_a[NP];
+  // Slot i of every wave is statically an A piece (i < NPA) or a B piece, so the inner
+  // loop needs no per-piece descriptor select.  When the piece count is not a multiple of
+  // the wave count the surplus slots re-copy an earlier piece (same bytes, same address).
+  constexpr int B_PIECES = BN / 32;
+  constexpr int NPA = (A_PIECES + NWAVES - 1) / NWAVES, NPB = (B_PIECES + NWAVES - 1) / NWAVES;
+  constexpr int NP = NPA + NPB;  // LDS-DMA instructions per wave per K-step
+  uint32_t a_src[NPA], b_src[NPB];   // per-lane byte offsets at K-step 0
+  int a_dst[NPA], b_dst[NPB];        // wave-uniform LDS byte offsets inside a stage
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    // surplus slots (PIECES not a multiple of NWAVES) re-copy an earlier piece: harmless
-    const int p = (wave + i * NWAVES) % PIECES;
-    is_a[i] = p < A_PIECES;
-    if (is_a[i]) {
-      const int half = p / (BM / 64), blk = p % (BM / 64);
-      dst[i] = half * (BM * 16) + blk * 1024;
-      int m = m0 + blk * 64 + lane;
-      m = m < A.M ? m : A.M - 1;  // tail rows re-read the last pixel; their results are not stored
-      const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);
-      const int ox = m - (int)rw_ * A.OW;
-      const uint32_t b = fastdiv(rw_, A.div_oh);
-      const int oy = (int)(rw_ - b * (uint32_t)A.OH);
-      src[i] = (uint32_t)((((int)b * G.Hp + oy * A.SH) * G.Wp + ox * A.SW) * G.Kc + half * 16);
-    } else {
-      const int q = p - A_PIECES;
-      const int half = q / (BN / 64), blk = q % (BN / 64);
-      dst[i] = A_BYTES + half * (BN * 16) + blk * 1024;
-      src[i] = (uint32_t)((n0 + blk * 64 + lane) * 32 + half * 16);
-    }
+  for (int i = 0; i < NPA; ++i) {
+    const int p = (wave + i * NWAVES) % A_PIECES;
+    const int half = p / (BM / 64), blk = p % (BM / 64);
+    a_dst[i] = half * (BM * 16) + blk * 1024;
+    int m = m0 + blk * 64 + lane;
+    m = m < A.M ? m : A.M - 1;  // tail rows re-read the last pixel; their results are not stored
+    const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);
+    const int ox = m - (int)rw_ * A.OW;
+    const uint32_t b = fastdiv(rw_, A.div_oh);
+    const int oy = (int)(rw_ - b * (uint32_t)A.OH);
+    a_src[i] = ((uint32_t)half * G.NPIX + (uint32_t)(((int)b * G.Hp + oy * A.SH) * G.Wp + ox * A.SW)) * 16u;
+  }
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int q = (wave + i * NWAVES) % B_PIECES;
+    const int half = q / (BN / 64), blk = q % (BN / 64);
+    b_dst[i] = A_BYTES + half * (BN * 16) + blk * 1024;
+    b_src[i] = (uint32_t)(half * G.Npad + n0 + blk * 64 + lane) * 16u;
   }
 
   f32x16 acc[WM][WN];
@@ -140,41 +147,104 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 
   const int KS = A.KH * A.KW * G.KCH;
 
-  auto fill = [&](int ks, int stage) {
-    const int tap = ks / G.KCH, kc = ks - tap * G.KCH;
-    const int fy = tap / A.KW, fx = tap - fy * A.KW;
-    const uint32_t a_delta = (uint32_t)((fy * A.DH * G.Wp + fx * A.DW) * G.Kc + kc * 32);
-    const uint32_t b_delta = (uint32_t)ks * (uint32_t)(G.Npad * 32);
+  // K-step ks = (tap (fy, fx), channel chunk kc).  fill() is always called with
+  // consecutive ks, so the operand offsets advance incrementally (a handful of scalar ops
+  // per K-step instead of divisions).
+  uint32_t a_off = 0, b_off = 0;    // byte offsets of the NEXT K-step to be filled
+  int f_kc = 0, f_fx = 0;
+  const uint32_t a_step_kc = 2u * G.NPIX * 16u;
+  const uint32_t a_step_fx = (uint32_t)A.DW * 16u - (uint32_t)G.KCH * a_step_kc;
+  const uint32_t a_step_fy = (uint32_t)(A.DH * G.Wp - A.KW * A.DW) * 16u;
+  const uint32_t b_step = (uint32_t)G.Npad * 32u;
+  auto fill = [&](int stage) {
     uint8_t* base = lds + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      buf_load_to_lds16(is_a[i] ? rx : rw, base + dst[i], src[i] + (is_a[i] ? a_delta : b_delta));
+    for (int i = 0; i < NPA; ++i) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
+    b_off += b_step;
+    a_off += a_step_kc;
+    if (++f_kc == G.KCH) {
+      f_kc = 0;
+      a_off += a_step_fx;
+      if (++f_fx == A.KW) {
+        f_fx = 0;
+        a_off += a_step_fy;
+      }
+    }
   };
 
-  // Two LDS stages: the DMA of K-step ks+1 flies while K-step ks is multiplied; the barrier
-  // at the end of the iteration waits for it (vmcnt) and for every wave's fragment reads.
-  fill(0, 0);
-  block_sync();
-
+  // STAGES-deep LDS ring + double-buffered fragment registers:
+  //   * the LDS-DMA of K-step ks+STAGES is issued during K-step ks, so ~3 K-steps of MFMA
+  //     work cover the DMA latency (~1 us under load);
+  //   * the fragments of K-step ks+1 are read from LDS while the MFMAs of K-step ks run,
+  //     so the matrix pipe restarts right after each barrier instead of waiting for LDS;
+  //   * the barrier in front of each K-step does not drain vmcnt: a wave waits (counted
+  //     vmcnt) only until ITS pieces of step ks+1 have landed, then the barrier makes all
+  //     waves' pieces visible and proves that stage ks % STAGES (whose fragments every wave
+  //     has finished reading) can be refilled.
   const int half = lane >> 5, l31 = lane & 31;
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) fill(ks + 1, (ks + 1) & 1);
-    const uint8_t* base = lds + (ks & 1) * STAGE;
-    u32x4 af[WM], bf[WN];
+  auto load_frags = [&](int ks, u32x4 (&af)[WM], u32x4 (&bf)[WN]) {
+    const uint8_t* base = lds + (ks % STAGES) * STAGE;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
       af[i] = *(const u32x4*)(base + half * (BM * 16) + ((wm * WM + i) * 32 + l31) * 16);
 #pragma unroll
     for (int j = 0; j < WN; ++j)
       bf[j] = *(const u32x4*)(base + A_BYTES + half * (BN * 16) + ((wn * WN + j) * 32 + l31) * 16);
+  };
+  // One K-step.  `steady` (compile-time) = the ring is full: a refill is due and exactly
+  // STAGES-1 younger fills are in flight, so the wait count is exact and nothing branches.
+  auto step = [&](auto steady, int ks, u32x4 (&af)[WM], u32x4 (&bf)[WN], u32x4 (&af_next)[WM],
+                  u32x4 (&bf_next)[WN]) {
+    if constexpr (decltype(steady)::value) {
+      wait_vmcnt<NP * (STAGES - 2)>();          // own pieces of step ks+1 have landed
+      block_barrier_keep_vm();
+      fill(ks % STAGES);                         // step ks+STAGES into the stage just vacated
+      load_frags(ks + 1, af_next, bf_next);
+    } else {
+      wait_vmcnt<0>();                           // tail: fewer fills in flight than the exact count
+      block_barrier_keep_vm();
+      if (ks + STAGES < KS) fill(ks % STAGES);
+      if (ks + 1 < KS) load_frags(ks + 1, af_next, bf_next);
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[i][j] = mfma_fp4_32x32x64(af[i], bf[j], acc[i][j]);
-    block_sync();
+    interleave_mfma_ldsread<WM + WN>();          // next step's fragment reads ride between the MFMAs
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) pin(acc[i][j]);  // ... and the MFMAs stay in front of the next barrier
+  };
+
+#pragma unroll
+  for (int d = 0; d < STAGES; ++d)
+    if (d < KS) fill(d);
+  if (STAGES <= KS) wait_vmcnt<NP * (STAGES - 1)>();
+  else wait_vmcnt<0>();
+  block_barrier_keep_vm();
+  u32x4 af0[WM], bf0[WN], af1[WM], bf1[WN];
+  load_frags(0, af0, bf0);
+  int ks = 0;
+  for (; ks + 1 + STAGES < KS; ks += 2) {       // both steps of the pair are steady
+    step(StepSteady{}, ks, af0, bf0, af1, bf1);
+    step(StepSteady{}, ks + 1, af1, bf1, af0, bf0);
+  }
+  for (; ks < KS; ks += 2) {
+    step(StepTail{}, ks, af0, bf0, af1, bf1);
+    if (ks + 1 < KS) step(StepTail{}, ks + 1, af1, bf1, af0, bf0);
   }
 
   // ------------------------------ fused output transform ------------------------------
+  // An accumulator tile is held "one channel per lane" (column = lane & 31, 16 pixel rows in
+  // 16 registers), which would make every global store a 4-byte-per-lane affair.  Instead:
+  //   * float / int8: the transformed 32x32 tile is transposed through a wave-private 4-KiB
+  //     LDS scratch (the pipeline ring is idle by now) so that a lane owns 4 consecutive
+  //     channels of one pixel and 8 lanes write a full 128-byte line with 16-byte stores;
+  //   * bitpacked: the 32 channel bits of a pixel are one v_cmp + ballot; the words are
+  //     gathered so that lane p owns pixel row p and stores its WN words at once.
   const float a_bt = G.a_bt, cminf = G.cmin, cmaxf = G.cmax;
   float mj[WN], bj[WN], tj[WN];
 #pragma unroll
@@ -184,45 +254,110 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     if constexpr (DST == kDstBitpacked) tj[j] = thrf[n];
     else { mj[j] = mul[n]; bj[j] = bias[n]; }
   }
-  const bool correct = DST == kDstFloat && A.zero_pad_mode == kZeroPadCorrection;
+
+  if constexpr (DST == kDstBitpacked) {
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
+    for (int i = 0; i < WM; ++i) {
+      uint32_t words[WN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int m = m0 + (wm * WM + i) * 32 + row;
-      const bool mvalid = m < A.M;
-      int zrow = -1;
-      if (correct && mvalid) {                                  // optimized_bgemm.h:153-177
-        const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);
-        const int ox = m - (int)rw_ * A.OW;
-        const int oy = (int)(rw_ - fastdiv(rw_, A.div_oh) * (uint32_t)A.OH);
-        zrow = zero_pad_cache_row(A, oy, ox);
+      for (int j = 0; j < WN; ++j) words[j] = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // register r holds pixel rows q (lanes 0-31) and q + 4 (lanes 32-63) of the tile
+        const int q = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          // accum > threshold  <=>  d < K_bt - 2*threshold (output_transform.h:160-168)
+          const unsigned long long bits = wave_ballot(acc[i][j][r] < tj[j]);
+          words[j] = lane == q ? (uint32_t)bits : words[j];
+          words[j] = lane == q + 4 ? (uint32_t)(bits >> 32) : words[j];
+        }
       }
+      // lane p (< 32) now owns pixel row p of the tile: WN consecutive output words
+      const int m = m0 + (wm * WM + i) * 32 + lane;
+      const int w0 = (n0 + wn * WN * 32) >> 5;
+      if (lane < 32 && m < A.M) {
+        uint32_t* o = (uint32_t*)out + (size_t)m * (size_t)A.Wout + (size_t)w0;
+        if (WN == 4 && w0 + 4 <= A.Wout && (A.Wout & 3) == 0) {
+          u32x4 v = {words[0], words[WN > 1 ? 1 : 0], words[WN > 2 ? 2 : 0], words[WN > 3 ? 3 : 0]};
+          *(u32x4*)o = v;
+        } else if (WN >= 2 && w0 + WN <= A.Wout && (A.Wout & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < WN; j += 2) {
+            u32x2 v = {words[j], words[j + 1 < WN ? j + 1 : j]};
+            *(u32x2*)(o + j) = v;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            if (w0 + j < A.Wout) o[j] = words[j];
+        }
+      }
+    }
+  } else {
+    float* scratch = (float*)(lds + wave * 4096);              // [32 rows][32 channels]
+    const int trow = lane >> 3, tcol = (lane & 7) * 4;          // after the transpose
+    const bool correct = DST == kDstFloat && A.zero_pad_mode == kZeroPadCorrection;
+    const bool vec_ok = (A.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int nbase = n0 + (wn * WN + j) * 32;
-        const int n = nbase + l31;
-        const float d = acc[i][j][r];                           // exact +-1 dot product
-        if constexpr (DST == kDstBitpacked) {
-          // accum > threshold  <=>  d < K_bt - 2*threshold (output_transform.h:160-168)
-          const unsigned long long bits = wave_ballot(d < tj[j]);
-          if (l31 == 0 && mvalid && nbase < A.N)
-            ((uint32_t*)out)[(size_t)m * (size_t)A.Wout + (size_t)(nbase >> 5)] = (uint32_t)(bits >> (32 * half));
-        } else {
-          const float x = med3(a_bt - d, cminf, cmaxf);         // = float(clamp(accum << 1))
-          float y = mul_then_add(x, mj[j], bj[j]);
-          if (mvalid && n < A.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float x = med3(a_bt - acc[i][j][r], cminf, cmaxf);  // = float(clamp(accum << 1))
+          scratch[row * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = trow + 8 * k;
+          const int m = m0 + (wm * WM + i) * 32 + row;
+          const int n = nbase + tcol;
+          f32x4 y = *(const f32x4*)(scratch + row * 32 + tcol);
+          if (m < A.M && n < A.N) {
             if constexpr (DST == kDstFloat) {
-              if (zrow >= 0) y = __fadd_rn(y, zpc[zrow + n]);
-              ((float*)out)[(size_t)m * (size_t)A.N + (size_t)n] = y;
+              if (correct) {                                    // optimized_bgemm.h:153-177
+                const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);
+                const int ox = m - (int)rw_ * A.OW;
+                const int oy = (int)(rw_ - fastdiv(rw_, A.div_oh) * (uint32_t)A.OH);
+                const int zrow = zero_pad_cache_row(A, oy, ox);
+                if (zrow >= 0) {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    if (n + c < A.N) y[c] = __fadd_rn(y[c], zpc[zrow + n + c]);
+                }
+              }
+              float* o = (float*)out + (size_t)m * (size_t)A.N + (size_t)n;
+              if (vec_ok && n + 4 <= A.N) {
+                *(f32x4*)o = y;
+              } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                  if (n + c < A.N) o[c] = y[c];
+              }
             } else {
-              float q = round_half_away(y);
-              q = fminf(fmaxf(q, -128.0f), 127.0f);
-              ((int8_t*)out)[(size_t)m * (size_t)A.N + (size_t)n] = (int8_t)(int)q;
+              uint32_t pk = 0;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                float q = round_half_away(y[c]);
+                q = fminf(fmaxf(q, -128.0f), 127.0f);
+                pk |= ((uint32_t)(int)q & 0xffu) << (8 * c);
+              }
+              int8_t* o = (int8_t*)out + (size_t)m * (size_t)A.N + (size_t)n;
+              if (vec_ok && n + 4 <= A.N) {
+                *(uint32_t*)o = pk;
+              } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                  if (n + c < A.N) o[c] = (int8_t)(pk >> (8 * c));
+              }
             }
           }
         }
+        wave_lds_fence();
       }
     }
   }

@@ -248,9 +248,9 @@ static void pack_for_mfma(HostPlan& p) {
       for (int c = 0; c < d.channels_in; ++c) {
         const uint32_t w = p.filter[((size_t)oc * taps + t) * p.cwg + c / 32];
         const uint8_t nib = ((w >> (c % 32)) & 1u) ? 0xA : 0x2;  // bit 1 = -1, bit 0 = +1
-        const int ks = t * kch + c / 64, j = c % 64;
-        uint8_t& byte = p.wq[((size_t)ks * p.npad + oc) * 32 + j / 2];
-        byte |= (uint8_t)(nib << (4 * (j & 1)));
+        const int ks = t * kch + c / 64, j = c % 64, half = j / 32, jj = j % 32;
+        uint8_t& byte = p.wq[(((size_t)ks * 2 + half) * p.npad + oc) * 16 + jj / 2];
+        byte |= (uint8_t)(nib << (4 * (jj & 1)));
       }
   p.mul_q.assign(p.npad, 0.0f);
   p.bias_q.assign(p.npad, 0.0f);
@@ -268,19 +268,18 @@ static void pack_for_mfma(HostPlan& p) {
 }
 
 static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
+  // Measured on MI355X (profiles/r01/tile_sweep_*.jsonl): 4-wave blocks with two or more
+  // blocks resident per CU beat the 8-wave 256x256 block (independent barriers overlap one
+  // block's LDS/epilogue phases with another's MFMAs).  Pick BN by the channel count, then
+  // halve it while the grid would leave CUs idle.
   const int n = p.d.channels_out;
-  // candidates by how well BN fits the channel count, then prefer the biggest block that
-  // still yields ~2 blocks per CU
-  const int bn_want = n > 128 ? 256 : n > 64 ? 128 : 64;
-  const MfmaCfg* best = nullptr;
-  for (const MfmaCfg& c : kMfmaCfgs) {
-    if (c.bn() != bn_want) continue;
-    const int64_t blocks = ((pixels + c.bm() - 1) / c.bm()) * ceil_div(n, c.bn());
-    if (!best) best = &c;                 // largest first in the table
-    if (blocks >= 512) { best = &c; break; }
-    best = &c;                            // otherwise keep shrinking
-  }
-  return best ? *best : kMfmaCfgs[4];
+  int bn = n > 128 ? 256 : n > 64 ? 128 : 64;
+  auto blocks = [&](int bm, int bn_) { return ((pixels + bm - 1) / bm) * (int64_t)ceil_div(n, bn_); };
+  while (bn > 64 && blocks(128, bn) < 512) bn /= 2;
+  const int bm = bn == 64 ? 256 : 128;
+  const MfmaCfg* c = mfma_cfg_by_tile(bm, bn);
+  if (bn == 64 && blocks(256, 64) < 512) c = mfma_cfg_by_tile(128, 64);
+  return c ? *c : kMfmaCfgs[4];
 }
 
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk) {
@@ -292,12 +291,12 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   MfmaArgs G{};
   G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
   G.Hp = p.hp; G.Wp = p.wp; G.PH = p.pad_h; G.PW = p.pad_w;
-  G.Kc = p.cpad / 2; G.CPW = p.cpad / 32; G.KCH = p.cpad / 64;
+  G.NPIX = (uint32_t)((int64_t)batch_chunk * p.hp * p.wp); G.CPW = p.cpad / 32; G.KCH = p.cpad / 64;
   G.Npad = p.npad;
   G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
   G.x_bytes = (uint32_t)mfma_workspace_bytes(p, batch_chunk);
   G.w_bytes = (uint32_t)p.wq.size();
-  G.div_cpw = make_fastdiv((uint32_t)G.CPW);
+  G.div_npix = make_fastdiv(G.NPIX);
   G.div_wp = make_fastdiv((uint32_t)G.Wp);
   G.div_hp = make_fastdiv((uint32_t)G.Hp);
   G.a_bt = (float)p.backtransform_add;

@@ -23,7 +23,8 @@ struct MfmaCfg {
   int bm() const { return 32 * wm * wgm; }
   int bn() const { return 32 * wn * wgn; }
   int threads() const { return 64 * wgm * wgn; }
-  int lds_bytes() const { return 2 * (bm() + bn()) * 32; }
+  static constexpr int kStages = 4;     // LDS ring depth of bconv2d_mfma
+  int lds_bytes() const { return kStages * (bm() + bn()) * 32; }
 };
 // The instantiated shapes, by block tile (pixels x channels).
 const MfmaCfg* mfma_cfg_by_tile(int bm, int bn);

@@ -133,7 +133,12 @@ inline void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
   memcpy(lds_dst + 16 * (g_ctx.tid_x & 63), &v, 16);
 }
 inline void block_sync() { g_ctx.block_bar->arrive_and_wait(); }
+inline void block_barrier_keep_vm() { g_ctx.block_bar->arrive_and_wait(); }
+template <int N> inline void wait_vmcnt() {}  // the simulated LDS-DMA is synchronous
+inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
 inline void sched_fence() {}
+inline void pin(f32x16&) {}
+template <int N> inline void interleave_mfma_ldsread() {}
 inline float med3(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 }  // namespace lce_dev

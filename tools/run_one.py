@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Run ONE bconv2d configuration a few times (for rocprofv3 counter passes).
+usage: run_one.py <H=W> <C> <f32|i8|bp> <valu|mfma> <tile|auto> [steps] [batch]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import synth  # noqa: E402
+
+amd = importlib.import_module("compute-engine_amd")
+hw, dname, engine, tile = int(sys.argv[1]), sys.argv[3], sys.argv[4], sys.argv[5]
+cin, cout = (int(v) for v in sys.argv[2].split("x")) if "x" in sys.argv[2] else (int(sys.argv[2]), int(sys.argv[2]))
+c = cin
+steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+B = int(sys.argv[7]) if len(sys.argv) > 7 else 256
+dst = {"f32": amd.F32, "i8": amd.I8, "bp": amd.BITPACKED}[dname]
+one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=cout,
+                 padding=O.PADDING_SAME, pad_values=1)
+_, w, mul, bias = synth.conv_inputs(one, 3)
+x = torch.from_numpy(synth.random_words(synth.rng(4), (B, hw, hw, (c + 31) // 32), c)).to("cuda:0")
+p = amd.ConvParams(B, hw, hw, c, 3, 3, cout, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
+                   out_scale=0.125, out_zero_point=3)
+plan = amd.Bconv2dPlan(p)
+plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
+plan.set_option("engine", engine)
+if tile != "auto":
+    if engine == "valu":
+        plan.set_option("kernel", "tiled")
+    plan.set_option("tile", tile)
+out = plan.run(x)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(steps):
+    plan.run(x, out)
+e1.record()
+torch.cuda.synchronize()
+print(plan.kernel_name(), e0.elapsed_time(e1) / steps, "ms")
