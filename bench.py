@@ -13,10 +13,11 @@ only for the barrier and the max-over-ranks of the elapsed time.  `value` is who
 binary MACs per second.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (bconv2d_tiled): algorithmic bytes per launch / mean launch
-                duration (events on the launch stream) vs the 8 TB/s HBM peak.  The kernel
-                is integer-VALU bound, not HBM bound, so the `alu` object gives
-                the fraction of the v_xor+v_bcnt VALU peak as well.
+  roofline      dominant kernel (bconv2d_mfma, or bconv2d_tiled with engine=valu): algorithmic
+                bytes per launch / mean launch duration (events on the launch stream, kernel
+                timed alone) vs the 8 TB/s HBM peak -- the binding roofline of this layer;
+  compute       the same kernel against the other roofline (FP4 MFMA peak, or the measured
+                v_xor+v_bcnt pair ceiling for the xor-popcount engine);
   cpu_baseline  the CPU oracle (a port of the reference's portable C++ path) on the host
                 cores, on a bounded sample of the same workload (rank 0, N == 1 only).
 """
@@ -37,7 +38,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_BMAC_PEAK = 256 * 4 * 32 * 2.4e9 * 32 / 2         # 256 CU x 4 SIMD-32 x 2.4 GHz, 2 VALU ops / 32 bMAC
+MFMA_FP4_PEAK_TFLOPS = 10000.0                         # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
+VALU_BMAC_PEAK = 8.1e14                                # measured v_xor+v_bcnt ceiling (profiles/r01/valu_peak_microbench.jsonl)
 
 L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_out=256)
 QUICKNET = [(56, 64), (28, 128), (14, 256), (7, 512)]  # (H=W, C): 4 layers each in QuickNet
@@ -57,8 +59,18 @@ def algorithmic_bytes(spec, dst) -> int:
     return inp + wts + params + out
 
 
-def time_layer(amd, torch, spec, dst, steps, warmup, seed, dev, scale=1.0, zp=0):
-    """Returns (mean seconds per launch from stream events, kernel name)."""
+def _event_time(torch, dev, fn, steps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / 1e3 / steps
+
+
+def time_layer(amd, torch, spec, dst, steps, warmup, seed, dev, scale=1.0, zp=0, engine="auto"):
+    """Returns (mean seconds per step from stream events, kernel name, plan, x, out)."""
     import oracle_lib as O
     import synth
     one = O.ConvSpec(**{**{k: getattr(spec, k) for k in (
@@ -75,18 +87,13 @@ def time_layer(amd, torch, spec, dst, steps, warmup, seed, dev, scale=1.0, zp=0)
     plan = amd.Bconv2dPlan(p)
     thr = O.thresholds_converter(one, mul, bias) if dst == amd.BITPACKED else None
     plan.set_weights(w, mul, bias, thr)
+    plan.set_option("engine", engine)
     dt = {amd.F32: torch.float32, amd.I8: torch.int8, amd.BITPACKED: torch.int32}[dst]
     out = torch.empty(plan.output_shape, dtype=dt, device=dev)
-    for _ in range(warmup):
+    for _ in range(max(1, warmup)):
         plan.run(x, out)
     torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(steps):
-        plan.run(x, out)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) / 1e3 / steps, plan.kernel_name(), plan, x, out
+    return _event_time(torch, dev, lambda: plan.run(x, out), steps), plan.kernel_name(), plan, x, out
 
 
 def cpu_baseline(target_seconds=12.0):
@@ -145,8 +152,8 @@ def main():
     global_batch = args.batch * world
     _, my_batch = shard.shard_range(global_batch, world, rank)
     spec = O.ConvSpec(batch=my_batch, padding=O.PADDING_SAME, pad_values=1, **L0)
-    # warm up + per-launch kernel time from stream events
-    k_sec, kname, plan, x, out = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev)
+    # warm up + per-step time from stream events (a step = every kernel of one LceBconv2d call)
+    step_sec, kname, plan, x, out = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev)
 
     # the contract's timed region: barrier + sync, exactly K steps, sync + barrier, MAX over ranks
     def barrier():
@@ -166,22 +173,34 @@ def main():
     total_bmacs = spec.binary_macs * args.steps * world
     value = total_bmacs / elapsed
     abytes = algorithmic_bytes(spec, O.DST_F32)
+    mfma = kname.startswith("bconv2d_mfma")
 
     result = {
         "metric": "binary-MACs/sec (LceBconv2d 3x3 256->256, 56x56, batch 256/GPU, f32 out)",
         "value": value, "unit": "binary-MAC/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32 xor+popcount (int32 accumulate), f32 epilogue",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("fp4-e2m1 (exact +-1) matrix-core dot product, fp32 accumulate, f32 epilogue" if mfma
+                  else "u32 xor+popcount, int32 accumulate, f32 epilogue"),
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: LceBconv2d 3x3 s1 SAME(pad_values=1) 56x56x256->256, "
                                "float32 output transform, device-resident bitpacked input",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"batch-shard x{world} (no data-path collective)"},
-        "layer_latency_ms": k_sec * 1e3,
+        "layer_latency_ms": step_sec * 1e3,
         "per_gpu_value": value / world,
-        "kernel": kname,
+        "kernel": kname + ("+expand_fp4" if mfma else ""),
     }
     if rank == 0:
+        # dominant kernel alone (the GEMM of the matrix-core engine, or the single VALU kernel)
+        if mfma:
+            plan.set_option("phase", "gemm")
+            k_sec = _event_time(torch, dev, lambda: plan.run(x, out), args.steps)
+            plan.set_option("phase", "expand")
+            e_sec = _event_time(torch, dev, lambda: plan.run(x, out), args.steps)
+            plan.set_option("phase", "all")
+        else:
+            k_sec, e_sec = step_sec, 0.0
         ach = abytes / k_sec / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -192,45 +211,50 @@ def main():
                 traffic = None
         result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                              "algorithmic_bytes_per_launch": abytes,
-                              "kernel_ms": k_sec * 1e3,
-                              "note": "integer-VALU bound kernel; see alu"}
-        result["alu"] = {"achieved": spec.binary_macs / k_sec, "peak": VALU_BMAC_PEAK,
-                         "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
-                         "model": "v_xor_b32 + v_bcnt_u32_b32 per 32 bMAC; 256 CU x 4 SIMD-32 x 2.4 GHz"}
+                              "algorithmic_bytes_per_launch": abytes, "kernel": kname,
+                              "kernel_ms": k_sec * 1e3, "expand_fp4_ms": e_sec * 1e3,
+                              "note": "HBM is the binding roofline of this layer at spec peaks "
+                                      "(0.106 ms vs 0.095 ms of FP4 MFMA); see `compute` for the other one"}
+        if mfma:
+            tf = 2.0 * spec.binary_macs / k_sec / 1e12
+            result["compute"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / MFMA_FP4_PEAK_TFLOPS,
+                                 "model": "v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4), 2 FLOP per binary MAC"}
+        else:
+            result["compute"] = {"bound": "valu", "achieved": spec.binary_macs / k_sec, "peak": VALU_BMAC_PEAK,
+                                 "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
+                                 "model": "v_xor_b32 + v_bcnt_u32_b32 per 32 bMAC, measured pair ceiling"}
         if not args.no_extra and world == 1:
             extra = {}
             st, wu = max(5, args.steps // 5), 3
             sc, zp = 0.125, 3
             for nm, dst, od in (("l0_int8_out", amd.I8, O.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, O.DST_BITPACKED)):
-                s, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
-                extra[nm] = {"ms": s * 1e3, "bmac_per_s": spec.binary_macs / s, "kernel": kn,
-                             "GBps_algorithmic": algorithmic_bytes(spec, od) / s / 1e9}
+                s_, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
+                extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
+                             "GBps_algorithmic": algorithmic_bytes(spec, od) / s_ / 1e9}
+            # the xor-popcount engine on the same layer (the north star's literal formulation)
+            s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="valu")
+            extra["l0_f32_valu_engine"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
+                                           "valu_pair_frac": spec.binary_macs / s_ / VALU_BMAC_PEAK}
             tot = 0.0
             for hw, c in QUICKNET:
                 sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
                                 channels_out=c, padding=O.PADDING_SAME, pad_values=1)
-                s, kn, *_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
-                tot += 4 * s
+                s_, kn, *_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
+                tot += 4 * s_
                 extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {
-                    "ms": s * 1e3, "bmac_per_s": sp.binary_macs / s, "kernel": kn,
-                    "GBps_algorithmic": algorithmic_bytes(sp, O.DST_F32) / s / 1e9,
-                    "hbm_frac": algorithmic_bytes(sp, O.DST_F32) / s / 1e9 / HBM_PEAK_GBS}
+                    "ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
+                    "GBps_algorithmic": algorithmic_bytes(sp, O.DST_F32) / s_ / 1e9,
+                    "hbm_frac": algorithmic_bytes(sp, O.DST_F32) / s_ / 1e9 / HBM_PEAK_GBS}
             extra["quicknet_16_layers_ms"] = tot * 1e3
             # LceQuantize stream: float32 56x56x256 feature map, batch 256
             fx = torch.randn((args.batch, 56, 56, 256), device=dev)
             ow = amd.bitpack(fx)
             torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(st):
-                amd.bitpack(fx, out=ow)
-            e1.record()
-            torch.cuda.synchronize(dev)
-            s = e0.elapsed_time(e1) / 1e3 / st
+            s_ = _event_time(torch, dev, lambda: amd.bitpack(fx, out=ow), st)
             qb = fx.numel() * 4 + ow.numel() * 4
-            extra["lcequantize_f32_256x56x56x256"] = {"ms": s * 1e3, "GBps_algorithmic": qb / s / 1e9,
-                                                      "hbm_frac": qb / s / 1e9 / HBM_PEAK_GBS}
+            extra["lcequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": qb / s_ / 1e9,
+                                                      "hbm_frac": qb / s_ / 1e9 / HBM_PEAK_GBS}
             del fx, ow
             result["extra"] = extra
         if not args.no_cpu_baseline and world == 1:

@@ -377,6 +377,13 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     else if (!strcmp(value, "valu")) h.engine_pref = 1;
     else if (!strcmp(value, "mfma")) h.engine_pref = 2;
     else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma");
+  } else if (!strcmp(key, "phase")) {
+    // profiling aid for the matrix-core engine: time its two kernels separately
+    if (!strcmp(value, "all")) h.phase = 0;
+    else if (!strcmp(value, "expand")) h.phase = 1;
+    else if (!strcmp(value, "gemm")) h.phase = 2;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: phase must be all|expand|gemm");
+    return LCE_HIP_OK;
   } else if (!strcmp(key, "kernel")) {
     if (!strcmp(value, "auto")) h.kernel_pref = 0;
     else if (!strcmp(value, "tiled")) h.kernel_pref = 1;
@@ -442,8 +449,11 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
       }
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
       const uint64_t chunks = (uint64_t)ws / 16;
-      lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
-      LCE_HIP_TRY(hipGetLastError());
+      if (h.phase != 2) {
+        lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
+        LCE_HIP_TRY(hipGetLastError());
+      }
+      if (h.phase == 1) continue;
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
       const dim3 grid((unsigned)((A.M + bm - 1) / bm), (unsigned)(h.npad / bn));
       hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), (size_t)h.mfma.lds_bytes(), st, A, G,

@@ -56,6 +56,7 @@ struct HostPlan {
 
   // matrix-core engine (lce_kernels_mfma.h)
   int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma
+  int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   bool use_mfma = false;
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
   int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count
