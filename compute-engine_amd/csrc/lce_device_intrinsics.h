@@ -152,6 +152,8 @@ LCE_DEVICE void wait_vmcnt() {
 // accesses go through differently-typed pointers: wait for the LDS queue, and stop the
 // compiler from moving LDS accesses across.
 LCE_DEVICE void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+LCE_DEVICE void set_wave_priority_high() { __builtin_amdgcn_s_setprio(1); }
+LCE_DEVICE void set_wave_priority_normal() { __builtin_amdgcn_s_setprio(0); }
 LCE_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Pins an accumulator tile at this point of the program: the MFMAs that produce it cannot
 // be sunk below (hipcc otherwise moves the register-only MFMAs of a K-step past the NEXT
@@ -166,6 +168,9 @@ LCE_DEVICE void interleave_mfma_ldsread() {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
   }
 }
+// Streaming (non-temporal) 16-byte store for outputs that are written once and not re-read
+// by this kernel: keeps the L2 for the operands that ARE re-read.
+LCE_DEVICE void store_streaming(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }
 LCE_DEVICE float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 }  // namespace lce_dev

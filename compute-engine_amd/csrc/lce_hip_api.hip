@@ -448,7 +448,7 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
         plan->workspace_bytes = ws;
       }
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
-      const uint64_t chunks = (uint64_t)ws / 16;
+      const uint64_t chunks = (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4);  // threads of expand_fp4
       if (h.phase != 2) {
         lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
         LCE_HIP_TRY(hipGetLastError());

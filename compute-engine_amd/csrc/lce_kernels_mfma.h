@@ -45,32 +45,56 @@ LCE_DEVICE uint32_t spread8_to_nibbles(uint32_t bits8) {
   return x;  // bit i of the input sits at bit 4*i
 }
 
+LCE_DEVICE u32x4 fp4_of_word(uint32_t word, int valid) {
+  u32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cnt = valid - 8 * q;
+    const uint32_t mask = cnt >= 8 ? 0xffffffffu : (cnt <= 0 ? 0u : ((1u << (4 * cnt)) - 1u));
+    v[q] = ((spread8_to_nibbles(word >> (8 * q)) << 3) | 0x22222222u) & mask;
+  }
+  return v;
+}
+
+// One thread per (workspace pixel, group of 4 input words): a 16-byte read of the pixel's
+// words (when the row allows it) feeds four 16-byte writes into four consecutive word
+// planes; consecutive threads are consecutive pixels, so every plane write is coalesced.
 LCE_KERNEL void __launch_bounds__(256)
 expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaArgs G, uint64_t total) {
   const uint64_t stride = (uint64_t)grid_dim_x() * (uint64_t)block_dim_x();
+  const bool vec = (G.Cw & 3) == 0;
   for (uint64_t e = (uint64_t)block_idx_x() * (uint64_t)block_dim_x() + (uint64_t)thread_idx_x();
        e < total; e += stride) {
-    const int cc = (int)fastdiv((uint32_t)e, G.div_npix);   // word plane; total < 2^31 (planner chunks the batch)
-    const uint32_t pix = (uint32_t)e - (uint32_t)cc * G.NPIX;
-    const uint32_t rowp = fastdiv(pix, G.div_wp);           // b * Hp + yp
+    const int qg = (int)fastdiv((uint32_t)e, G.div_npix);    // word-plane group; total < 2^31
+    const uint32_t pix = (uint32_t)e - (uint32_t)qg * G.NPIX;
+    const uint32_t rowp = fastdiv(pix, G.div_wp);            // b * Hp + yp
     const int xp = (int)(pix - rowp * (uint32_t)G.Wp);
     const uint32_t b = fastdiv(rowp, G.div_hp);
     const int yp = (int)(rowp - b * (uint32_t)G.Hp);
     const int iy = yp - G.PH, ix = xp - G.PW;
     const bool inside = (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W;
-    uint32_t word = 0;  // outside the image: bit 0 = +1 (pad_values 1)
-    if (inside && cc < G.Cw) word = in[(((size_t)b * G.H + iy) * G.W + ix) * (size_t)G.Cw + cc];
-    int valid = G.Cin - cc * 32;  // channels of this chunk that really exist
-    valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
-    if (!inside && G.zero_border) valid = 0;
-    u32x4 v;
+    const int c0 = qg * 4;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};                        // outside the image: bit 0 = +1 (pad_values 1)
+    if (inside) {
+      const uint32_t* src = in + (((size_t)b * G.H + iy) * G.W + ix) * (size_t)G.Cw + c0;
+      if (vec && c0 + 4 <= G.Cw) {
+        const u32x4 v = *(const u32x4*)src;
+        w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
+      } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cnt = valid - 8 * q;
-      const uint32_t mask = cnt >= 8 ? 0xffffffffu : (cnt <= 0 ? 0u : ((1u << (4 * cnt)) - 1u));
-      v[q] = ((spread8_to_nibbles(word >> (8 * q)) << 3) | 0x22222222u) & mask;
+        for (int k = 0; k < 4; ++k)
+          if (c0 + k < G.Cw) w[k] = src[k];
+      }
     }
-    out[e] = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = c0 + k;
+      if (cc >= G.CPW) break;
+      int valid = G.Cin - cc * 32;                             // channels of this word that exist
+      valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
+      if (!inside && G.zero_border) valid = 0;
+      out[(size_t)cc * G.NPIX + pix] = fp4_of_word(w[k], valid);
+    }
   }
 }
 
@@ -104,7 +128,16 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const int lane = tid & (kWave - 1);
   const int wave = uniform(tid >> 6);
   const int wm = wave % WGM, wn = wave / WGM;
-  const int m0 = block_idx_x() * BM, n0 = block_idx_y() * BN;
+  // Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, not
+  // promised).  Remapping so that an XCD works on a CONTIGUOUS run of pixel tiles lets
+  // neighbouring tiles share their halo rows in that XCD's L2.  Pure speed: any placement
+  // computes the same thing.
+  int bx = block_idx_x();
+  {
+    const int nb = grid_dim_x(), per = nb >> 3;
+    if (bx < per * 8) bx = (bx & 7) * per + (bx >> 3);   // the last nb % 8 blocks keep their index
+  }
+  const int m0 = bx * BM, n0 = block_idx_y() * BN;
 
   const rsrc_t rx = make_rsrc(xp, G.x_bytes);
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
@@ -332,7 +365,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
               }
               float* o = (float*)out + (size_t)m * (size_t)A.N + (size_t)n;
               if (vec_ok && n + 4 <= A.N) {
-                *(f32x4*)o = y;
+                store_streaming((f32x4*)o, y);
               } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)

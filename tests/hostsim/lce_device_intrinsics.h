@@ -136,9 +136,12 @@ inline void block_sync() { g_ctx.block_bar->arrive_and_wait(); }
 inline void block_barrier_keep_vm() { g_ctx.block_bar->arrive_and_wait(); }
 template <int N> inline void wait_vmcnt() {}  // the simulated LDS-DMA is synchronous
 inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
+inline void set_wave_priority_high() {}
+inline void set_wave_priority_normal() {}
 inline void sched_fence() {}
 inline void pin(f32x16&) {}
 template <int N> inline void interleave_mfma_ldsread() {}
+inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
 inline float med3(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 }  // namespace lce_dev
