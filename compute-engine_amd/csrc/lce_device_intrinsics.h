@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #define LCE_DEVICE __device__ __forceinline__
+#define LCE_LAMBDA_INLINE __attribute__((always_inline))
 #define LCE_KERNEL __global__
 
 namespace lce_dev {
@@ -56,6 +57,15 @@ LCE_DEVICE uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 LCE_DEVICE int popc(uint32_t x) { return __popc(x); }
 LCE_DEVICE bool wave_any(bool p) { return __ballot(p) != 0ull; }
 LCE_DEVICE unsigned long long wave_ballot(bool p) { return __ballot(p); }
+// v_writelane_b32: returns `old` with lane `lane_index` (a compile-time constant here)
+// replaced by the wave-uniform `value`.
+template <int LANE>
+LCE_DEVICE uint32_t write_lane(uint32_t value, uint32_t old) {
+  // s_nop: the SGPR holding `value` was just written by a VALU compare; hipcc does not pad
+  // hazards inside or in front of inline asm (without it lanes came back stale on gfx950).
+  asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
+  return old;
+}
 LCE_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
 LCE_DEVICE float round_half_away(float y) { return roundf(y); }  // std::round semantics
 

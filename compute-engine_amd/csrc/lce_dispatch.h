@@ -54,23 +54,25 @@ inline general_fn find_general(int dst) {
 typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const uint8_t*, const float*,
                         const float*, const float*, const float*, void*);
 
-template <int DST>
+// CORR = the optimized kernels' SAME-zero float correction in the epilogue (float output only)
+template <int DST, bool CORR>
 mfma_fn mfma_by_tile(int bm, int bn) {
-  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4>;
-  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2>;
-  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2>;
-  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4>;
-  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2>;
-  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2>;
-  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2>;
+  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR>;
+  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR>;
+  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR>;
+  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR>;
+  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR>;
+  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR>;
+  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR>;
   return nullptr;
 }
 
-inline mfma_fn find_mfma(int dst, int bm, int bn) {
+inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false) {
   switch (dst) {
-    case LCE_HIP_F32: return mfma_by_tile<kDstFloat>(bm, bn);
-    case LCE_HIP_I8: return mfma_by_tile<kDstInt8>(bm, bn);
-    default: return mfma_by_tile<kDstBitpacked>(bm, bn);
+    case LCE_HIP_F32:
+      return zero_pad_correction ? mfma_by_tile<kDstFloat, true>(bm, bn) : mfma_by_tile<kDstFloat, false>(bm, bn);
+    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false>(bm, bn);
+    default: return mfma_by_tile<kDstBitpacked, false>(bm, bn);
   }
 }
 

@@ -437,7 +437,7 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
     const uint32_t* in = (const uint32_t*)input_dev + (size_t)b0 * in_img_words;
     void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
     if (h.use_mfma) {
-      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn());
+      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t ws = lce::mfma_workspace_bytes(h, nb);
       if (plan->workspace_bytes < ws) {

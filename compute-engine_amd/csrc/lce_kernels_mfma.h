@@ -105,10 +105,11 @@ expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaA
 //   wq : FP4 weights [KS][2 halves][Npad][16 bytes]
 //   thrf : bitpacked output: per-channel float t with  bit = (d < t)   (= accum > threshold)
 // ---------------------------------------------------------------------------------
+template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
 
-template <int DST, int WGM, int WGN, int WM, int WN, int STAGES = 4>
+template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, int STAGES = 4>
 LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
              const uint8_t* __restrict__ wq, const float* __restrict__ mul,
@@ -294,18 +295,23 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       uint32_t words[WN];
 #pragma unroll
       for (int j = 0; j < WN; ++j) words[j] = 0u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // register r holds pixel rows q (lanes 0-31) and q + 4 (lanes 32-63) of the tile
-        const int q = (r & 3) + 8 * (r >> 2);
+      // register r holds pixel rows q (lanes 0-31) and q + 4 (lanes 32-63) of the tile,
+      // q = (r & 3) + 8 * (r >> 2);  accum > threshold <=> d < K_bt - 2*threshold
+      // (output_transform.h:160-168).  v_writelane drops each 32-channel word into the lane
+      // that will store it.
+      auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
+        constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          // accum > threshold  <=>  d < K_bt - 2*threshold (output_transform.h:160-168)
           const unsigned long long bits = wave_ballot(acc[i][j][r] < tj[j]);
-          words[j] = lane == q ? (uint32_t)bits : words[j];
-          words[j] = lane == q + 4 ? (uint32_t)(bits >> 32) : words[j];
+          words[j] = write_lane<q>((uint32_t)bits, words[j]);              // lane q     <- row q
+          words[j] = write_lane<q + 4>((uint32_t)(bits >> 32), words[j]);  // lane q + 4 <- row q + 4
         }
-      }
+      };
+      gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
+      gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
+      gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
+      gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
       // lane p (< 32) now owns pixel row p of the tile: WN consecutive output words
       const int m = m0 + (wm * WM + i) * 32 + lane;
       const int w0 = (n0 + wn * WN * 32) >> 5;
@@ -330,7 +336,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   } else {
     float* scratch = (float*)(lds + wave * 4096);              // [32 rows][32 channels]
     const int trow = lane >> 3, tcol = (lane & 7) * 4;          // after the transpose
-    const bool correct = DST == kDstFloat && A.zero_pad_mode == kZeroPadCorrection;
     const bool vec_ok = (A.N & 3) == 0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -352,7 +357,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           f32x4 y = *(const f32x4*)(scratch + row * 32 + tcol);
           if (m < A.M && n < A.N) {
             if constexpr (DST == kDstFloat) {
-              if (correct) {                                    // optimized_bgemm.h:153-177
+              if constexpr (CORR) {                             // optimized_bgemm.h:153-177
                 const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);
                 const int ox = m - (int)rw_ * A.OW;
                 const int oy = (int)(rw_ - fastdiv(rw_, A.div_oh) * (uint32_t)A.OH);

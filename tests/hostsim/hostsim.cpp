@@ -122,7 +122,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
     if (h.use_mfma) {
-      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn());
+      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const MfmaArgs G = make_mfma_args(h, nb);
       const size_t ws = mfma_workspace_bytes(h, nb);

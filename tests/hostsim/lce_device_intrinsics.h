@@ -14,6 +14,7 @@
 #include <vector>
 
 #define LCE_DEVICE inline
+#define LCE_LAMBDA_INLINE
 #define LCE_KERNEL inline
 #define __restrict__
 #define __launch_bounds__(...)
@@ -84,6 +85,10 @@ inline unsigned long long wave_ballot(bool p) {
 }
 // sequential mode: answering "true" is always safe -- the guarded code masks per lane
 inline bool wave_any(bool p) { return g_ctx.bar ? wave_ballot(p) != 0ull : true; }
+template <int LANE>
+inline uint32_t write_lane(uint32_t value, uint32_t old) {
+  return (g_ctx.tid_x & 63) == LANE ? value : old;
+}
 inline uint32_t shfl_xor(uint32_t v, int mask) {
   const int lane = g_ctx.tid_x & 63;
   g_ctx.xchg[lane] = v;
