@@ -55,25 +55,33 @@ typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const ui
                         const float*, const float*, const float*, void*);
 
 // CORR = the optimized kernels' SAME-zero float correction in the epilogue (float output only)
-template <int DST, bool CORR>
+// DIRECT = LDS-resident input halo instead of the FP4 workspace (lce_kernels_mfma.h)
+template <int DST, bool CORR, bool DIRECT>
 mfma_fn mfma_by_tile(int bm, int bn) {
-  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR>;
-  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR>;
-  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR>;
-  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR>;
-  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR>;
-  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR>;
-  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR>;
+  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR, DIRECT>;
+  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR, DIRECT>;
+  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR, DIRECT>;
+  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR, DIRECT>;
+  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR, DIRECT>;
+  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR, DIRECT>;
+  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR, DIRECT>;
   return nullptr;
 }
 
-inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false) {
+template <bool DIRECT>
+mfma_fn find_mfma_v(int dst, int bm, int bn, bool zero_pad_correction) {
   switch (dst) {
     case LCE_HIP_F32:
-      return zero_pad_correction ? mfma_by_tile<kDstFloat, true>(bm, bn) : mfma_by_tile<kDstFloat, false>(bm, bn);
-    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false>(bm, bn);
-    default: return mfma_by_tile<kDstBitpacked, false>(bm, bn);
+      return zero_pad_correction ? mfma_by_tile<kDstFloat, true, DIRECT>(bm, bn)
+                                 : mfma_by_tile<kDstFloat, false, DIRECT>(bm, bn);
+    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false, DIRECT>(bm, bn);
+    default: return mfma_by_tile<kDstBitpacked, false, DIRECT>(bm, bn);
   }
+}
+
+inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false) {
+  return direct ? find_mfma_v<true>(dst, bm, bn, zero_pad_correction)
+                : find_mfma_v<false>(dst, bm, bn, zero_pad_correction);
 }
 
 }  // namespace lce

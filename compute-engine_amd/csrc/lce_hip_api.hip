@@ -88,6 +88,7 @@ struct lce_hip_bconv2d_plan {
   DevBuf<uint8_t> d_wq;
   DevBuf<float> d_thrq;
   void* workspace = nullptr;       // FP4 expanded activations (matrix-core engine)
+  void* lds_opt_in = nullptr;      // kernel already granted > 64 KiB of dynamic LDS
   size_t workspace_bytes = 0;
   // staging for run_host
   void* stage_in = nullptr;
@@ -376,7 +377,8 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     if (!strcmp(value, "auto")) h.engine_pref = 0;
     else if (!strcmp(value, "valu")) h.engine_pref = 1;
     else if (!strcmp(value, "mfma")) h.engine_pref = 2;
-    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma");
+    else if (!strcmp(value, "direct")) h.engine_pref = 3;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct");
   } else if (!strcmp(key, "phase")) {
     // profiling aid for the matrix-core engine: time its two kernels separately
     if (!strcmp(value, "all")) h.phase = 0;
@@ -437,8 +439,24 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
     const uint32_t* in = (const uint32_t*)input_dev + (size_t)b0 * in_img_words;
     void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
     if (h.use_mfma) {
-      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection);
+      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
+                             h.use_direct);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
+      const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
+      const int bm = h.mfma.bm(), bn = h.mfma.bn();
+      if (h.use_direct) {
+        // no workspace: every block expands its own input halo into LDS
+        const size_t lds = (size_t)h.mfma.direct_lds_bytes(h.halo_bytes);
+        if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
+          LCE_HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          plan->lds_opt_in = (void*)fn;
+        }
+        const dim3 grid((unsigned)((int64_t)nb * h.tpi), (unsigned)(h.npad / bn));
+        hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), lds, st, A, G, (const uint8_t*)in, plan->d_wq.ptr,
+                           plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_zpc.ptr, out);
+        LCE_HIP_TRY(hipGetLastError());
+        continue;
+      }
       const size_t ws = lce::mfma_workspace_bytes(h, nb);
       if (plan->workspace_bytes < ws) {
         if (plan->workspace) (void)hipFree(plan->workspace);
@@ -447,14 +465,12 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
         LCE_HIP_TRY(hipMalloc(&plan->workspace, ws + 256));
         plan->workspace_bytes = ws;
       }
-      const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
       const uint64_t chunks = (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4);  // threads of expand_fp4
       if (h.phase != 2) {
         lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
         LCE_HIP_TRY(hipGetLastError());
       }
       if (h.phase == 1) continue;
-      const int bm = h.mfma.bm(), bn = h.mfma.bn();
       const dim3 grid((unsigned)((A.M + bm - 1) / bm), (unsigned)(h.npad / bn));
       hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), (size_t)h.mfma.lds_bytes(), st, A, G,
                          (const uint8_t*)plan->workspace, plan->d_wq.ptr, plan->d_mul.ptr, plan->d_bias.ptr,

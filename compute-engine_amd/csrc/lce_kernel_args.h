@@ -70,6 +70,14 @@ struct MfmaArgs {
   FastDiv div_npix, div_wp, div_hp;
   float a_bt;              // KH*KW*Cin as float (back-transform constant)
   float cmin, cmax;        // output-transform clamps as floats (exact integers)
+  // direct variant only (bconv2d_mfma<..., DIRECT>): a block's input halo lives in LDS
+  int32_t TPI;             // pixel tiles per image = ceil(OH*OW / BM); tiles never cross an image
+  int32_t OHOW;            // output pixels per image
+  int32_t halo_rows;       // input rows staged per tile (enough for any tile of the image)
+  int32_t PS;              // LDS bytes per halo pixel = CPW*16 + 16 (the +16 staggers banks)
+  int32_t halo_bytes;      // halo_rows * Wp * PS, rounded up to 1 KiB; the weight ring follows
+  int32_t QG;              // 16-byte groups of input words per pixel = ceil(CPW / 4)
+  FastDiv div_tpi, div_qg;
 };
 
 }  // namespace lce

@@ -109,7 +109,8 @@ template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
 
-template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, int STAGES = 4>
+template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, bool DIRECT = false,
+          int STAGES = DIRECT ? 3 : 4>
 LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
              const uint8_t* __restrict__ wq, const float* __restrict__ mul,
@@ -118,13 +119,15 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // WGM x WGN waves per block, each owning WM x WN MFMA tiles of 32x32
   constexpr int NWAVES = WGM * WGN;
   constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
-  constexpr int A_BYTES = BM * 32, B_BYTES = BN * 32, STAGE = A_BYTES + B_BYTES;
+  // DIRECT: the A operand is not staged per K-step at all (see "direct variant" below)
+  constexpr int A_BYTES = DIRECT ? 0 : BM * 32, B_BYTES = BN * 32, STAGE = A_BYTES + B_BYTES;
   // LDS image of a stage: A as [k-half][row][16 B], B as [k-half][channel][16 B]; a wave
   // fills it in 1-KiB pieces (64 rows of one half) with one LDS-DMA instruction each.
   constexpr int A_PIECES = BM / 32;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tiles are filled in 64-row pieces");
 
-  uint8_t* lds = lds_base();
+  uint8_t* const lds0 = lds_base();
+  uint8_t* const lds = lds0 + (DIRECT ? G.halo_bytes : 0);   // the K-step ring
   const int tid = thread_idx_x();
   const int lane = tid & (kWave - 1);
   const int wave = uniform(tid >> 6);
@@ -138,7 +141,16 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     const int nb = grid_dim_x(), per = nb >> 3;
     if (bx < per * 8) bx = (bx & 7) * per + (bx >> 3);   // the last nb % 8 blocks keep their index
   }
-  const int m0 = bx * BM, n0 = block_idx_y() * BN;
+  // GEMM variant: tile = BM consecutive pixels of the whole batch.  Direct variant: tile =
+  // BM consecutive pixels of ONE image (the last tile of an image is partial).
+  int m0 = bx * BM, m_end = A.M, p0 = 0, img = 0;
+  if constexpr (DIRECT) {
+    img = (int)fastdiv((uint32_t)bx, G.div_tpi);
+    p0 = (bx - img * G.TPI) * BM;
+    m0 = img * G.OHOW + p0;
+    m_end = (img + 1) * G.OHOW;
+  }
+  const int n0 = block_idx_y() * BN;
 
   const rsrc_t rx = make_rsrc(xp, G.x_bytes);
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
@@ -148,17 +160,17 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // loop needs no per-piece descriptor select.  When the piece count is not a multiple of
   // the wave count the surplus slots re-copy an earlier piece (same bytes, same address).
   constexpr int B_PIECES = BN / 32;
-  constexpr int NPA = (A_PIECES + NWAVES - 1) / NWAVES, NPB = (B_PIECES + NWAVES - 1) / NWAVES;
+  constexpr int NPA = DIRECT ? 0 : (A_PIECES + NWAVES - 1) / NWAVES, NPB = (B_PIECES + NWAVES - 1) / NWAVES;
   constexpr int NP = NPA + NPB;  // LDS-DMA instructions per wave per K-step
-  uint32_t a_src[NPA], b_src[NPB];   // per-lane byte offsets at K-step 0
-  int a_dst[NPA], b_dst[NPB];        // wave-uniform LDS byte offsets inside a stage
+  uint32_t a_src[NPA + 1], b_src[NPB];   // per-lane byte offsets at K-step 0
+  int a_dst[NPA + 1], b_dst[NPB];        // wave-uniform LDS byte offsets inside a stage
 #pragma unroll
   for (int i = 0; i < NPA; ++i) {
     const int p = (wave + i * NWAVES) % A_PIECES;
     const int half = p / (BM / 64), blk = p % (BM / 64);
     a_dst[i] = half * (BM * 16) + blk * 1024;
     int m = m0 + blk * 64 + lane;
-    m = m < A.M ? m : A.M - 1;  // tail rows re-read the last pixel; their results are not stored
+    m = m < m_end ? m : m_end - 1;  // tail rows re-read the last pixel; their results are not stored
     const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);
     const int ox = m - (int)rw_ * A.OW;
     const uint32_t b = fastdiv(rw_, A.div_oh);
@@ -218,11 +230,111 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   //     waves' pieces visible and proves that stage ks % STAGES (whose fragments every wave
   //     has finished reading) can be refilled.
   const int half = lane >> 5, l31 = lane & 31;
+
+  // start the pipeline: the first STAGES K-steps are on their way before anything else happens
+#pragma unroll
+  for (int d = 0; d < STAGES; ++d)
+    if (d < KS) fill(d);
+
+  // ---- direct variant: the tile's input halo, expanded to FP4 once, stays in LDS ---------
+  // The GEMM variant re-fetches every pixel of the tile once per filter tap (KH*KW times,
+  // 128 bytes each) through LDS-DMA, and needs a separate pass over the whole tensor to
+  // produce that FP4 image.  Here a block reads the bitpacked rows its tile needs (tile rows
+  // + filter extent) ONCE, expands them in registers and keeps the result in LDS as
+  //     halo[slot row][padded x][PS bytes],  PS = 16 bytes per input word + 16;
+  // the A fragment of pixel (oy, ox) for tap (fy, fx), chunk kc is then the 16 bytes at
+  //     ((oy - oy0)*SH + fy*DH) * Wp + ox*SW + fx*DW  pixels, + kc*32 + k-half*16 bytes:
+  // a per-lane base plus a wave-uniform cursor.  The +16 in PS makes 16 consecutive pixels
+  // hit 16 different bank groups (PS/4 = 4 mod 8 dwords).  No FP4 workspace, no A traffic in
+  // the K loop; only the weights stream through the ring.
+  uint32_t a_base[WM];
+  uint32_t a_cur = 0;               // byte offset of the K-step whose fragments are read next
+  int c_kc = 0, c_fx = 0;
+  if constexpr (DIRECT) {
+    const int oy0 = (int)fastdiv((uint32_t)p0, A.div_ow);
+    const int iy_first = oy0 * A.SH - G.PH;
+    const uint32_t* src_img = (const uint32_t*)xp + (size_t)img * G.H * G.W * (size_t)G.Cw;
+    const int items = G.halo_rows * G.Wp * G.QG;
+    const bool vec = (G.Cw & 3) == 0;
+    // Loads first, arithmetic second: a thread's (up to) PRE 16-byte loads are all in flight
+    // before the first one is consumed, so the block pays one memory latency for its halo
+    // instead of one per item.
+    constexpr int PRE = 4, NT = 64 * NWAVES;
+    for (int e0 = 0; e0 < items; e0 += PRE * NT) {
+      u32x4 wv[PRE];
+      int pixv[PRE], c0v[PRE];
+      bool inv[PRE];
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        const int e = e0 + k * NT + tid;
+        wv[k] = u32x4{0u, 0u, 0u, 0u};                           // outside: bit 0 = +1 (pad_values 1)
+        pixv[k] = -1; c0v[k] = 0; inv[k] = false;
+        if (e < items) {
+          const int pix = (int)fastdiv((uint32_t)e, G.div_qg);   // slot * Wp + x
+          const int c0 = (e - pix * G.QG) * 4;
+          const int slot = (int)fastdiv((uint32_t)pix, G.div_wp);
+          const int iy = iy_first + slot, ix = pix - slot * G.Wp - G.PW;
+          const bool inside = (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W;
+          pixv[k] = pix; c0v[k] = c0; inv[k] = inside;
+          if (inside) {
+            const uint32_t* src = src_img + ((size_t)iy * G.W + ix) * (size_t)G.Cw + c0;
+            if (vec && c0 + 4 <= G.Cw) {
+              wv[k] = *(const u32x4*)src;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (c0 + q < G.Cw) wv[k][q] = src[q];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        if (pixv[k] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cc = c0v[k] + q;
+          if (cc < G.CPW) {
+            int valid = G.Cin - cc * 32;                         // channels of this word that exist
+            valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
+            if (!inv[k] && G.zero_border) valid = 0;             // exact SAME-zero: 0 contributes 0
+            *(u32x4*)(lds0 + (size_t)pixv[k] * G.PS + cc * 16) = fp4_of_word(wv[k][q], valid);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      int p = p0 + (wm * WM + i) * 32 + l31;
+      p = p < G.OHOW ? p : G.OHOW - 1;   // rows past the image re-read its last pixel; never stored
+      const int oy = (int)fastdiv((uint32_t)p, A.div_ow);
+      const int ox = p - oy * A.OW;
+      a_base[i] = (uint32_t)(((oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
+    }
+  }
+  const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * 32u;
+  const uint32_t c_step_fy = (uint32_t)((A.DH * G.Wp - A.KW * A.DW) * G.PS);
+
+  // load_frags is always called with consecutive ks (0, 1, 2, ...), once each
   auto load_frags = [&](int ks, u32x4 (&af)[WM], u32x4 (&bf)[WN]) {
     const uint8_t* base = lds + (ks % STAGES) * STAGE;
+    if constexpr (DIRECT) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
-      af[i] = *(const u32x4*)(base + half * (BM * 16) + ((wm * WM + i) * 32 + l31) * 16);
+      for (int i = 0; i < WM; ++i) af[i] = *(const u32x4*)(lds0 + (a_base[i] + a_cur));
+      a_cur += 32u;
+      if (++c_kc == G.KCH) {
+        c_kc = 0;
+        a_cur += c_step_fx;
+        if (++c_fx == A.KW) {
+          c_fx = 0;
+          a_cur += c_step_fy;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        af[i] = *(const u32x4*)(base + half * (BM * 16) + ((wm * WM + i) * 32 + l31) * 16);
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j)
       bf[j] = *(const u32x4*)(base + A_BYTES + half * (BN * 16) + ((wn * WN + j) * 32 + l31) * 16);
@@ -253,9 +365,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       for (int j = 0; j < WN; ++j) pin(acc[i][j]);  // ... and the MFMAs stay in front of the next barrier
   };
 
-#pragma unroll
-  for (int d = 0; d < STAGES; ++d)
-    if (d < KS) fill(d);
   if (STAGES <= KS) wait_vmcnt<NP * (STAGES - 1)>();
   else wait_vmcnt<0>();
   block_barrier_keep_vm();
@@ -315,7 +424,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       // lane p (< 32) now owns pixel row p of the tile: WN consecutive output words
       const int m = m0 + (wm * WM + i) * 32 + lane;
       const int w0 = (n0 + wn * WN * 32) >> 5;
-      if (lane < 32 && m < A.M) {
+      if (lane < 32 && m < m_end) {
         uint32_t* o = (uint32_t*)out + (size_t)m * (size_t)A.Wout + (size_t)w0;
         if (WN == 4 && w0 + 4 <= A.Wout && (A.Wout & 3) == 0) {
           u32x4 v = {words[0], words[WN > 1 ? 1 : 0], words[WN > 2 ? 2 : 0], words[WN > 3 ? 3 : 0]};
@@ -334,7 +443,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       }
     }
   } else {
-    float* scratch = (float*)(lds + wave * 4096);              // [32 rows][32 channels]
+    float* scratch = (float*)(lds0 + wave * 4096);              // [32 rows][32 channels]
     const int trow = lane >> 3, tcol = (lane & 7) * 4;          // after the transpose
     const bool vec_ok = (A.N & 3) == 0;
 #pragma unroll
@@ -355,7 +464,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           const int m = m0 + (wm * WM + i) * 32 + row;
           const int n = nbase + tcol;
           f32x4 y = *(const f32x4*)(scratch + row * 32 + tcol);
-          if (m < A.M && n < A.N) {
+          if (m < m_end && n < A.N) {
             if constexpr (DST == kDstFloat) {
               if constexpr (CORR) {                             // optimized_bgemm.h:153-177
                 const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);

@@ -282,6 +282,49 @@ static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
   return c ? *c : kMfmaCfgs[4];
 }
 
+// Direct variant: does the input halo of a BM-pixel tile (plus the weight ring) fit LDS?
+bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  if (!mfma_supported(p)) return false;
+  const int cpad = ceil_div(d.channels_in, 64) * 64;
+  const int64_t wp = std::max<int64_t>(p.pad_w + d.in_width,
+                                       (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
+  const int bm = c.bm();
+  // a tile of bm consecutive pixels of one image touches at most this many output rows
+  const int rows_out = std::min(p.out_h, (bm + p.out_w - 2) / p.out_w + 1);
+  const int64_t rows = (int64_t)(rows_out - 1) * d.stride_height + (int64_t)(d.filter_height - 1) * d.dilation_height + 1;
+  const int64_t stride = (cpad / 32) * 16 + 16;
+  const int64_t bytes = (rows * wp * stride + 1023) / 1024 * 1024;
+  if (bytes + (int64_t)MfmaCfg::kDirectStages * c.bn() * 32 > 160 * 1024) return false;
+  *tpi = ceil_div(p.out_h * p.out_w, bm);
+  *halo_rows = (int)rows;
+  *ps = (int)stride;
+  *halo_bytes = (int)bytes;
+  return true;
+}
+
+// Block tile of the direct variant.  Tiles never cross an image, so the last tile of every
+// image is padded: the rule (from profiles/r01/tile_sweep_direct.jsonl) is 128 channels per
+// block when there are that many, 256 pixels unless that pads > 8 % more than 128 pixels
+// would, and no direct variant at all when less than 70 % of the tile rows are real (7x7
+// images) or the halo does not fit LDS -- the workspace GEMM, whose tiles span images, is
+// better there.
+bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out) {
+  const int ohow = p.out_h * p.out_w;
+  const int bn = p.d.channels_out > 64 ? 128 : 64;
+  auto padded = [&](int bm) { return (double)ceil_div(ohow, bm) * bm / (double)ohow; };
+  int order[2] = {256, 128};
+  if (padded(256) - padded(128) > 0.08) std::swap(order[0], order[1]);
+  for (int bm : order) {
+    const MfmaCfg* c = mfma_cfg_by_tile(bm, bn);
+    int a, b, c2, e;
+    if (!c || padded(bm) > 1.0 / 0.7 || !direct_geometry(p, *c, &a, &b, &c2, &e)) continue;
+    *out = *c;
+    return true;
+  }
+  return false;
+}
+
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk) {
   return (size_t)batch_chunk * p.hp * p.wp * (p.cpad / 2);
 }
@@ -302,6 +345,12 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   G.a_bt = (float)p.backtransform_add;
   G.cmin = (float)p.clamp_min;
   G.cmax = (float)p.clamp_max;
+  if (p.use_direct) {
+    G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;
+    G.halo_bytes = p.halo_bytes; G.QG = (G.CPW + 3) / 4;
+    G.div_tpi = make_fastdiv((uint32_t)G.TPI);
+    G.div_qg = make_fastdiv((uint32_t)G.QG);
+  }
   return G;
 }
 
@@ -312,17 +361,35 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
 
   // ---- engine: matrix cores vs xor-popcount VALU ----
   p.use_mfma = false;
-  if (p.engine_pref == 2 && !mfma_supported(p))
+  p.use_direct = false;
+  if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (grouped, or too deep)";
-  if (p.engine_pref == 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
+  if (p.engine_pref >= 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
                              mfma_supported(p) && pixels * d.channels_out >= (1 << 16))) {
     p.use_mfma = true;
     p.use_tiled = false;
     MfmaCfg want = choose_mfma_cfg(p, pixels);
-    if (p.engine_pref == 2 && p.tile_pref.tm != 0) {
+    bool direct = false;
+    if (p.engine_pref >= 2 && p.tile_pref.tm != 0) {
       const MfmaCfg* forced = mfma_cfg_by_tile(p.tile_pref.tm, p.tile_pref.tn);
       if (!forced) return "bconv2d: no matrix-core kernel instance for the requested block tile";
       want = *forced;
+      direct = p.engine_pref == 3;
+    } else if (p.engine_pref != 2) {
+      // auto / engine=direct without a tile: the direct variant when a good tile exists
+      MfmaCfg dc;
+      if (choose_direct_cfg(p, &dc)) {
+        want = dc;
+        direct = true;
+      } else if (p.engine_pref == 3) {
+        // forced: take any tile whose halo fits, whatever the padding waste
+        for (int bm : {128, 256}) {
+          const MfmaCfg* c = mfma_cfg_by_tile(bm, d.channels_out > 64 ? 128 : 64);
+          int a, b, c2, e;
+          if (c && direct_geometry(p, *c, &a, &b, &c2, &e)) { want = *c; direct = true; break; }
+        }
+        if (!direct) direct = true;  // reported below by direct_geometry
+      }
     }
     const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
     p.mfma = want;
@@ -333,8 +400,13 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     p.wp = (int)std::max<int64_t>(p.pad_w + d.in_width,
                                   (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
     if (repack && p.have_weights) pack_for_mfma(p);
+    if (direct) {
+      if (!direct_geometry(p, want, &p.tpi, &p.halo_rows, &p.ps, &p.halo_bytes))
+        return "bconv2d: the direct matrix-core variant cannot hold this tile's input halo in LDS";
+      p.use_direct = true;
+    }
     char nm[96];
-    snprintf(nm, sizeof nm, "bconv2d_mfma<%s,%dx%d>",
+    snprintf(nm, sizeof nm, "bconv2d_mfma%s<%s,%dx%d>", p.use_direct ? "_direct" : "",
              d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", want.bm(), want.bn());
     p.kernel_name = nm;
     return "";

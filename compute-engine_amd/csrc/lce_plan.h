@@ -23,8 +23,13 @@ struct MfmaCfg {
   int bm() const { return 32 * wm * wgm; }
   int bn() const { return 32 * wn * wgn; }
   int threads() const { return 64 * wgm * wgn; }
-  static constexpr int kStages = 4;     // LDS ring depth of bconv2d_mfma
+  static constexpr int kStages = 4;        // LDS ring depth of bconv2d_mfma (A + B per stage)
+  static constexpr int kDirectStages = 3;  // ... of its direct variant (B only; the halo is extra)
   int lds_bytes() const { return kStages * (bm() + bn()) * 32; }
+  int direct_lds_bytes(int halo_bytes) const {
+    const int need = halo_bytes + kDirectStages * bn() * 32, scratch = (threads() / 64) * 4096;
+    return need > scratch ? need : scratch;
+  }
 };
 // The instantiated shapes, by block tile (pixels x channels).
 const MfmaCfg* mfma_cfg_by_tile(int bm, int bn);
@@ -55,7 +60,9 @@ struct HostPlan {
   std::string kernel_name;
 
   // matrix-core engine (lce_kernels_mfma.h)
-  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma
+  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo)
+  bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
+  int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0;  // direct-variant geometry
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   bool use_mfma = false;
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
@@ -90,6 +97,8 @@ int max_batch_per_launch(const HostPlan& p);
 
 // Matrix-core engine: can it run this convolution, and its launch constants.
 bool mfma_supported(const HostPlan& p);
+bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out);
+bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes);
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 

@@ -122,15 +122,22 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
     if (h.use_mfma) {
-      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection);
+      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
+                             h.use_direct);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const MfmaArgs G = make_mfma_args(h, nb);
-      const size_t ws = mfma_workspace_bytes(h, nb);
-      std::vector<lce_dev::u32x4> work(ws / 16 + 16);
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
-      launch_sequential(3, 1, 256, [&] { expand_fp4(in, work.data(), G, (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4)); });
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
+      if (h.use_direct) {
+        launch_block_lockstep(nb * h.tpi, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.direct_lds_bytes(h.halo_bytes), [&] {
+          fn(A, G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
+        });
+        continue;
+      }
+      const size_t ws = mfma_workspace_bytes(h, nb);
+      std::vector<lce_dev::u32x4> work(ws / 16 + 16);
+      launch_sequential(3, 1, 256, [&] { expand_fp4(in, work.data(), G, (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4)); });
       launch_block_lockstep((A.M + bm - 1) / bm, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.lds_bytes(), [&] {
         fn(A, G, (const uint8_t*)work.data(), wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
       });

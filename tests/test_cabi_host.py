@@ -101,7 +101,7 @@ def test_kernel_selection_is_host_side_and_named():
     _, filt, mul, bias = synth.conv_inputs(O.ConvSpec(1, 3, 3, 256, 3, 3, 256), 1)
     plan = amd.Bconv2dPlan(_params(spec, amd.F32))
     plan.set_weights(filt, mul, bias)
-    assert plan.kernel_name().startswith("bconv2d_mfma<f32,")         # auto: matrix-core engine
+    assert plan.kernel_name() == "bconv2d_mfma_direct<f32,256x128>"   # auto: matrix cores, LDS-halo variant
     plan.set_option("engine", "valu")
     assert plan.kernel_name().startswith("bconv2d_tiled<f32,TM=")     # xor-popcount engine
     plan.set_option("kernel", "general")
@@ -114,7 +114,17 @@ def test_kernel_selection_is_host_side_and_named():
     plan.set_option("kernel", "auto")
     plan.set_option("engine", "mfma")
     plan.set_option("tile", "128x128")
-    assert plan.kernel_name() == "bconv2d_mfma<f32,128x128>"
+    assert plan.kernel_name() == "bconv2d_mfma<f32,128x128>"         # workspace GEMM variant
+    plan.set_option("engine", "direct")
+    assert plan.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
+    plan.set_option("tile", "auto")
+    plan.set_option("engine", "auto")
+    # tiles of the direct variant never cross an image: 7x7 images would leave 62 % of a
+    # 128-pixel tile empty, so auto falls back to the workspace GEMM there
+    small = amd.Bconv2dPlan(amd.ConvParams(256, 7, 7, 512, 3, 3, 512, padding=amd.PADDING_SAME, pad_values=1))
+    assert small.kernel_name().startswith("bconv2d_mfma<f32,")
+    mid = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1))
+    assert mid.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     grouped = amd.Bconv2dPlan(amd.ConvParams(1, 8, 8, 128, 3, 3, 64, groups=2))
     grouped.set_option("engine", "mfma")
     assert grouped.kernel_name() == ""                              # refused: grouped convolution

@@ -48,7 +48,7 @@ def _gpu_conv(spec, dst, x, w, mul=None, bias=None, thr=None, scale=1.0, zp=0, k
 
 
 def _check_all_dst(spec, seed, kernel="auto", tile="auto", engine="valu"):
-    x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2 if engine == "mfma" else 0.0)
+    x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2 if engine != "valu" else 0.0)
     zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
     names = []
     if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
@@ -63,7 +63,7 @@ def _check_all_dst(spec, seed, kernel="auto", tile="auto", engine="valu"):
     got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel, tile=tile, engine=engine)
     assert np.array_equal(got, want), n
     names.append(n)
-    if tile in ("auto", "2x32", "1x32") or engine == "mfma":
+    if tile in ("auto", "2x32", "1x32") or engine != "valu":
         thr = O.thresholds_converter(spec, mul, bias)
         thr[::5] = np.iinfo(np.int32).max
         thr[1::7] = np.iinfo(np.int32).min
@@ -179,9 +179,11 @@ def test_conv_reference_grid(case):
         _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF)
 
 
+@pytest.mark.parametrize("engine", ["mfma", "direct"])
 @pytest.mark.parametrize("case", [c for c in GRID if c[2] == 1], ids=_id)
-def test_conv_reference_grid_mfma_engine(case):
-    """Same grid through the FP4 matrix-core engine (groups == 1 only)."""
+def test_conv_reference_grid_mfma_engine(case, engine):
+    """Same grid through the FP4 matrix-core engine (groups == 1 only), both variants: the
+    workspace GEMM and the direct one (input halo expanded into LDS by each block)."""
     inp, flt, g, st, dil, pad, act = case
     for sem in (O.SEM_REFERENCE, O.SEM_OPTIMIZED):
         if not legal(inp, flt, g, pad, sem):
@@ -191,22 +193,30 @@ def test_conv_reference_grid_mfma_engine(case):
                           dil[0], dil[1], padding, pv, act, sem)
         if spec.out_h <= 0 or spec.out_w <= 0:
             continue
-        names = _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF, engine="mfma")
-        assert all(n.startswith("bconv2d_mfma") for n in names)
+        names = _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF, engine=engine)
+        assert all(n.startswith("bconv2d_mfma_direct<" if engine == "direct" else "bconv2d_mfma<") for n in names)
 
 
 @pytest.mark.parametrize("tile", ["256x256", "256x128", "512x64", "128x256", "128x128", "256x64", "128x64"])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 40), (96, 33), (20, 7), (160, 96), (256, 130), (512, 256)])
 @pytest.mark.parametrize("pad", ["VALID", "SAME", "ONE"])
-def test_conv_every_mfma_tile(tile, cin, cout, pad):
+@pytest.mark.parametrize("engine", ["mfma", "direct"])
+def test_conv_every_mfma_tile(tile, cin, cout, pad, engine):
     padding, pv = PADS[pad]
     for sem, st, dil, act in [(O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_NONE),
                               (O.SEM_OPTIMIZED, (2, 1), (1, 2), O.ACT_NONE),
                               (O.SEM_REFERENCE, (1, 2), (2, 1), O.ACT_RELU)]:
         if pad == "SAME" and sem == O.SEM_REFERENCE and cin % 2:
             continue
-        spec = O.ConvSpec(3, 9, 11, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pv, act, sem)
-        names = _check_all_dst(spec, cin * 7 + cout, tile=tile, engine="mfma")
+        # direct: 19x23 = 437 pixels -> several tiles per image, partial last one, mid-row starts
+        hw = (9, 11) if engine == "mfma" else (19, 23)
+        spec = O.ConvSpec(3, hw[0], hw[1], cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pv, act, sem)
+        try:
+            names = _check_all_dst(spec, cin * 7 + cout, tile=tile, engine=engine)
+        except amd.LceHipError as e:
+            # the only legal refusal: a 512-channel halo of a whole image does not fit 160 KiB
+            assert engine == "direct" and cin == 512 and "halo in LDS" in str(e), e
+            continue
         assert all(("," + tile + ">") in n for n in names), names
 
 
@@ -295,7 +305,7 @@ L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_ou
           padding=O.PADDING_SAME, pad_values=1)
 
 
-@pytest.mark.parametrize("engine", ["valu", "mfma"])
+@pytest.mark.parametrize("engine", ["valu", "mfma", "direct"])
 @pytest.mark.parametrize("dst", [amd.F32, amd.I8, amd.BITPACKED])
 def test_l0_batch256_properties(dst, engine):
     """BASELINE config 2: 3x3 256->256 on 56x56, batch 256.
@@ -315,7 +325,7 @@ def test_l0_batch256_properties(dst, engine):
         kw.update(scale=scale, zp=zp)
     kw["engine"] = engine
     got, name = _gpu_conv(spec, dst, x, w, **kw)
-    assert name.startswith("bconv2d_tiled" if engine == "valu" else "bconv2d_mfma")
+    assert name.startswith({"valu": "bconv2d_tiled", "mfma": "bconv2d_mfma<", "direct": "bconv2d_mfma_direct<"}[engine])
     # (a)
     subset = [0, 97, 200, 255]
     sub_spec = O.ConvSpec(batch=len(subset), **L0)
@@ -351,8 +361,9 @@ def test_quicknet_layer_shapes_batch256(hw, c):
     got, name = _gpu_conv(spec, amd.F32, x, w, mul, bias)
     gen, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel="general")
     assert np.array_equal(got.view(np.int32), gen.view(np.int32)), name
-    mf, mname = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine="mfma")
-    assert mname.startswith("bconv2d_mfma") and np.array_equal(mf.view(np.int32), gen.view(np.int32)), mname
+    for engine in ("mfma", "direct"):
+        mf, mname = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine=engine)
+        assert mname.startswith("bconv2d_mfma") and np.array_equal(mf.view(np.int32), gen.view(np.int32)), mname
     subset = [0, 128, 255]
     want = O.bconv2d(O.ConvSpec(batch=3, **kwargs), O.DST_F32, x[subset], w, mul, bias, threads=8)
     assert np.array_equal(got[subset].view(np.int32), want.view(np.int32))

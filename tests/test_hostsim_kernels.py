@@ -180,13 +180,13 @@ def test_bmaxpool(f, s, pad):
 MFMA_TILES = [(256, 256), (256, 128), (512, 64), (128, 256), (128, 128), (256, 64), (128, 64)]
 
 
-def _run_all_dst_mfma(spec, seed, tile=(0, 0), max_batch=0):
+def _run_all_dst_mfma(spec, seed, tile=(0, 0), max_batch=0, engine="mfma"):
     x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2)
     zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
     names = []
     if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
         want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
-        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, tile=tile, max_batch=max_batch, engine="mfma")
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, tile=tile, max_batch=max_batch, engine=engine)
         assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
         names.append(name)
     if zero_pad and spec.semantics == O.SEM_OPTIMIZED:
@@ -194,7 +194,7 @@ def _run_all_dst_mfma(spec, seed, tile=(0, 0), max_batch=0):
     scale, zp = synth.int8_quant_params(seed)
     want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
     got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp,
-                          tile=tile, max_batch=max_batch, engine="mfma")
+                          tile=tile, max_batch=max_batch, engine=engine)
     assert np.array_equal(got, want), name
     names.append(name)
     thr = O.thresholds_converter(spec, mul, bias)
@@ -202,7 +202,7 @@ def _run_all_dst_mfma(spec, seed, tile=(0, 0), max_batch=0):
     thr[1::7] = np.iinfo(np.int32).min
     thr[2::11] = -1
     want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
-    got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, tile=tile, max_batch=max_batch, engine="mfma")
+    got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, tile=tile, max_batch=max_batch, engine=engine)
     assert np.array_equal(got, want), name
     names.append(name)
     return names
@@ -243,6 +243,31 @@ def test_mfma_engine_batch_chunking_and_pointwise():
     _run_all_dst_mfma(spec, 11, max_batch=2)
     spec = O.ConvSpec(3, 6, 7, 128, 3, 3, 48, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU6)
     _run_all_dst_mfma(spec, 12, max_batch=1)
+
+
+@pytest.mark.parametrize("tile", [(128, 64), (128, 128), (256, 64), (128, 256)], ids=lambda t: "%dx%d" % t)
+@pytest.mark.parametrize("cin,cout,pad", [(64, 64, "ONE"), (96, 33, "SAME"), (20, 7, "VALID"), (160, 70, "ONE")])
+def test_mfma_direct_variant(tile, cin, cout, pad):
+    """The direct variant (input halo expanded into LDS by each block, no FP4 workspace):
+    several tiles per image with a partial last one, tiles that start mid-row, strides,
+    dilation, both zero-padding semantics, channel counts that are not multiples of 64."""
+    padding, pad_values = PADS[pad]
+    combos = {"ONE": [(O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_NONE)],
+              "SAME": [(O.SEM_OPTIMIZED, (2, 1), (1, 2), O.ACT_NONE), (O.SEM_REFERENCE, (1, 1), (1, 1), O.ACT_RELU)],
+              "VALID": [(O.SEM_REFERENCE, (1, 2), (2, 1), O.ACT_RELU)]}[pad]
+    for sem, st, dil, act in combos:
+        spec = O.ConvSpec(2, 15, 13, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pad_values, act, sem)
+        names = _run_all_dst_mfma(spec, seed=cin * 5 + cout, tile=tile, engine="direct")
+        assert all("bconv2d_mfma_direct" in n and ",%dx%d>" % tile in n for n in names), names
+
+
+def test_mfma_direct_variant_shapes():
+    # 1x1 filter, 5x5 filter with asymmetric SAME padding (even input, stride 2), batch chunking
+    _run_all_dst_mfma(O.ConvSpec(3, 9, 17, 64, 1, 1, 32), 21, tile=(128, 64), engine="direct", max_batch=2)
+    _run_all_dst_mfma(O.ConvSpec(1, 12, 14, 32, 5, 5, 40, 1, 2, 2, 1, 1, O.PADDING_SAME, 0, O.ACT_NONE, O.SEM_REFERENCE), 22,
+                      tile=(128, 64), engine="direct")
+    _run_all_dst_mfma(O.ConvSpec(1, 12, 14, 32, 5, 5, 40, 1, 2, 2, 1, 1, O.PADDING_SAME, 0, O.ACT_NONE, O.SEM_OPTIMIZED), 23,
+                      tile=(128, 64), engine="direct")
 
 
 def test_mfma_engine_refuses_grouped():

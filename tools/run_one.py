@@ -4,6 +4,7 @@ usage: run_one.py <H=W> <C> <f32|i8|bp> <valu|mfma> <tile|auto> [steps] [batch]"
 import importlib
 import os
 import sys
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +24,9 @@ one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=
                  padding=O.PADDING_SAME, pad_values=1)
 _, w, mul, bias = synth.conv_inputs(one, 3)
 x = torch.from_numpy(synth.random_words(synth.rng(4), (B, hw, hw, (c + 31) // 32), c)).to("cuda:0")
+if os.environ.get("LCE_ZERO"):   # constant operands: how much of the time is the power budget?
+    x.zero_()
+    w = np.zeros_like(w)
 p = amd.ConvParams(B, hw, hw, c, 3, 3, cout, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
                    out_scale=0.125, out_zero_point=3)
 plan = amd.Bconv2dPlan(p)

@@ -19,7 +19,8 @@ B = int(os.environ.get("SWEEP_BATCH", "256"))
 steps = int(os.environ.get("SWEEP_STEPS", "10"))
 layers = [("L0_56x56x256", 56, 256)] + [(f"qn_{hw}x{hw}x{c}", hw, c) for hw, c in bench.QUICKNET]
 dsts = [("f32", amd.F32, O.DST_F32), ("i8", amd.I8, O.DST_I8), ("bp", amd.BITPACKED, O.DST_BITPACKED)]
-tiles = ["4x16", "2x32", "2x16", "1x32", "1x16", "m256x256", "m256x128", "m512x64", "m128x256", "m128x128", "m256x64", "m128x64"]
+tiles = ["4x16", "2x32", "2x16", "1x32", "1x16", "m256x256", "m256x128", "m512x64", "m128x256", "m128x128", "m256x64", "m128x64",
+         "d256x256", "d256x128", "d512x64", "d128x256", "d128x128", "d256x64", "d128x64"]
 only = set(sys.argv[1:])
 for lname, hw, c in layers:
     spec = O.ConvSpec(batch=B, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=c,
@@ -28,7 +29,8 @@ for lname, hw, c in layers:
         if only and dname not in only and lname not in only:
             continue
         for tile in tiles:
-            mfma = tile.startswith("m")
+            direct = tile.startswith("d")
+            mfma = tile.startswith("m") or direct
             if not mfma and dst == amd.BITPACKED and not tile.endswith("32"):
                 continue
             os.environ["LCE_SWEEP_TILE"] = tile
@@ -41,10 +43,12 @@ for lname, hw, c in layers:
                                out_scale=0.125, out_zero_point=3)
             plan = amd.Bconv2dPlan(p)
             plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
-            plan.set_option("engine", "mfma" if mfma else "valu")
+            plan.set_option("engine", "direct" if direct else "mfma" if mfma else "valu")
             if not mfma:
                 plan.set_option("kernel", "tiled")
-            plan.set_option("tile", tile.lstrip("m"))
+            plan.set_option("tile", tile.lstrip("md"))
+            if not plan.kernel_name():
+                continue
             out = plan.run(x)
             for _ in range(2):
                 plan.run(x, out)
