@@ -182,5 +182,22 @@ LCE_DEVICE void interleave_mfma_ldsread() {
 // by this kernel: keeps the L2 for the operands that ARE re-read.
 LCE_DEVICE void store_streaming(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }
 LCE_DEVICE float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi (4-7), lo (0-3)}; 0x0c = 0x00
+LCE_DEVICE uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// v_pk_lshrrev_b16: the two 16-bit halves shifted right by their own amounts
+template <int SLO, int SHI>
+LCE_DEVICE uint32_t pk_lshr_b16(uint32_t v) {
+  typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+  u16x2_t x = __builtin_bit_cast(u16x2_t, v);
+  const u16x2_t sh = {(unsigned short)SLO, (unsigned short)SHI};
+  x = x >> sh;
+  return __builtin_bit_cast(uint32_t, x);
+}
+// low bytes of four ints -> one dword (v_perm_b32: selector byte 0-3 = src1 bytes, 4-7 = src0, 0x0c = 0)
+LCE_DEVICE uint32_t pack4_u8(int q0, int q1, int q2, int q3) {
+  const uint32_t lo = __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
+  const uint32_t hi = __builtin_amdgcn_perm((uint32_t)q3, (uint32_t)q2, 0x0c0c0400u);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
 
 }  // namespace lce_dev

@@ -42,11 +42,21 @@ LCE_DEVICE float ot_float(int acc, int cmin, int cmax, float mul, float bias) {
   return mul_then_add((float)x, mul, bias);
 }
 
+// saturate<int8>(std::round(y)) (output_transform.h:31-44) in four instructions.  Rounding is
+// monotone and the bounds are integers, so clamping first is equivalent; for |y| <= 128,
+// trunc(y + copysign(pred(0.5), y)) IS round-half-away: with 0.5 itself the sum for
+// y = pred(0.5) would round up to 1.0, with pred(0.5) = 0x1.fffffep-2 every exact tie
+// n + 0.5 lands within half an ulp below n + 1 and rounds up to it, and everything below a
+// tie stays below.  Checked against roundf for EVERY float by
+// tests/test_hostsim_kernels.py::test_round_sat_i8_every_float.
+LCE_DEVICE int round_sat_i8(float y) {
+  const float c = med3(y, -128.0f, 127.0f);
+  return (int)(c + __builtin_copysignf(0x1.fffffep-2f, c));   // float -> int conversion truncates
+}
+
 // :17-27,31-44,133-143 -- std::round (half away from zero), saturate to int8.
 LCE_DEVICE int ot_int8(int acc, int cmin, int cmax, float mul, float bias) {
-  float r = round_half_away(ot_float(acc, cmin, cmax, mul, bias));
-  r = fminf(fmaxf(r, -128.0f), 127.0f);
-  return (int)r;
+  return round_sat_i8(ot_float(acc, cmin, cmax, mul, bias));
 }
 
 // zero_padding_correction.h:196-275: which cached correction row (if any) applies to
@@ -253,10 +263,7 @@ bconv2d_tiled(const ConvArgs A, const uint32_t* __restrict__ in,
         if (full_tile && (A.N & 3) == 0) {
 #pragma unroll
           for (int j = 0; j < TN; j += 4) {
-            const uint32_t pk = (uint32_t)(q[j] & 0xff) | ((uint32_t)(q[j + 1] & 0xff) << 8) |
-                                ((uint32_t)(q[j + 2] & 0xff) << 16) |
-                                ((uint32_t)(q[j + 3] & 0xff) << 24);
-            *(uint32_t*)(o + j) = pk;
+            *(uint32_t*)(o + j) = pack4_u8(q[j], q[j + 1], q[j + 2], q[j + 3]);
           }
         } else {
 #pragma unroll

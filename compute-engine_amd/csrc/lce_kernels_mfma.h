@@ -56,6 +56,22 @@ LCE_DEVICE u32x4 fp4_of_word(uint32_t word, int valid) {
   return v;
 }
 
+// All 32 channels present: 17 VALU instructions per word instead of ~40.  Byte q of the word
+// becomes one dword of 8 nibbles: its four bit PAIRS are moved to the low 2 bits of the four
+// bytes of a selector (perm + packed 16-bit shifts), and v_perm_b32 then looks each pair up
+// in the 4-entry table {++, -+, +-, --} = {0x22, 0x2A, 0xA2, 0xAA}.
+LCE_DEVICE u32x4 fp4_of_full_word(uint32_t word) {
+  const uint32_t w2 = word >> 2;
+  u32x4 v;
+  auto one = [&](uint32_t sel) LCE_LAMBDA_INLINE {
+    // bytes: [b, b >> 2, b, b >> 2] -> halves shifted by (0, 4) -> pairs 0..3 in the low bits
+    const uint32_t u = pk_lshr_b16<0, 4>(perm_b32(w2, word, sel)) & 0x03030303u;
+    return perm_b32(0u, 0xAAA22A22u, u);
+  };
+  v[0] = one(0x04000400u); v[1] = one(0x05010501u); v[2] = one(0x06020602u); v[3] = one(0x07030703u);
+  return v;
+}
+
 // One thread per (workspace pixel, group of 4 input words): a 16-byte read of the pixel's
 // words (when the row allows it) feeds four 16-byte writes into four consecutive word
 // planes; consecutive threads are consecutive pixels, so every plane write is coalesced.
@@ -93,7 +109,7 @@ expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaA
       int valid = G.Cin - cc * 32;                             // channels of this word that exist
       valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
       if (!inside && G.zero_border) valid = 0;
-      out[(size_t)cc * G.NPIX + pix] = fp4_of_word(w[k], valid);
+      out[(size_t)cc * G.NPIX + pix] = valid == 32 ? fp4_of_full_word(w[k]) : fp4_of_word(w[k], valid);
     }
   }
 }
@@ -298,7 +314,8 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
             int valid = G.Cin - cc * 32;                         // channels of this word that exist
             valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
             if (!inv[k] && G.zero_border) valid = 0;             // exact SAME-zero: 0 contributes 0
-            *(u32x4*)(lds0 + (size_t)pixv[k] * G.PS + cc * 16) = fp4_of_word(wv[k][q], valid);
+            *(u32x4*)(lds0 + (size_t)pixv[k] * G.PS + cc * 16) =
+                valid == 32 ? fp4_of_full_word(wv[k][q]) : fp4_of_word(wv[k][q], valid);
           }
         }
       }
@@ -486,13 +503,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
                   if (n + c < A.N) o[c] = y[c];
               }
             } else {
-              uint32_t pk = 0;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                float q = round_half_away(y[c]);
-                q = fminf(fmaxf(q, -128.0f), 127.0f);
-                pk |= ((uint32_t)(int)q & 0xffu) << (8 * c);
-              }
+              const uint32_t pk = pack4_u8(round_sat_i8(y[0]), round_sat_i8(y[1]), round_sat_i8(y[2]), round_sat_i8(y[3]));
               int8_t* o = (int8_t*)out + (size_t)m * (size_t)A.N + (size_t)n;
               if (vec_ok && n + 4 <= A.N) {
                 *(uint32_t*)o = pk;

@@ -159,6 +159,28 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   return 0;
 }
 
+// Exhaustive check of lce::round_sat_i8 against saturate(roundf(y)) over every finite float
+// (and the infinities).  Returns the number of mismatches; *first_bad = bits of the first one.
+uint64_t hostsim_check_round_sat_i8(uint32_t* first_bad) {
+  uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+  for (int64_t hi = 0; hi < 65536; ++hi) {
+    for (uint32_t lo = 0; lo < 65536; ++lo) {
+      const uint32_t bits = ((uint32_t)hi << 16) | lo;
+      float y;
+      memcpy(&y, &bits, 4);
+      if (y != y) continue;   // NaN: the reference's behaviour is unspecified
+      float r = roundf(y);
+      r = r < -128.0f ? -128.0f : (r > 127.0f ? 127.0f : r);
+      if (round_sat_i8(y) != (int)r) {
+        if (bad == 0 && first_bad) *first_bad = bits;
+        ++bad;
+      }
+    }
+  }
+  return bad;
+}
+
 // in_type: LCE_HIP_F32 / I8 / BOOL.  force_rows != 0 -> always the ballot kernel.
 int hostsim_bitpack(int in_type, const void* in, uint64_t rows, uint64_t cols, int32_t zero_point,
                     uint32_t* out, int force_rows) {

@@ -148,5 +148,20 @@ inline void pin(f32x16&) {}
 template <int N> inline void interleave_mfma_ldsread() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
 inline float med3(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+inline uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+  const uint64_t pool = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t s = (sel >> (8 * i)) & 0xff;
+    const uint32_t b = s < 8 ? (uint32_t)(pool >> (8 * s)) & 0xff : 0u;   // only 0-7 and 0x0c (zero) are used
+    r |= b << (8 * i);
+  }
+  return r;
+}
+template <int SLO, int SHI>
+inline uint32_t pk_lshr_b16(uint32_t v) { return ((v & 0xffffu) >> SLO) | (((v >> 16) >> SHI) << 16); }
+inline uint32_t pack4_u8(int q0, int q1, int q2, int q3) {
+  return (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
+}
 
 }  // namespace lce_dev

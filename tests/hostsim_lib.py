@@ -42,6 +42,15 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def check_round_sat_i8():
+    """(number of floats where the kernels' 4-instruction int8 rounding differs from
+    saturate(roundf(y)), bits of the first such float) over ALL 2^32 bit patterns but NaNs."""
+    l = lib()
+    l.hostsim_check_round_sat_i8.restype = C.c_uint64
+    first = C.c_uint32(0)
+    return int(l.hostsim_check_round_sat_i8(C.byref(first))), first.value
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

@@ -175,6 +175,13 @@ def test_bmaxpool(f, s, pad):
     assert np.array_equal(H.bmaxpool(x, f[0], f[1], s[0], s[1], pad), O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
 
 
+def test_round_sat_i8_every_float():
+    """The int8 epilogue's rounding (clamp, add copysign(pred(0.5)), truncate) equals the
+    reference's saturate(std::round(y)) (output_transform.h:31-44) for every float."""
+    bad, first = H.check_round_sat_i8()
+    assert bad == 0, "first mismatch at float bits 0x%08x" % first
+
+
 # ------------------------------------------------------------------------------------ matrix-core engine
 
 MFMA_TILES = [(256, 256), (256, 128), (512, 64), (128, 256), (128, 128), (256, 64), (128, 64)]
