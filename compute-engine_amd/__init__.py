@@ -17,7 +17,8 @@ import os
 from dataclasses import dataclass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblce_hip.so")
+# LCE_HIP_LIBRARY: an alternative build of the same library (kernel A/B experiments, tools/)
+LIB_PATH = os.environ.get("LCE_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "liblce_hip.so")
 
 # enums of include/lce_hip.h
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_RUNTIME, ERR_NO_DEVICE = range(5)
