@@ -161,17 +161,19 @@ def main():
             dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize(dev)
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    ev0.record()                       # same stream the plan launches on (torch's current stream)
-    for _ in range(args.steps):
+    evs[0].record()                    # same stream the plan launches on (torch's current stream)
+    for i in range(args.steps):
         plan.run(x, out)
-    ev1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    region_event_sec = ev0.elapsed_time(ev1) / 1e3 / args.steps
+    region_event_sec = evs[0].elapsed_time(evs[-1]) / 1e3 / args.steps
+    per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    pct = lambda q: per_step_ms[min(len(per_step_ms) - 1, int(q * len(per_step_ms)))]
     elapsed = shard.max_over_ranks(elapsed, dist, dev)
 
     total_bmacs = spec.binary_macs * args.steps * world
@@ -193,6 +195,8 @@ def main():
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "parallelism": f"batch-shard x{world} (no data-path collective)"},
         "layer_latency_ms": step_sec * 1e3,
+        # spread of the K timed steps (the chip's power management moves the clock during a run)
+        "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
         "per_gpu_value": value / world,
         "kernel": kname + ("+expand_fp4" if mfma and not direct else ""),
     }
@@ -258,6 +262,18 @@ def main():
                     "GBps_algorithmic": algorithmic_bytes(sp, O.DST_F32) / s_ / 1e9,
                     "hbm_frac": algorithmic_bytes(sp, O.DST_F32) / s_ / 1e9 / HBM_PEAK_GBS}
             extra["quicknet_16_layers_ms"] = tot * 1e3
+            # BASELINE config 4: QuickNetLarge = blocks (6, 8, 12, 6) of the same four layer shapes
+            extra["quicknet_large_32_layers_ms"] = sum(
+                n * extra[f"quicknet_{hw}x{hw}x{c}_f32"]["ms"] for n, (hw, c) in zip((6, 8, 12, 6), QUICKNET))
+            # BASELINE config 5 flavour: 1x1 int8-output layers with a RELU clamp (the HBM-bound cases)
+            for hw, c in QUICKNET:
+                sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
+                                channels_out=c, activation=O.ACT_RELU)
+                s_, kn, *_ = time_layer(amd, torch, sp, amd.I8, st, wu, hw + 1, dev, sc, zp)
+                ab = algorithmic_bytes(sp, O.DST_I8)
+                extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {
+                    "ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
+                    "GBps_algorithmic": ab / s_ / 1e9, "hbm_frac": ab / s_ / 1e9 / HBM_PEAK_GBS}
             # LceQuantize stream: float32 56x56x256 feature map, batch 256
             fx = torch.randn((args.batch, 56, 56, 256), device=dev)
             ow = amd.bitpack(fx)

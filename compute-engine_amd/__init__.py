@@ -16,6 +16,8 @@ import ctypes as C
 import os
 from dataclasses import dataclass
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LCE_HIP_LIBRARY: an alternative build of the same library (kernel A/B experiments, tools/)
 LIB_PATH = os.environ.get("LCE_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "liblce_hip.so")
@@ -37,7 +39,10 @@ ABI_SYMBOLS = (
     "lce_hip_bconv2d_plan_padding", "lce_hip_bconv2d_plan_set_weights", "lce_hip_bconv2d_plan_folded",
     "lce_hip_bconv2d_plan_set_option", "lce_hip_bconv2d_plan_kernel_name", "lce_hip_bconv2d_run",
     "lce_hip_bconv2d_run_host", "lce_hip_bmaxpool_output_shape", "lce_hip_bmaxpool",
+    "lce_hip_prepare_binary_filter", "lce_hip_prepare_fuse_post_op", "lce_hip_prepare_can_fuse_activation",
+    "lce_hip_prepare_bitpacked_output", "lce_hip_prepare_bitpack_filter",
 )
+POST_ADD, POST_SUB, POST_MUL, POST_DIV = 0, 1, 2, 3
 
 
 class LceHipError(RuntimeError):
@@ -260,3 +265,55 @@ def bmaxpool(x, filter_height, filter_width, stride_height, stride_width, paddin
                                  stride_height, stride_width, padding, C.c_void_p(out.data_ptr()),
                                  C.c_void_p(stream)))
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# converter-side parameter preparation (host-only; include/lce_hip.h "lce_hip_prepare_*")
+# ---------------------------------------------------------------------------------------
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def prepare_binary_filter(filter_hwio):
+    """float HWIO +-scale filter -> (OHWI +-1 filter, post_activation_multiplier, post_activation_bias)."""
+    f = _f32(filter_hwio)
+    kh, kw, cin, cout = f.shape
+    ohwi = np.empty((cout, kh, kw, cin), np.float32)
+    mul, bias = np.empty(cout, np.float32), np.empty(cout, np.float32)
+    check(lib().lce_hip_prepare_binary_filter(_host_ptr(f), kh, kw, cin, cout, _host_ptr(ohwi),
+                                              _host_ptr(mul), _host_ptr(bias)))
+    return ohwi, mul, bias
+
+
+def prepare_fuse_post_op(op: int, value, mul, bias):
+    """Fuses ``conv <op> value`` into (mul, bias); returns new arrays."""
+    v = _f32(np.atleast_1d(value))
+    m, b = _f32(mul).copy(), _f32(bias).copy()
+    check(lib().lce_hip_prepare_fuse_post_op(op, _host_ptr(v), v.size, _host_ptr(m), _host_ptr(b), m.size))
+    return m, b
+
+
+def prepare_can_fuse_activation(mul, bias, padding: int, pad_values: int) -> bool:
+    m, b = _f32(mul), _f32(bias)
+    return bool(lib().lce_hip_prepare_can_fuse_activation(_host_ptr(m), _host_ptr(b), m.size, padding, pad_values))
+
+
+def prepare_bitpacked_output(filter_ohwi, mul, bias, activation: int = ACT_NONE,
+                             padding: int = PADDING_VALID, pad_values: int = 0):
+    """-> (sign-flipped OHWI filter, int32 thresholds) of the bit-writing convolution."""
+    f = _f32(filter_ohwi).copy()
+    cout, kh, kw, cin = f.shape
+    m, b = _f32(mul), _f32(bias)
+    thr = np.empty(cout, np.int32)
+    check(lib().lce_hip_prepare_bitpacked_output(_host_ptr(f), kh, kw, cin, cout, activation, padding, pad_values,
+                                                 _host_ptr(m), _host_ptr(b), _host_ptr(thr)))
+    return f, thr
+
+
+def prepare_bitpack_filter(filter_ohwi):
+    """float OHWI filter -> int32 [O, H, W, ceil(I/32)] (input 1 of LceBconv2d)."""
+    f = _f32(filter_ohwi)
+    cout, kh, kw, cin = f.shape
+    words = np.empty((cout, kh, kw, (cin + 31) // 32), np.int32)
+    check(lib().lce_hip_prepare_bitpack_filter(_host_ptr(f), kh, kw, cin, cout, _host_ptr(words)))
+    return words

@@ -12,6 +12,7 @@
 #include "lce_kernels.h"
 #include "lce_dispatch.h"
 #include "lce_plan.h"
+#include "lce_prepare.h"
 
 namespace {
 
@@ -557,6 +558,42 @@ lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t
                                                               words, oh, ow, fh, fw, sh, sw, ph, pw, total);
   LCE_HIP_TRY(hipGetLastError());
   return LCE_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// converter-side parameter preparation (host-only, lce_prepare.cpp)
+// ------------------------------------------------------------------------------------
+static lce_hip_status prep_status(const std::string& err) {
+  return err.empty() ? LCE_HIP_OK : fail(LCE_HIP_ERR_INVALID, "%s", err.c_str());
+}
+
+lce_hip_status lce_hip_prepare_binary_filter(const float* filter_hwio, int32_t kh, int32_t kw, int32_t cin,
+                                             int32_t cout, float* filter_ohwi, float* mul, float* bias) {
+  return prep_status(lce::prepare_binary_filter(filter_hwio, kh, kw, cin, cout, filter_ohwi, mul, bias));
+}
+
+lce_hip_status lce_hip_prepare_fuse_post_op(lce_hip_post_op op, const float* value, int32_t value_count,
+                                            float* mul, float* bias, int32_t channels_out) {
+  return prep_status(lce::fuse_post_op((int)op, value, value_count, mul, bias, channels_out));
+}
+
+int lce_hip_prepare_can_fuse_activation(const float* mul, const float* bias, int32_t channels_out,
+                                        int32_t padding, int32_t pad_values) {
+  if (!mul || !bias || channels_out <= 0) return 0;
+  return lce::can_fuse_activation(mul, bias, channels_out, padding == LCE_HIP_PADDING_SAME, pad_values) ? 1 : 0;
+}
+
+lce_hip_status lce_hip_prepare_bitpacked_output(float* filter_ohwi, int32_t kh, int32_t kw, int32_t cin,
+                                                int32_t cout, int32_t activation, int32_t padding,
+                                                int32_t pad_values, const float* mul, const float* bias,
+                                                int32_t* thresholds) {
+  return prep_status(lce::prepare_bitpacked_output(filter_ohwi, kh, kw, cin, cout, activation,
+                                                   padding == LCE_HIP_PADDING_SAME, pad_values, mul, bias, thresholds));
+}
+
+lce_hip_status lce_hip_prepare_bitpack_filter(const float* filter_ohwi, int32_t kh, int32_t kw, int32_t cin,
+                                              int32_t cout, int32_t* filter_words) {
+  return prep_status(lce::bitpack_filter(filter_ohwi, kh, kw, cin, cout, filter_words));
 }
 
 }  // extern "C"

@@ -194,6 +194,54 @@ lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t
                                 int32_t filter_width, int32_t stride_height, int32_t stride_width,
                                 int32_t padding, int32_t* output_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Converter-side parameter preparation (host-only).
+ * What the reference's MLIR converter does offline to the constants of one binary
+ * convolution, so that an unconverted Larq layer (float +-scale HWIO filter, fused
+ * mul/add constants) arrives at exactly the tensors LceBconv2d expects.  WEIGHTS only --
+ * nothing here processes activations.  Paths relative to larq_compute_engine/mlir/.
+ * ---------------------------------------------------------------------------------- */
+
+/* transforms/prepare_patterns_common.td:97-168 + prepare_tf.cc:40-92: checks the filter is
+ * binary (+-scale[o] within 0.5 %), writes filter/|scale| transposed HWIO -> OHWI,
+ * post_activation_multiplier = |scale|, post_activation_bias = 0 (either may be NULL). */
+lce_hip_status lce_hip_prepare_binary_filter(const float* filter_hwio, int32_t filter_height,
+                                             int32_t filter_width, int32_t channels_in_per_group,
+                                             int32_t channels_out, float* filter_ohwi,
+                                             float* post_activation_multiplier,
+                                             float* post_activation_bias);
+
+typedef enum lce_hip_post_op {
+  LCE_HIP_POST_ADD = 0, LCE_HIP_POST_SUB = 1, LCE_HIP_POST_MUL = 2, LCE_HIP_POST_DIV = 3
+} lce_hip_post_op;
+/* transforms/optimize_patterns_common.td:39-118: fuse `conv <op> constant` (constant scalar
+ * or per-channel) into post_activation_{multiplier,bias}, float arithmetic. */
+lce_hip_status lce_hip_prepare_fuse_post_op(lce_hip_post_op op, const float* value,
+                                            int32_t value_count, float* post_activation_multiplier,
+                                            float* post_activation_bias, int32_t channels_out);
+/* transforms/optimize_patterns_common.td:122-182: 1 iff a following Relu/Relu1/Relu6 may
+ * become the fused activation (multiplier all 1, bias all 0, VALID or SAME/pad_values 1). */
+int lce_hip_prepare_can_fuse_activation(const float* post_activation_multiplier,
+                                        const float* post_activation_bias, int32_t channels_out,
+                                        int32_t padding, int32_t pad_values);
+
+/* transforms/bitpack_activations_patterns.td:19-60 + optimize.cc:128-244: the rewrite of
+ * LceQuantize(LceBconv2d(x)) into a bit-writing convolution: multiplies filter_ohwi IN PLACE
+ * by sign(multiplier) and computes the int32 thresholds (bit = accumulator > threshold). */
+lce_hip_status lce_hip_prepare_bitpacked_output(float* filter_ohwi, int32_t filter_height,
+                                                int32_t filter_width, int32_t channels_in_per_group,
+                                                int32_t channels_out, int32_t activation,
+                                                int32_t padding, int32_t pad_values,
+                                                const float* post_activation_multiplier,
+                                                const float* post_activation_bias,
+                                                int32_t* thresholds);
+
+/* transforms/bitpack.cc:19-57: float OHWI filter -> int32 [O][H][W][ceil(I/32)]
+ * (bit = x < 0, LSB first, rows padded with 0 bits) = input 1 of LceBconv2d. */
+lce_hip_status lce_hip_prepare_bitpack_filter(const float* filter_ohwi, int32_t filter_height,
+                                              int32_t filter_width, int32_t channels_in_per_group,
+                                              int32_t channels_out, int32_t* filter_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,3 +399,48 @@ def test_bmaxpool(f, s, pad):
     x = synth.random_words(synth.rng(99), (4, 19, 17, 3))
     got = amd.bmaxpool(torch.from_numpy(x).to(DEV), f[0], f[1], s[0], s[1], pad).cpu().numpy()
     assert np.array_equal(got, O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
+
+
+# ------------------------------------------------------------------------------------ converter-side preparation (n2)
+
+@pytest.mark.parametrize("act", [O.ACT_NONE, O.ACT_RELU])
+def test_unconverted_float_layer_through_prepare(act):
+    """An unconverted Larq layer -- float +-scale HWIO filter, a fused per-channel Mul (some
+    negative) and Add -- prepared by lce_hip_prepare_* and run two ways: float output, and
+    the converter's bit-writing rewrite (flipped filter + thresholds).  The bits must be the
+    signs of the float outputs (away from zero, where float rounding of y could differ from
+    the integer threshold), and the float output must equal a float convolution."""
+    g = synth.rng(90 + act)
+    B, H, W, cin, cout, kh, kw = 4, 14, 14, 96, 72, 3, 3
+    sign = g.choice([-1.0, 1.0], (kh, kw, cin, cout)).astype(np.float32)
+    scale = g.uniform(0.05, 0.5, cout).astype(np.float32)
+    ohwi, mul, bias = amd.prepare_binary_filter(sign * scale)
+    bn_mul = g.uniform(-1.5, 1.5, cout).astype(np.float32)
+    bn_add = g.uniform(-3.0, 3.0, cout).astype(np.float32)
+    if act == O.ACT_NONE:
+        mul, bias = amd.prepare_fuse_post_op(amd.POST_MUL, bn_mul, mul, bias)
+        mul, bias = amd.prepare_fuse_post_op(amd.POST_ADD, bn_add, mul, bias)
+    else:
+        # a ReLU can only be fused while nothing else is (optimize_patterns_common.td:122-182)
+        ohwi, mul, bias = ohwi, np.ones(cout, np.float32), np.zeros(cout, np.float32)
+        assert amd.prepare_can_fuse_activation(mul, bias, amd.PADDING_VALID, 0)
+        mul, bias = amd.prepare_fuse_post_op(amd.POST_MUL, bn_mul, mul, bias)
+        mul, bias = amd.prepare_fuse_post_op(amd.POST_SUB, bn_add, mul, bias)
+    xs = g.choice([-1.0, 1.0], (B, H, W, cin)).astype(np.float32)
+    x = O.bitpack(xs.reshape(-1, cin)).reshape(B, H, W, -1)
+    spec = O.ConvSpec(B, H, W, cin, kh, kw, cout, activation=act)
+    y, _ = _gpu_conv(spec, amd.F32, x, amd.prepare_bitpack_filter(ohwi), mul, bias, engine="auto")
+    # float convolution of the +-1 tensors, clamp, then mul/bias
+    import torch
+    ref = torch.nn.functional.conv2d(torch.from_numpy(xs).permute(0, 3, 1, 2).double(),
+                                     torch.from_numpy(ohwi).permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1).numpy()
+    if act == O.ACT_RELU:
+        ref = np.maximum(ref, 0.0)
+    ref = ref * mul.astype(np.float64) + bias.astype(np.float64)
+    assert np.allclose(y, ref, rtol=1e-5, atol=1e-4)
+    flipped, thr = amd.prepare_bitpacked_output(ohwi, mul, bias, act)
+    bits, _ = _gpu_conv(spec, amd.BITPACKED, x, amd.prepare_bitpack_filter(flipped), thr=thr, engine="auto")
+    got = O.unpack(bits.reshape(-1, bits.shape[-1]), cout, np.float32).reshape(y.shape) < 0     # bit 1 <=> -1
+    decided = np.abs(ref) > 1e-3
+    assert decided.mean() > 0.95
+    assert np.array_equal(got[decided], (ref < 0)[decided])
