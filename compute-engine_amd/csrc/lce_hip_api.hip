@@ -452,7 +452,7 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
           LCE_HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
           plan->lds_opt_in = (void*)fn;
         }
-        const dim3 grid((unsigned)((int64_t)nb * h.tpi), (unsigned)(h.npad / bn));
+        const dim3 grid((unsigned)(h.ipt > 1 ? (nb + h.ipt - 1) / h.ipt : (int64_t)nb * h.tpi), (unsigned)(h.npad / bn));
         hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), lds, st, A, G, (const uint8_t*)in, plan->d_wq.ptr,
                            plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_zpc.ptr, out);
         LCE_HIP_TRY(hipGetLastError());

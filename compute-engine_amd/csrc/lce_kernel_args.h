@@ -77,7 +77,10 @@ struct MfmaArgs {
   int32_t PS;              // LDS bytes per halo pixel = CPW*16 + 16 (the +16 staggers banks)
   int32_t halo_bytes;      // halo_rows * Wp * PS, rounded up to 1 KiB; the weight ring follows
   int32_t QG;              // 16-byte groups of input words per pixel = ceil(CPW / 4)
-  FastDiv div_tpi, div_qg;
+  int32_t IPT;             // whole images per tile (> 1 only when OH*OW <= BM / 2; then TPI == 1)
+  int32_t B;               // images of this launch
+  int32_t HPIX;            // halo pixels per image = halo_rows * Wp
+  FastDiv div_tpi, div_qg, div_ohow, div_hpix;
 };
 
 }  // namespace lce

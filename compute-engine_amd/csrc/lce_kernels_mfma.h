@@ -161,10 +161,16 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // BM consecutive pixels of ONE image (the last tile of an image is partial).
   int m0 = bx * BM, m_end = A.M, p0 = 0, img = 0;
   if constexpr (DIRECT) {
-    img = (int)fastdiv((uint32_t)bx, G.div_tpi);
-    p0 = (bx - img * G.TPI) * BM;
-    m0 = img * G.OHOW + p0;
-    m_end = (img + 1) * G.OHOW;
+    if (G.IPT > 1) {                       // small images: IPT whole images per tile
+      img = bx * G.IPT;
+      m0 = img * G.OHOW;
+      m_end = (img + G.IPT < G.B ? img + G.IPT : G.B) * G.OHOW;
+    } else {
+      img = (int)fastdiv((uint32_t)bx, G.div_tpi);
+      p0 = (bx - img * G.TPI) * BM;
+      m0 = img * G.OHOW + p0;
+      m_end = (img + 1) * G.OHOW;
+    }
   }
   const int n0 = block_idx_y() * BN;
 
@@ -269,8 +275,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   if constexpr (DIRECT) {
     const int oy0 = (int)fastdiv((uint32_t)p0, A.div_ow);
     const int iy_first = oy0 * A.SH - G.PH;
-    const uint32_t* src_img = (const uint32_t*)xp + (size_t)img * G.H * G.W * (size_t)G.Cw;
-    const int items = G.halo_rows * G.Wp * G.QG;
+    const size_t img_words = (size_t)G.H * G.W * (size_t)G.Cw;
+    const uint32_t* src_img0 = (const uint32_t*)xp + (size_t)img * img_words;
+    const int items = G.IPT * G.HPIX * G.QG;
     const bool vec = (G.Cw & 3) == 0;
     // Loads first, arithmetic second: a thread's (up to) PRE 16-byte loads are all in flight
     // before the first one is consumed, so the block pays one memory latency for its halo
@@ -286,14 +293,16 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         wv[k] = u32x4{0u, 0u, 0u, 0u};                           // outside: bit 0 = +1 (pad_values 1)
         pixv[k] = -1; c0v[k] = 0; inv[k] = false;
         if (e < items) {
-          const int pix = (int)fastdiv((uint32_t)e, G.div_qg);   // slot * Wp + x
+          const int pix = (int)fastdiv((uint32_t)e, G.div_qg);   // (image * halo_rows + slot) * Wp + x
           const int c0 = (e - pix * G.QG) * 4;
-          const int slot = (int)fastdiv((uint32_t)pix, G.div_wp);
-          const int iy = iy_first + slot, ix = pix - slot * G.Wp - G.PW;
-          const bool inside = (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W;
+          const int li = (int)fastdiv((uint32_t)pix, G.div_hpix);  // image of the tile (0 unless IPT > 1)
+          const int ipix = pix - li * G.HPIX;
+          const int slot = (int)fastdiv((uint32_t)ipix, G.div_wp);
+          const int iy = iy_first + slot, ix = ipix - slot * G.Wp - G.PW;
+          const bool inside = (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W && img + li < G.B;
           pixv[k] = pix; c0v[k] = c0; inv[k] = inside;
           if (inside) {
-            const uint32_t* src = src_img + ((size_t)iy * G.W + ix) * (size_t)G.Cw + c0;
+            const uint32_t* src = src_img0 + (size_t)li * img_words + ((size_t)iy * G.W + ix) * (size_t)G.Cw + c0;
             if (vec && c0 + 4 <= G.Cw) {
               wv[k] = *(const u32x4*)src;
             } else {
@@ -322,11 +331,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      int p = p0 + (wm * WM + i) * 32 + l31;
-      p = p < G.OHOW ? p : G.OHOW - 1;   // rows past the image re-read its last pixel; never stored
+      int p = p0 + (wm * WM + i) * 32 + l31;   // pixel of the tile's first image, or beyond it
+      const int lim = G.IPT * G.OHOW;
+      p = p < lim ? p : lim - 1;               // rows past the tile re-read its last pixel; never stored
+      const int li = (int)fastdiv((uint32_t)p, G.div_ohow);
+      p -= li * G.OHOW;
       const int oy = (int)fastdiv((uint32_t)p, A.div_ow);
       const int ox = p - oy * A.OW;
-      a_base[i] = (uint32_t)(((oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
+      a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
     }
   }
   const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * 32u;

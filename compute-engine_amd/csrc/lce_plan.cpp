@@ -282,24 +282,38 @@ static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
   return c ? *c : kMfmaCfgs[4];
 }
 
-// Direct variant: does the input halo of a BM-pixel tile (plus the weight ring) fit LDS?
-bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes) {
+// Direct variant: geometry of a BM-pixel tile and whether its input halo (plus the weight ring)
+// fits LDS.  Images of at most BM/2 pixels are tiled IPT whole images at a time, larger ones
+// in BM-pixel pieces of ONE image.
+bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
+                     int* ipt, int lds_budget) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!mfma_supported(p)) return false;
   const int cpad = ceil_div(d.channels_in, 64) * 64;
   const int64_t wp = std::max<int64_t>(p.pad_w + d.in_width,
                                        (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
-  const int bm = c.bm();
-  // a tile of bm consecutive pixels of one image touches at most this many output rows
-  const int rows_out = std::min(p.out_h, (bm + p.out_w - 2) / p.out_w + 1);
-  const int64_t rows = (int64_t)(rows_out - 1) * d.stride_height + (int64_t)(d.filter_height - 1) * d.dilation_height + 1;
+  const int bm = c.bm(), ohow = p.out_h * p.out_w;
+  const int64_t ring = (int64_t)MfmaCfg::kDirectStages * c.bn() * 32;
   const int64_t stride = (cpad / 32) * 16 + 16;
-  const int64_t bytes = (rows * wp * stride + 1023) / 1024 * 1024;
-  if (bytes + (int64_t)MfmaCfg::kDirectStages * c.bn() * 32 > 160 * 1024) return false;
-  *tpi = ceil_div(p.out_h * p.out_w, bm);
+  int images = 1;
+  int64_t rows;
+  if (ohow * 2 <= bm) {
+    // whole images: as many as fill the tile, fewer if LDS says so
+    rows = (int64_t)(p.out_h - 1) * d.stride_height + (int64_t)(d.filter_height - 1) * d.dilation_height + 1;
+    images = (int)std::min<int64_t>(bm / ohow, (lds_budget - ring) / std::max<int64_t>(1, rows * wp * stride));
+    if (images < 1) return false;
+  } else {
+    // a tile of bm consecutive pixels of one image touches at most this many output rows
+    const int rows_out = std::min(p.out_h, (bm + p.out_w - 2) / p.out_w + 1);
+    rows = (int64_t)(rows_out - 1) * d.stride_height + (int64_t)(d.filter_height - 1) * d.dilation_height + 1;
+  }
+  const int64_t bytes = ((int64_t)images * rows * wp * stride + 1023) / 1024 * 1024;
+  if (bytes + ring > lds_budget) return false;
+  *tpi = ohow * 2 <= bm ? 1 : ceil_div(ohow, bm);
   *halo_rows = (int)rows;
   *ps = (int)stride;
   *halo_bytes = (int)bytes;
+  *ipt = images;
   return true;
 }
 
@@ -312,17 +326,27 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
 bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out) {
   const int ohow = p.out_h * p.out_w;
   const int bn = p.d.channels_out > 64 ? 128 : 64;
-  auto padded = [&](int bm) { return (double)ceil_div(ohow, bm) * bm / (double)ohow; };
-  int order[2] = {256, 128};
-  if (padded(256) - padded(128) > 0.08) std::swap(order[0], order[1]);
-  for (int bm : order) {
+  struct Cand { const MfmaCfg* c; double padded; int64_t blocks; };
+  Cand cand[2];
+  int n = 0;
+  for (int bm : {256, 128}) {
     const MfmaCfg* c = mfma_cfg_by_tile(bm, bn);
-    int a, b, c2, e;
-    if (!c || padded(bm) > 1.0 / 0.7 || !direct_geometry(p, *c, &a, &b, &c2, &e)) continue;
-    *out = *c;
-    return true;
+    int tpi, rows, ps, bytes, ipt;
+    // two blocks per CU (80 KiB each) is where the variant pays: with one, nothing overlaps a
+    // block's halo expansion (measured: 28x28x1024 at 138 KiB loses to the workspace GEMM)
+    if (!c || !direct_geometry(p, *c, &tpi, &rows, &ps, &bytes, &ipt, kDirectLdsAuto)) continue;
+    // rows of a tile that are real pixels
+    const double padded = ohow * 2 <= bm ? (double)bm / ((double)ipt * ohow) : (double)tpi * bm / (double)ohow;
+    if (padded > 1.0 / 0.7) continue;
+    const int64_t blocks = (int64_t)(ohow * 2 <= bm ? ceil_div(p.d.batch, ipt) : p.d.batch * tpi) * ceil_div(p.d.channels_out, bn);
+    cand[n++] = Cand{c, padded, blocks};
   }
-  return false;
+  if (n == 0) return false;
+  int pick = 0;
+  // 256 pixels unless that pads > 8 % more than 128 would, or leaves fewer than 2 blocks per CU
+  if (n == 2 && cand[0].c->bm() == 256 && (cand[0].padded - cand[1].padded > 0.08 || cand[0].blocks < 512)) pick = 1;
+  *out = *cand[pick].c;
+  return true;
 }
 
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk) {
@@ -348,8 +372,11 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   if (p.use_direct) {
     G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;
     G.halo_bytes = p.halo_bytes; G.QG = (G.CPW + 3) / 4;
+    G.IPT = p.ipt; G.B = batch_chunk; G.HPIX = p.halo_rows * p.wp;
     G.div_tpi = make_fastdiv((uint32_t)G.TPI);
     G.div_qg = make_fastdiv((uint32_t)G.QG);
+    G.div_ohow = make_fastdiv((uint32_t)G.OHOW);
+    G.div_hpix = make_fastdiv((uint32_t)G.HPIX);
   }
   return G;
 }
@@ -385,8 +412,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
         // forced: take any tile whose halo fits, whatever the padding waste
         for (int bm : {128, 256}) {
           const MfmaCfg* c = mfma_cfg_by_tile(bm, d.channels_out > 64 ? 128 : 64);
-          int a, b, c2, e;
-          if (c && direct_geometry(p, *c, &a, &b, &c2, &e)) { want = *c; direct = true; break; }
+          int a, b, c2, e, f;
+          if (c && direct_geometry(p, *c, &a, &b, &c2, &e, &f, kDirectLdsMax)) { want = *c; direct = true; break; }
         }
         if (!direct) direct = true;  // reported below by direct_geometry
       }
@@ -401,7 +428,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
                                   (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
     if (repack && p.have_weights) pack_for_mfma(p);
     if (direct) {
-      if (!direct_geometry(p, want, &p.tpi, &p.halo_rows, &p.ps, &p.halo_bytes))
+      if (!direct_geometry(p, want, &p.tpi, &p.halo_rows, &p.ps, &p.halo_bytes, &p.ipt,
+                           p.engine_pref == 3 ? kDirectLdsMax : kDirectLdsAuto))
         return "bconv2d: the direct matrix-core variant cannot hold this tile's input halo in LDS";
       p.use_direct = true;
     }

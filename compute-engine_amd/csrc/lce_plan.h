@@ -62,7 +62,7 @@ struct HostPlan {
   // matrix-core engine (lce_kernels_mfma.h)
   int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo)
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
-  int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0;  // direct-variant geometry
+  int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   bool use_mfma = false;
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
@@ -98,7 +98,10 @@ int max_batch_per_launch(const HostPlan& p);
 // Matrix-core engine: can it run this convolution, and its launch constants.
 bool mfma_supported(const HostPlan& p);
 bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out);
-bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes);
+constexpr int kDirectLdsMax = 160 * 1024;   // one block per CU
+constexpr int kDirectLdsAuto = 80 * 1024;   // two blocks per CU: what the auto rule requires
+bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
+                     int* ipt, int lds_budget);
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 

@@ -130,7 +130,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       wq.resize(wq.size() + 64, 0);
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
       if (h.use_direct) {
-        launch_block_lockstep(nb * h.tpi, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.direct_lds_bytes(h.halo_bytes), [&] {
+        launch_block_lockstep(h.ipt > 1 ? (nb + h.ipt - 1) / h.ipt : nb * h.tpi, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.direct_lds_bytes(h.halo_bytes), [&] {
           fn(A, G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
         });
         continue;

@@ -119,10 +119,12 @@ def test_kernel_selection_is_host_side_and_named():
     assert plan.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     plan.set_option("tile", "auto")
     plan.set_option("engine", "auto")
-    # tiles of the direct variant never cross an image: 7x7 images would leave 62 % of a
-    # 128-pixel tile empty, so auto falls back to the workspace GEMM there
+    # small images share a tile (7x7: two whole images per 128-pixel tile)
     small = amd.Bconv2dPlan(amd.ConvParams(256, 7, 7, 512, 3, 3, 512, padding=amd.PADDING_SAME, pad_values=1))
-    assert small.kernel_name().startswith("bconv2d_mfma<f32,")
+    assert small.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
+    # 2048 input channels: the LDS halo of any tile is too big -> workspace GEMM
+    deep = amd.Bconv2dPlan(amd.ConvParams(8, 28, 28, 2048, 3, 3, 256, padding=amd.PADDING_SAME, pad_values=1))
+    assert deep.kernel_name().startswith("bconv2d_mfma<f32,")
     mid = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1))
     assert mid.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     grouped = amd.Bconv2dPlan(amd.ConvParams(1, 8, 8, 128, 3, 3, 64, groups=2))

@@ -277,6 +277,24 @@ def test_mfma_direct_variant_shapes():
                       tile=(128, 64), engine="direct")
 
 
+def test_mfma_direct_variant_small_images_share_a_tile():
+    """Images of at most BM/2 pixels: a tile holds several whole images (each with its own
+    LDS halo); the batch need not be a multiple of that count."""
+    for spec, tile in [
+        (O.ConvSpec(5, 7, 7, 64, 3, 3, 40, padding=O.PADDING_SAME, pad_values=1), (128, 64)),           # 2 images / tile
+        (O.ConvSpec(7, 5, 4, 96, 3, 3, 33, padding=O.PADDING_SAME, pad_values=0,
+                    semantics=O.SEM_REFERENCE), (128, 64)),                                              # 6 images / tile
+        (O.ConvSpec(7, 5, 4, 96, 3, 3, 33, padding=O.PADDING_SAME, pad_values=0,
+                    semantics=O.SEM_OPTIMIZED), (128, 64)),
+        (O.ConvSpec(4, 9, 8, 32, 3, 2, 70, 1, 2, 1, 1, 2, O.PADDING_VALID, 0, O.ACT_RELU), (256, 128)),  # strided, dilated
+        (O.ConvSpec(3, 6, 6, 64, 1, 1, 64), (128, 128)),                                                 # pointwise
+    ]:
+        names = _run_all_dst_mfma(spec, 31 + spec.batch, tile=tile, engine="direct")
+        assert all("bconv2d_mfma_direct" in n for n in names), names
+    _run_all_dst_mfma(O.ConvSpec(9, 5, 4, 64, 3, 3, 32, padding=O.PADDING_SAME, pad_values=1), 40, tile=(128, 64),
+                      engine="direct", max_batch=4)   # launches of 4, 4, 1 images
+
+
 def test_mfma_engine_refuses_grouped():
     spec = O.ConvSpec(1, 6, 6, 128, 3, 3, 64, groups=2)
     x, w, mul, bias = synth.conv_inputs(spec, 1)

@@ -20,14 +20,15 @@ c = cin
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 B = int(sys.argv[7]) if len(sys.argv) > 7 else 256
 dst = {"f32": amd.F32, "i8": amd.I8, "bp": amd.BITPACKED}[dname]
-one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=cout,
+K = int(os.environ.get("LCE_K", "3"))   # filter height = width
+one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=K, filter_w=K, channels_out=cout,
                  padding=O.PADDING_SAME, pad_values=1)
 _, w, mul, bias = synth.conv_inputs(one, 3)
 x = torch.from_numpy(synth.random_words(synth.rng(4), (B, hw, hw, (c + 31) // 32), c)).to("cuda:0")
 if os.environ.get("LCE_ZERO"):   # constant operands: how much of the time is the power budget?
     x.zero_()
     w = np.zeros_like(w)
-p = amd.ConvParams(B, hw, hw, c, 3, 3, cout, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
+p = amd.ConvParams(B, hw, hw, c, K, K, cout, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
                    out_scale=0.125, out_zero_point=3)
 plan = amd.Bconv2dPlan(p)
 plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
