@@ -226,10 +226,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const uint32_t b_step = (uint32_t)G.Npad * 32u;
   auto fill = [&](int stage) {
     uint8_t* base = lds + stage * STAGE;
+    // a slot beyond the piece count (fewer pieces than waves) is simply not issued: the
+    // counted vmcnt waits of such a wave are then satisfied early, which is harmless
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
+    for (int i = 0; i < NPA; ++i)
+      if (NPA * NWAVES == A_PIECES || wave + i * NWAVES < A_PIECES) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
+    for (int i = 0; i < NPB; ++i)
+      if (NPB * NWAVES == B_PIECES || wave + i * NWAVES < B_PIECES) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
     b_off += b_step;
     a_off += a_step_kc;
     if (++f_kc == G.KCH) {
