@@ -282,7 +282,19 @@ def main():
             qb = fx.numel() * 4 + ow.numel() * 4
             extra["lcequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": qb / s_ / 1e9,
                                                       "hbm_frac": qb / s_ / 1e9 / HBM_PEAK_GBS}
-            del fx, ow
+            # LceDequantize (bits -> float) and LceBMaxPool2d (2x2 stride 2) on the same feature map
+            fo = amd.unpack(ow, 256, torch.float32)
+            torch.cuda.synchronize(dev)
+            s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32), st)
+            extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": qb / s_ / 1e9,
+                                                        "hbm_frac": qb / s_ / 1e9 / HBM_PEAK_GBS}
+            po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
+            torch.cuda.synchronize(dev)
+            s_ = _event_time(torch, dev, lambda: amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID), st)
+            pb = ow.numel() * 4 + po.numel() * 4
+            extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": pb / s_ / 1e9,
+                                                        "hbm_frac": pb / s_ / 1e9 / HBM_PEAK_GBS}
+            del fx, ow, fo, po
             result["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()

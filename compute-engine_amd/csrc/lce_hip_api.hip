@@ -292,17 +292,24 @@ lce_hip_status lce_hip_unpack(lce_hip_dtype out_type, const int32_t* in_dev, siz
   const uint32_t wpr = (uint32_t)((cols + 31) / 32);
   const uint64_t total = (uint64_t)rows * cols;
   const unsigned grid = grid_for_stream((total + 63) / 64, 4);
+  // whole words only and a 16-byte aligned destination: the flat, division-free kernel
+  const bool flat = cols % 32 == 0 && ((uintptr_t)out_dev & 15) == 0;
+  const uint64_t chunks_f32 = total / 4, chunks_b8 = total / 16;
+  auto dv = (lce_dev::u32x4*)out_dev;
   if (out_type == LCE_HIP_F32) {
-    lce::unpack_rows<float><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (float*)out_dev, total, (uint32_t)cols, wpr, 1.0f, -1.0f);
+    if (flat) lce::unpack_flat<float><<<grid_for_stream((chunks_f32 + 63) / 64, 4), 256, 0, st>>>((const uint32_t*)in_dev, dv, chunks_f32, 1.0f, -1.0f);
+    else lce::unpack_rows<float><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (float*)out_dev, total, (uint32_t)cols, wpr, 1.0f, -1.0f);
   } else if (out_type == LCE_HIP_I8) {
     // quantization.cc:131-138
     if (!(scale > 0.0f)) return fail(LCE_HIP_ERR_INVALID, "lce_hip_unpack: int8 output needs a positive scale");
     const int offset = (int)std::round(1.0f / scale);
     const int zero_bit = std::min(127, zero_point + offset);
     const int one_bit = std::max(-128, zero_point - offset);
-    lce::unpack_rows<int8_t><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (int8_t*)out_dev, total, (uint32_t)cols, wpr, (int8_t)zero_bit, (int8_t)one_bit);
+    if (flat) lce::unpack_flat<int8_t><<<grid_for_stream((chunks_b8 + 63) / 64, 4), 256, 0, st>>>((const uint32_t*)in_dev, dv, chunks_b8, (int8_t)zero_bit, (int8_t)one_bit);
+    else lce::unpack_rows<int8_t><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (int8_t*)out_dev, total, (uint32_t)cols, wpr, (int8_t)zero_bit, (int8_t)one_bit);
   } else {
-    lce::unpack_rows<uint8_t><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (uint8_t*)out_dev, total, (uint32_t)cols, wpr, (uint8_t)1, (uint8_t)0);
+    if (flat) lce::unpack_flat<uint8_t><<<grid_for_stream((chunks_b8 + 63) / 64, 4), 256, 0, st>>>((const uint32_t*)in_dev, dv, chunks_b8, (uint8_t)1, (uint8_t)0);
+    else lce::unpack_rows<uint8_t><<<grid, 256, 0, st>>>((const uint32_t*)in_dev, (uint8_t*)out_dev, total, (uint32_t)cols, wpr, (uint8_t)1, (uint8_t)0);
   }
   LCE_HIP_TRY(hipGetLastError());
   return LCE_HIP_OK;

@@ -450,6 +450,26 @@ unpack_rows(const uint32_t* __restrict__ in, T* __restrict__ out, uint64_t total
   }
 }
 
+// cols % 32 == 0: the tensor is one flat bit stream (bitpack.h:294-298 in reverse).  A thread
+// turns 16 / sizeof(T) consecutive bits into one 16-byte store, so the lanes of a wave write
+// consecutive 16-byte pieces (float: 8 lanes share a word and fill one 128-byte line), and
+// there is no division anywhere.
+template <typename T>
+LCE_KERNEL void __launch_bounds__(256)
+unpack_flat(const uint32_t* __restrict__ in, u32x4* __restrict__ out, uint64_t chunks, T zero_bit_value,
+            T one_bit_value) {
+  constexpr int EPT = 16 / (int)sizeof(T);        // elements per thread: 4 floats or 16 bytes
+  constexpr int TPW = 32 / EPT;                   // threads per input word
+  const uint64_t stride = (uint64_t)grid_dim_x() * (uint64_t)block_dim_x();
+  for (uint64_t e = (uint64_t)block_idx_x() * (uint64_t)block_dim_x() + (uint64_t)thread_idx_x(); e < chunks; e += stride) {
+    const uint32_t bits = in[e / TPW] >> ((uint32_t)(e % TPW) * EPT);
+    union { T v[EPT]; u32x4 q; } u;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) u.v[k] = ((bits >> k) & 1u) ? one_bit_value : zero_bit_value;
+    out[e] = u.q;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // LceBMaxPool2d: bitwise AND over the (clipped) window (core/bmaxpool.h:24-88).
 // One thread per output word.

@@ -226,14 +226,16 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const uint32_t b_step = (uint32_t)G.Npad * 32u;
   auto fill = [&](int stage) {
     uint8_t* base = lds + stage * STAGE;
-    // a slot beyond the piece count (fewer pieces than waves) is simply not issued: the
-    // counted vmcnt waits of such a wave are then satisfied early, which is harmless
+    // The counted vmcnt waits assume every wave issues exactly NP pieces per fill -- or none
+    // at all.  So a surplus slot (fewer pieces than waves) may only be skipped when that leaves
+    // the wave with nothing: the direct variant with one B slot.  Otherwise it re-copies an
+    // earlier piece (same bytes to the same address).
+    constexpr bool kSkipSurplus = DIRECT && NPB == 1 && B_PIECES < NWAVES;
 #pragma unroll
-    for (int i = 0; i < NPA; ++i)
-      if (NPA * NWAVES == A_PIECES || wave + i * NWAVES < A_PIECES) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
+    for (int i = 0; i < NPA; ++i) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
-      if (NPB * NWAVES == B_PIECES || wave + i * NWAVES < B_PIECES) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
+      if (!kSkipSurplus || wave < B_PIECES) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
     b_off += b_step;
     a_off += a_step_kc;
     if (++f_kc == G.KCH) {

@@ -217,13 +217,21 @@ int hostsim_unpack(int out_type, const uint32_t* in, uint64_t rows, uint64_t col
                    int32_t zero_point, void* out) {
   const uint32_t wpr = (uint32_t)((cols + 31) / 32);
   const uint64_t total = rows * cols;
+  const bool flat = cols % 32 == 0 && ((uintptr_t)out & 15) == 0;   // same rule as lce_hip_unpack
+  auto dv = (lce_dev::u32x4*)out;
   launch_sequential(2, 1, 256, [&] {
-    if (out_type == LCE_HIP_F32) unpack_rows<float>(in, (float*)out, total, (uint32_t)cols, wpr, 1.0f, -1.0f);
-    else if (out_type == LCE_HIP_I8) {
+    if (out_type == LCE_HIP_F32) {
+      if (flat) unpack_flat<float>(in, dv, total / 4, 1.0f, -1.0f);
+      else unpack_rows<float>(in, (float*)out, total, (uint32_t)cols, wpr, 1.0f, -1.0f);
+    } else if (out_type == LCE_HIP_I8) {
       const int offset = (int)roundf(1.0f / scale);
-      unpack_rows<int8_t>(in, (int8_t*)out, total, (uint32_t)cols, wpr,
-                          (int8_t)std::min(127, zero_point + offset), (int8_t)std::max(-128, zero_point - offset));
-    } else unpack_rows<uint8_t>(in, (uint8_t*)out, total, (uint32_t)cols, wpr, (uint8_t)1, (uint8_t)0);
+      const int8_t z = (int8_t)std::min(127, zero_point + offset), o = (int8_t)std::max(-128, zero_point - offset);
+      if (flat) unpack_flat<int8_t>(in, dv, total / 16, z, o);
+      else unpack_rows<int8_t>(in, (int8_t*)out, total, (uint32_t)cols, wpr, z, o);
+    } else {
+      if (flat) unpack_flat<uint8_t>(in, dv, total / 16, (uint8_t)1, (uint8_t)0);
+      else unpack_rows<uint8_t>(in, (uint8_t*)out, total, (uint32_t)cols, wpr, (uint8_t)1, (uint8_t)0);
+    }
   });
   return 0;
 }

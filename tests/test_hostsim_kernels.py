@@ -151,7 +151,7 @@ def test_bitpack_kernels(dtype, rows, cols):
         assert np.array_equal(H.bitpack(x, zp, force_rows=True), want)
 
 
-@pytest.mark.parametrize("cols", [1, 2, 31, 32, 33, 64, 68])
+@pytest.mark.parametrize("cols", [1, 2, 31, 32, 33, 64, 68, 96, 256])
 def test_quantize_dequantize_round_trip(cols):
     """tflite/tests/quantization_test.cc:75-130."""
     g = synth.rng(cols)
