@@ -562,7 +562,7 @@ lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t
   const uint64_t total = (uint64_t)batch * oh * ow * words;
   const unsigned grid = grid_for_stream((total + 63) / 64, 4);
   lce::bmaxpool_words<<<grid, 256, 0, (hipStream_t)stream>>>((const uint32_t*)input_dev, (uint32_t*)output_dev, batch, in_h, in_w,
-                                                              words, oh, ow, fh, fw, sh, sw, ph, pw, total);
+                                                              words, oh, ow, fh, fw, sh, sw, ph, pw, total, lce::make_fastdiv((uint32_t)words), lce::make_fastdiv((uint32_t)ow), lce::make_fastdiv((uint32_t)oh));
   LCE_HIP_TRY(hipGetLastError());
   return LCE_HIP_OK;
 }

@@ -477,14 +477,25 @@ unpack_flat(const uint32_t* __restrict__ in, u32x4* __restrict__ out, uint64_t c
 LCE_KERNEL void __launch_bounds__(256)
 bmaxpool_words(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int B, int H, int W,
                int C, int OH, int OW, int FH, int FW, int SH, int SW, int PH, int PW,
-               uint64_t total) {
+               uint64_t total, FastDiv div_c, FastDiv div_ow, FastDiv div_oh) {
   const uint64_t stride = (uint64_t)grid_dim_x() * (uint64_t)block_dim_x();
+  const bool small = total < (1ull << 31);   // the multiply-shift division is exact below 2^31
   for (uint64_t e = (uint64_t)block_idx_x() * (uint64_t)block_dim_x() + (uint64_t)thread_idx_x(); e < total; e += stride) {
-    const int c = (int)(e % (uint64_t)C);
-    uint64_t p = e / (uint64_t)C;
-    const int ox = (int)(p % (uint64_t)OW); p /= (uint64_t)OW;
-    const int oy = (int)(p % (uint64_t)OH);
-    const int b = (int)(p / (uint64_t)OH);
+    int c, ox, oy, b;
+    if (small) {
+      uint32_t p = fastdiv((uint32_t)e, div_c);
+      c = (int)((uint32_t)e - p * (uint32_t)C);
+      uint32_t q = fastdiv(p, div_ow);
+      ox = (int)(p - q * (uint32_t)OW);
+      b = (int)fastdiv(q, div_oh);
+      oy = (int)(q - (uint32_t)b * (uint32_t)OH);
+    } else {
+      c = (int)(e % (uint64_t)C);
+      uint64_t p = e / (uint64_t)C;
+      ox = (int)(p % (uint64_t)OW); p /= (uint64_t)OW;
+      oy = (int)(p % (uint64_t)OH);
+      b = (int)(p / (uint64_t)OH);
+    }
     const int x0 = ox * SW - PW, y0 = oy * SH - PH;
     const int xs = x0 < 0 ? 0 : x0, ys = y0 < 0 ? 0 : y0;
     const int xe = x0 + FW < W ? x0 + FW : W, ye = y0 + FH < H ? y0 + FH : H;

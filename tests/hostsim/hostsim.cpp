@@ -242,7 +242,8 @@ int hostsim_bmaxpool(const uint32_t* in, int b, int h, int w, int c, int fh, int
   const int ow = padding == LCE_HIP_PADDING_SAME ? (w + sw - 1) / sw : (w + sw - fw) / sw;
   const int ph = std::max(0, (oh - 1) * sh + fh - h) / 2, pw = std::max(0, (ow - 1) * sw + fw - w) / 2;
   const uint64_t total = (uint64_t)b * oh * ow * c;
-  launch_sequential(2, 1, 256, [&] { bmaxpool_words(in, out, b, h, w, c, oh, ow, fh, fw, sh, sw, ph, pw, total); });
+  launch_sequential(2, 1, 256, [&] { bmaxpool_words(in, out, b, h, w, c, oh, ow, fh, fw, sh, sw, ph, pw, total, make_fastdiv((uint32_t)c), make_fastdiv((uint32_t)ow),
+                   make_fastdiv((uint32_t)oh)); });
   return 0;
 }
 
