@@ -265,6 +265,41 @@ def main():
             # BASELINE config 4: QuickNetLarge = blocks (6, 8, 12, 6) of the same four layer shapes
             extra["quicknet_large_32_layers_ms"] = sum(
                 n * extra[f"quicknet_{hw}x{hw}x{c}_f32"]["ms"] for n, (hw, c) in zip((6, 8, 12, 6), QUICKNET))
+            # the same 16 layers as ONE device-resident chain, each fed by LceQuantize of the previous
+            # float output (what a converted QuickNet does between its binary convolutions), replayed
+            # from a captured HIP graph: launch gaps and the LceQuantize passes included
+            try:
+                chain = []
+                for hw, c in QUICKNET:
+                    sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                                    channels_out=c, padding=O.PADDING_SAME, pad_values=1)
+                    _, _, pl, xq, yo = time_layer(amd, torch, sp, amd.F32, 1, 1, hw, dev)
+                    chain.append((pl, xq, yo))
+
+                def run_chain():
+                    for pl, xq, yo in chain:
+                        for _ in range(4):
+                            pl.run(xq, yo)
+                            amd.bitpack(yo, out=xq)
+                run_chain()
+                torch.cuda.synchronize(dev)
+                eager = _event_time(torch, dev, run_chain, st)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    run_chain()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    run_chain()
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                extra["quicknet_16_layers_with_lcequantize_chain_ms"] = {
+                    "eager": eager * 1e3, "hip_graph_replay": _event_time(torch, dev, graph.replay, st) * 1e3}
+                del chain, graph
+            except Exception as e:   # a report line must not take the bench down
+                extra["quicknet_16_layers_with_lcequantize_chain_ms"] = {"error": repr(e)[:200]}
             # BASELINE config 5 flavour: 1x1 int8-output layers with a RELU clamp (the HBM-bound cases)
             for hw, c in QUICKNET:
                 sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,

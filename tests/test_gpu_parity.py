@@ -444,3 +444,69 @@ def test_unconverted_float_layer_through_prepare(act):
     decided = np.abs(ref) > 1e-3
     assert decided.mean() > 0.95
     assert np.array_equal(got[decided], (ref < 0)[decided])
+
+
+# ------------------------------------------------------------------------------------ device-resident chains, graph replay
+
+def test_device_resident_chain_captures_into_a_graph():
+    """A binary section kept on the device -- LceQuantize -> LceBconv2d(float) -> LceQuantize ->
+    LceBconv2d(bitpacked) -> LceBMaxPool2d -> LceBconv2d(int8) -- runs the same eagerly, replayed
+    from a captured HIP graph (no allocation, copy or synchronisation hides in the run path once the
+    plans are warm), and on the CPU oracle."""
+    g = synth.rng(77)
+    B, H, C = 8, 28, 128
+    x0 = g.uniform(-1.5, 1.5, (B, H, H, C)).astype(np.float32)
+    s1 = O.ConvSpec(B, H, H, C, 3, 3, C, padding=O.PADDING_SAME, pad_values=1)
+    s2 = O.ConvSpec(B, H, H, C, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    s3 = O.ConvSpec(B, H // 2, H // 2, 96, 1, 1, 64)
+    _, w1, m1, b1 = synth.conv_inputs(s1, 1)
+    _, w2, m2, b2 = synth.conv_inputs(s2, 2)
+    _, w3, m3, b3 = synth.conv_inputs(s3, 3)
+    thr2 = O.thresholds_converter(s2, m2, b2)
+    sc3, zp3 = synth.int8_quant_params(3)
+    p1 = amd.Bconv2dPlan(_params(s1, amd.F32)); p1.set_weights(w1, m1, b1)
+    p2 = amd.Bconv2dPlan(_params(s2, amd.BITPACKED)); p2.set_weights(w2, None, None, thr2)
+    p3 = amd.Bconv2dPlan(_params(s3, amd.I8, out_scale=float(sc3), out_zero_point=zp3)); p3.set_weights(w3, m3, b3)
+    xd = torch.from_numpy(x0).to(DEV)
+    # static buffers (a graph replays fixed addresses)
+    q1 = torch.empty((B, H, H, C // 32), dtype=torch.int32, device=DEV)
+    y1 = torch.empty(p1.output_shape, dtype=torch.float32, device=DEV)
+    q2 = torch.empty_like(q1)
+    y2 = torch.empty(p2.output_shape, dtype=torch.int32, device=DEV)
+    y3 = torch.empty(p3.output_shape, dtype=torch.int8, device=DEV)
+
+    def chain():
+        amd.bitpack(xd, out=q1)
+        p1.run(q1, y1)
+        amd.bitpack(y1, out=q2)
+        p2.run(q2, y2)
+        pooled = amd.bmaxpool(y2, 2, 2, 2, 2, amd.PADDING_VALID)
+        p3.run(pooled, y3)
+        return pooled
+
+    chain()                                   # warm: uploads, workspace, LDS opt-in
+    torch.cuda.synchronize()
+    eager = (y1.clone(), y2.clone(), y3.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chain()                               # warm the allocator on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    y1.zero_(); y2.zero_(); y3.zero_()
+    with torch.cuda.graph(graph):
+        chain()
+    y1.zero_(); y2.zero_(); y3.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, (y1, y2, y3)):
+        assert torch.equal(a, b)
+    # oracle
+    o1 = O.bconv2d(s1, O.DST_F32, O.bitpack(x0), w1, m1, b1)
+    o2 = O.bconv2d(s2, O.DST_BITPACKED, O.bitpack(o1), w2, thresholds=thr2)
+    o3 = O.bconv2d(s3, O.DST_I8, O.bmaxpool(o2, 2, 2, 2, 2, O.PADDING_VALID), w3, m3, b3,
+                   out_scale=float(sc3), out_zero_point=zp3)
+    assert np.array_equal(y1.cpu().numpy().view(np.int32), o1.view(np.int32))
+    assert np.array_equal(y2.cpu().numpy(), o2)
+    assert np.array_equal(y3.cpu().numpy(), o3)
