@@ -510,3 +510,38 @@ def test_device_resident_chain_captures_into_a_graph():
     assert np.array_equal(y1.cpu().numpy().view(np.int32), o1.view(np.int32))
     assert np.array_equal(y2.cpu().numpy(), o2)
     assert np.array_equal(y3.cpu().numpy(), o3)
+
+
+@pytest.mark.parametrize("engine", ["auto", "mfma", "valu"])
+def test_batch_larger_than_one_buffer_resource(engine):
+    """Maximum sizes: a float output of > 2 GiB cannot be addressed by one 32-bit buffer
+    resource, so the plan splits the batch into several launches (lce_plan.cpp,
+    max_batch_per_launch).  Images on both sides of every launch boundary must equal the
+    same images run alone (batch independence), and untouched memory after the output stays
+    untouched."""
+    hw, c = 56, 256
+    per_image = hw * hw * c * 4
+    B = (1 << 31) // per_image + 70                      # 738 images, 2.2 GiB of float output
+    spec = O.ConvSpec(B, hw, hw, c, 3, 3, c, padding=O.PADDING_SAME, pad_values=1)
+    one = O.ConvSpec(1, hw, hw, c, 3, 3, c, padding=O.PADDING_SAME, pad_values=1)
+    _, w, mul, bias = synth.conv_inputs(one, 5)
+    g = synth.rng(6)
+    base = synth.random_words(g, (8, hw, hw, c // 32), c)
+    idx = g.integers(0, 8, B)
+    x = torch.from_numpy(base).to(DEV)[torch.from_numpy(idx).to(DEV)].contiguous()   # B images drawn from 8
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    plan.set_option("engine", engine)
+    out = torch.full((B + 1, hw, hw, c), -7.0, dtype=torch.float32, device=DEV)
+    plan.run(x, out[:B])
+    torch.cuda.synchronize()
+    assert torch.all(out[B] == -7.0)
+    p1 = amd.Bconv2dPlan(_params(O.ConvSpec(8, hw, hw, c, 3, 3, c, padding=O.PADDING_SAME, pad_values=1), amd.F32))
+    p1.set_weights(w, mul, bias)
+    p1.set_option("engine", engine)
+    ref8 = p1.run(torch.from_numpy(base).to(DEV))
+    want = O.bconv2d(one, O.DST_F32, base[3:4], w, mul, bias, threads=8)
+    assert np.array_equal(ref8[3:4].cpu().numpy().view(np.int32), want.view(np.int32))
+    # every image equals the run of its source image
+    ok = (out[:B] == ref8[torch.from_numpy(idx).to(DEV)]).flatten(1).all(1)
+    assert bool(ok.all()), "first differing image: %d (%s)" % (int((~ok).nonzero()[0]), plan.kernel_name())
