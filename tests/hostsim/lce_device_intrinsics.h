@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <barrier>
+#include <deque>
 #include <vector>
 
 #define LCE_DEVICE inline
@@ -40,6 +41,9 @@ struct ThreadCtx {
   // wave collectives (only valid when the 64 lanes of a wave run as real threads)
   std::barrier<>* bar = nullptr;
   uint32_t* xchg = nullptr;  // 64 slots shared by the wave
+  // LDS-DMA in flight (this lane's 16 bytes of every piece its wave issued), oldest first
+  struct PendingDma { uint8_t* dst; uint8_t data[16]; };
+  std::deque<PendingDma> dma;
 };
 inline thread_local ThreadCtx g_ctx;
 
@@ -133,13 +137,28 @@ inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
 }
 inline f32x16 f32x16_zero() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.0f; return z; }
 inline uint8_t* lds_base() { return g_ctx.lds; }
+// The simulated LDS-DMA is as asynchronous as the hardware allows, in the most hostile legal
+// way: the destination is POISONED the moment the piece is issued (a reader that has not
+// finished with that stage, or that reads before the data is due, sees garbage) and the
+// real bytes land only when the issuing wave executes the s_waitcnt vmcnt(N) that retires
+// the piece.  A missing or miscounted wait, or a refill of a stage still being read, turns
+// into a wrong result instead of a lucky pass.
 inline void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
   const u32x4 v = buf_load_impl<u32x4>(r, byte_off);
-  memcpy(lds_dst + 16 * (g_ctx.tid_x & 63), &v, 16);
+  ThreadCtx::PendingDma p;
+  p.dst = lds_dst + 16 * (g_ctx.tid_x & 63);
+  memcpy(p.data, &v, 16);
+  memset(p.dst, 0xEE, 16);
+  g_ctx.dma.push_back(p);
 }
 inline void block_sync() { g_ctx.block_bar->arrive_and_wait(); }
 inline void block_barrier_keep_vm() { g_ctx.block_bar->arrive_and_wait(); }
-template <int N> inline void wait_vmcnt() {}  // the simulated LDS-DMA is synchronous
+template <int N> inline void wait_vmcnt() {     // retire the oldest pieces until at most N are in flight
+  while ((int)g_ctx.dma.size() > N) {
+    memcpy(g_ctx.dma.front().dst, g_ctx.dma.front().data, 16);
+    g_ctx.dma.pop_front();
+  }
+}
 inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
 inline void set_wave_priority_high() {}
 inline void set_wave_priority_normal() {}
