@@ -158,6 +158,18 @@ class Bconv2dPlan:
         check(lib().lce_hip_bconv2d_plan_output_shape(self._h, dims))
         self.output_shape = tuple(dims)
 
+    @classmethod
+    def from_handle(cls, handle: int, dst_type: int, channels_out: int = 0) -> "Bconv2dPlan":
+        """Adopts a plan created through the C ABI elsewhere (lce_tflite_model_bconv2d_plan)."""
+        import types
+        self = cls.__new__(cls)
+        self.params = types.SimpleNamespace(dst_type=dst_type, channels_out=channels_out)
+        self._h = C.c_void_p(handle)
+        dims = (C.c_int32 * 4)()
+        check(lib().lce_hip_bconv2d_plan_output_shape(self._h, dims))
+        self.output_shape = tuple(dims)
+        return self
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().lce_hip_bconv2d_plan_destroy(self._h)

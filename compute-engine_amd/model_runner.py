@@ -1,0 +1,235 @@
+"""Run the binary sections of a converted Larq model (.tflite) on the GPU, in true batches.
+
+Host-side counterpart of the reference's Python ``Interpreter`` for the LCE custom ops
+(larq_compute_engine/tflite/python/interpreter.py:58-98, interpreter_base.py:30-95): the same
+property names and the same ``predict`` contract -- a NumPy array with an implicit leading batch
+dimension (or a list of arrays, one per model input) in, concatenated predictions out -- but the
+reference feeds samples one at a time through a batch-1 interpreter (the converter pins the batch
+to 1, mlir/tf_tfl_passes.cc:141-144) while this runner re-plans every LceBconv2d for
+``batch_size`` images and keeps all intermediate tensors in HBM.
+
+Only graphs made of LCE custom ops (LceQuantize, LceBconv2d, LceBMaxPool2d, LceDequantize) can
+run: anything else raises ``NotImplementedError`` -- float stems / heads stay with TensorFlow Lite.
+The model file is read by the bounds-checked reader in csrc/tflite (include/lce_tflite_model.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+from typing import List, Optional, Union
+
+import numpy as np
+
+_amd = importlib.import_module(__package__ or "compute-engine_amd")
+_TFL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "tflite")
+_tfl = None
+
+FLOAT32, INT32, BOOL, INT8 = 0, 2, 6, 9
+_NP = {FLOAT32: np.float32, INT32: np.int32, BOOL: np.bool_, INT8: np.int8}
+LCE_OPS = ("LceQuantize", "LceDequantize", "LceBconv2d", "LceBMaxPool2d")
+
+
+class _TensorInfo(C.Structure):
+    _fields_ = [("type", C.c_int32), ("rank", C.c_int32), ("dims", C.c_int32 * 8), ("quantized", C.c_int32),
+                ("scale", C.c_float), ("zero_point", C.c_int32), ("data", C.c_void_p), ("bytes", C.c_size_t),
+                ("name", C.c_char_p)]
+
+
+class _OperatorInfo(C.Structure):
+    _fields_ = [("builtin_code", C.c_int32), ("custom_code", C.c_char_p), ("inputs", C.POINTER(C.c_int32)),
+                ("num_inputs", C.c_int32), ("outputs", C.POINTER(C.c_int32)), ("num_outputs", C.c_int32),
+                ("custom_options", C.POINTER(C.c_uint8)), ("custom_options_size", C.c_size_t)]
+
+
+def tflite_lib() -> C.CDLL:
+    global _tfl
+    if _tfl is None:
+        path = os.path.join(_TFL_DIR, "liblce_tflite_ops.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-C", _TFL_DIR], check=True, capture_output=True)
+        l = C.CDLL(path)
+        l.lce_tflite_model_open.restype = C.c_void_p
+        l.lce_tflite_model_open.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        l.lce_tflite_model_close.argtypes = [C.c_void_p]
+        for f in ("lce_tflite_model_num_tensors", "lce_tflite_model_num_operators"):
+            getattr(l, f).argtypes = [C.c_void_p]
+        for f in ("lce_tflite_model_inputs", "lce_tflite_model_outputs"):
+            getattr(l, f).argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+        l.lce_tflite_model_tensor.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_TensorInfo)]
+        l.lce_tflite_model_operator.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_OperatorInfo)]
+        l.lce_tflite_model_bconv2d_plan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        l.lce_tflite_option_int.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int32)]
+        l.lce_tflite_model_last_error.restype = C.c_char_p
+        _tfl = l
+    return _tfl
+
+
+class Tensor:
+    def __init__(self, info: _TensorInfo):
+        self.type = info.type
+        self.shape = tuple(info.dims[i] for i in range(info.rank))
+        self.scale = float(info.scale) if info.quantized else None
+        self.zero_point = int(info.zero_point) if info.quantized else None
+        self.name = (info.name or b"").decode()
+        self.constant = bool(info.data)
+
+
+class Operator:
+    def __init__(self, info: _OperatorInfo):
+        self.builtin_code = info.builtin_code
+        self.custom_code = (info.custom_code or b"").decode()
+        self.inputs = [info.inputs[i] for i in range(info.num_inputs)]
+        self.outputs = [info.outputs[i] for i in range(info.num_outputs)]
+        self._opts = (info.custom_options, info.custom_options_size)
+
+    def option(self, key: str) -> Optional[int]:
+        v = C.c_int32()
+        rc = tflite_lib().lce_tflite_option_int(C.cast(self._opts[0], C.c_void_p), self._opts[1], key.encode(), C.byref(v))
+        return None if rc else v.value
+
+
+class LceModel:
+    """A parsed .tflite flatbuffer (first subgraph)."""
+
+    def __init__(self, flatbuffer: Union[bytes, str, os.PathLike]):
+        if not isinstance(flatbuffer, (bytes, bytearray)):
+            with open(flatbuffer, "rb") as f:
+                flatbuffer = f.read()
+        self._data = bytes(flatbuffer)            # must outlive the handle (zero-copy reader)
+        err = C.create_string_buffer(256)
+        self._h = tflite_lib().lce_tflite_model_open(self._data, len(self._data), err, 256)
+        if not self._h:
+            raise ValueError("not a readable TFLite model: " + err.value.decode(errors="replace"))
+        l = tflite_lib()
+        self.tensors: List[Tensor] = []
+        for i in range(l.lce_tflite_model_num_tensors(self._h)):
+            info = _TensorInfo()
+            _amd.check(l.lce_tflite_model_tensor(self._h, i, C.byref(info)))
+            self.tensors.append(Tensor(info))
+        self.operators: List[Operator] = []
+        for i in range(l.lce_tflite_model_num_operators(self._h)):
+            info = _OperatorInfo()
+            _amd.check(l.lce_tflite_model_operator(self._h, i, C.byref(info)))
+            self.operators.append(Operator(info))
+        buf = (C.c_int32 * 64)()
+        self.inputs = [buf[i] for i in range(l.lce_tflite_model_inputs(self._h, buf, 64))]
+        self.outputs = [buf[i] for i in range(l.lce_tflite_model_outputs(self._h, buf, 64))]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            tflite_lib().lce_tflite_model_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def bconv2d_plan(self, op_index: int, batch: int, semantics: int = _amd.SEM_OPTIMIZED) -> "_amd.Bconv2dPlan":
+        """A ready plan (weights set) for LceBconv2d operator ``op_index`` at the given batch size."""
+        h = C.c_void_p()
+        rc = tflite_lib().lce_tflite_model_bconv2d_plan(self._h, op_index, batch, semantics, C.byref(h))
+        if rc:
+            msg = tflite_lib().lce_tflite_model_last_error().decode() or _amd.lib().lce_hip_last_error().decode()
+            raise _amd.LceHipError(rc, msg)
+        out_type = self.tensors[self.operators[op_index].outputs[0]].type
+        dst = {FLOAT32: _amd.F32, INT8: _amd.I8, INT32: _amd.BITPACKED}[out_type]
+        cout = self.tensors[self.operators[op_index].inputs[1]].shape[0]
+        return _amd.Bconv2dPlan.from_handle(h.value, dst, cout)
+
+
+class Interpreter:
+    """``Interpreter(flatbuffer_model, batch_size=...)`` -- see the module docstring."""
+
+    def __init__(self, flatbuffer_model, batch_size: int = 256, device: str = "cuda:0",
+                 use_reference_bconv: bool = False):
+        self.model = flatbuffer_model if isinstance(flatbuffer_model, LceModel) else LceModel(flatbuffer_model)
+        self.batch_size = int(batch_size)
+        self.device = device
+        self._sem = _amd.SEM_REFERENCE if use_reference_bconv else _amd.SEM_OPTIMIZED
+        for op in self.model.operators:
+            if op.builtin_code != 32 or op.custom_code not in LCE_OPS:
+                raise NotImplementedError(
+                    "only LCE custom ops run here; the model contains builtin operator %d %r"
+                    % (op.builtin_code, op.custom_code))
+        self._plans = {}   # (operator index, batch) -> Bconv2dPlan
+
+    # ---- the reference Interpreter's properties (interpreter_base.py:34-72) -------------------
+    def _props(self, ids):
+        t = [self.model.tensors[i] for i in ids]
+        return t
+
+    @property
+    def input_types(self):
+        return [_NP[t.type] for t in self._props(self.model.inputs)]
+
+    @property
+    def input_shapes(self):
+        return [t.shape for t in self._props(self.model.inputs)]
+
+    @property
+    def input_scales(self):
+        return [t.scale for t in self._props(self.model.inputs)]
+
+    @property
+    def input_zero_points(self):
+        return [t.zero_point for t in self._props(self.model.inputs)]
+
+    @property
+    def output_types(self):
+        return [_NP[t.type] for t in self._props(self.model.outputs)]
+
+    @property
+    def output_shapes(self):
+        return [t.shape for t in self._props(self.model.outputs)]
+
+    @property
+    def output_scales(self):
+        return [t.scale for t in self._props(self.model.outputs)]
+
+    @property
+    def output_zero_points(self):
+        return [t.zero_point for t in self._props(self.model.outputs)]
+
+    # ---- execution ------------------------------------------------------------------------------
+    def _plan(self, op_index: int, batch: int):
+        key = (op_index, batch)
+        if key not in self._plans:
+            self._plans[key] = self.model.bconv2d_plan(op_index, batch, self._sem)
+        return self._plans[key]
+
+    def _run_batch(self, inputs):
+        import torch
+        live = {}
+        for idx, arr in zip(self.model.inputs, inputs):
+            live[idx] = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        batch = inputs[0].shape[0]
+        for i, op in enumerate(self.model.operators):
+            x = live[op.inputs[0]]
+            out_t = self.model.tensors[op.outputs[0]]
+            if op.custom_code == "LceQuantize":      # quantization.cc:76-114
+                in_t = self.model.tensors[op.inputs[0]]
+                y = _amd.bitpack(x, in_t.zero_point if x.dtype == torch.int8 else 0)
+            elif op.custom_code == "LceDequantize":  # quantization.cc:116-147
+                dt = {FLOAT32: torch.float32, INT8: torch.int8, BOOL: torch.bool}[out_t.type]
+                y = _amd.unpack(x, out_t.shape[-1], dt, out_t.scale or 1.0, out_t.zero_point or 0)
+            elif op.custom_code == "LceBMaxPool2d":  # bmaxpool.cc:20-98
+                y = _amd.bmaxpool(x, op.option("filter_height"), op.option("filter_width"), op.option("stride_height"),
+                                  op.option("stride_width"), op.option("padding"))
+            else:
+                y = self._plan(i, batch).run(x)
+            live[op.outputs[0]] = y
+        return [live[o].cpu().numpy() for o in self.model.outputs]
+
+    def predict(self, x, verbose: int = 0):
+        """NumPy array(s) with a leading sample dimension -> concatenated predictions
+        (interpreter_base.py:74-95); samples are processed ``batch_size`` at a time."""
+        xs = [x] if isinstance(x, np.ndarray) else list(x)
+        if not xs or len(xs) != len(self.model.inputs):
+            raise ValueError("expected one array per model input (%d)" % len(self.model.inputs))
+        n = xs[0].shape[0]
+        outs = None
+        for b0 in range(0, n, self.batch_size):
+            res = self._run_batch([a[b0:b0 + self.batch_size] for a in xs])
+            outs = [[r] for r in res] if outs is None else [o + [r] for o, r in zip(outs, res)]
+        outputs = [np.concatenate(o) for o in outs]
+        return outputs[0] if len(self.model.outputs) == 1 else outputs

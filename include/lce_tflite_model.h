@@ -1,0 +1,84 @@
+/* lce_tflite_model.h -- read a converted Larq model (.tflite) and hand its LCE custom ops to
+ * the GPU library.  C ABI of liblce_tflite_ops.so.
+ *
+ * Replaces, for the LCE part of a graph, what the reference's callers obtain from TensorFlow
+ * Lite: tflite::FlatBufferModel::BuildFromBuffer + InterpreterBuilder + the interpreter's
+ * tensor table (examples/lce_minimal.cc:28-40; tflite/python/interpreter_wrapper_lite.cc:40-58;
+ * tflite/python/interpreter_wrapper_utils.h).  Host-only except where a plan is created.
+ * The flatbuffer reader restates the published format (see
+ * compute-engine_amd/csrc/tflite/tflite_flatbuffer_reader.h); no real converter output exists
+ * in the build image, so parity with real files is unpinned.
+ */
+#ifndef LCE_TFLITE_MODEL_H_
+#define LCE_TFLITE_MODEL_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lce_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lce_tflite_model lce_tflite_model;
+
+/* TensorType values of schema.fbs that LCE graphs use */
+enum { LCE_TFLITE_FLOAT32 = 0, LCE_TFLITE_INT32 = 2, LCE_TFLITE_BOOL = 6, LCE_TFLITE_INT8 = 9 };
+
+/* Parses `data` (kept by reference: it must outlive the model).  Returns NULL and writes a
+ * message into err (if given) when the buffer is not a well-formed TFL3 flatbuffer. */
+lce_tflite_model* lce_tflite_model_open(const void* data, size_t size, char* err, size_t err_len);
+void lce_tflite_model_close(lce_tflite_model* model);
+
+int32_t lce_tflite_model_num_tensors(const lce_tflite_model* model);
+int32_t lce_tflite_model_num_operators(const lce_tflite_model* model);
+/* Subgraph inputs / outputs (tensor indices); returns the count, fills up to `cap`. */
+int32_t lce_tflite_model_inputs(const lce_tflite_model* model, int32_t* indices, int32_t cap);
+int32_t lce_tflite_model_outputs(const lce_tflite_model* model, int32_t* indices, int32_t cap);
+
+typedef struct lce_tflite_tensor_info {
+  int32_t type;            /* schema TensorType */
+  int32_t rank;
+  int32_t dims[8];
+  int32_t quantized;       /* 1 when scale / zero_point are present */
+  float scale;
+  int32_t zero_point;
+  const void* data;        /* constant data inside the model buffer, or NULL */
+  size_t bytes;
+  const char* name;        /* owned by the model */
+} lce_tflite_tensor_info;
+lce_hip_status lce_tflite_model_tensor(const lce_tflite_model* model, int32_t index, lce_tflite_tensor_info* info);
+
+typedef struct lce_tflite_operator_info {
+  int32_t builtin_code;    /* 32 = CUSTOM */
+  const char* custom_code; /* "LceBconv2d", "LceQuantize", "LceDequantize", "LceBMaxPool2d", or "" */
+  const int32_t* inputs;   /* tensor indices (-1: optional input absent); owned by the model */
+  int32_t num_inputs;
+  const int32_t* outputs;
+  int32_t num_outputs;
+  const uint8_t* custom_options;   /* flexbuffer map, as written by mlir/ir/lce_ops.cc:36-51 */
+  size_t custom_options_size;
+} lce_tflite_operator_info;
+lce_hip_status lce_tflite_model_operator(const lce_tflite_model* model, int32_t index, lce_tflite_operator_info* info);
+
+/* Builds a ready-to-run plan for operator `index`, which must be an LceBconv2d: descriptor
+ * from the op's option map + tensor shapes / types / output quantization exactly as
+ * bconv2d::Init + Prepare collect them (tflite/kernels/bconv2d.cc:85-131,137-300), weights
+ * from the constant tensors (OneTimeSetup, :324-392).  `batch` > 0 overrides the batch
+ * dimension recorded in the file (the converter pins it to 1, mlir/tf_tfl_passes.cc:141-144).
+ * `semantics` selects which registration's behaviour to follow (lce_hip_semantics). */
+lce_hip_status lce_tflite_model_bconv2d_plan(const lce_tflite_model* model, int32_t index, int32_t batch,
+                                             int32_t semantics, lce_hip_bconv2d_plan** plan);
+
+/* Option lookup on any LCE op's custom_options (bmaxpool: filter_height, filter_width,
+ * stride_height, stride_width, padding).  Returns 0 and writes *value when the key exists. */
+int lce_tflite_option_int(const uint8_t* custom_options, size_t size, const char* key, int32_t* value);
+
+/* Message of the last failing lce_tflite_model_* call on this thread (plan creation failures
+ * report through lce_hip_last_error()). */
+const char* lce_tflite_model_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCE_TFLITE_MODEL_H_ */

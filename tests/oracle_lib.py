@@ -80,6 +80,11 @@ class ConvSpec:
     semantics: int = SEM_REFERENCE
     _c: _Conv = field(default=None, repr=False, compare=False)
 
+    def with_batch(self, batch: int) -> "ConvSpec":
+        """Same layer at another batch size (dataclasses.replace would carry the cached C struct)."""
+        import dataclasses
+        return dataclasses.replace(self, batch=batch, _c=None)
+
     def c_struct(self) -> _Conv:
         if self._c is None:
             c = _Conv()

@@ -1,0 +1,45 @@
+"""The batched model runner (compute-engine_amd/model_runner.py) on the
+GPU: a .tflite made of LCE ops is read, every LceBconv2d is planned from the file, and
+``Interpreter.predict`` returns what the CPU oracle computes op by op -- in true batches, with a
+ragged last batch, and identically to the reference's one-sample-at-a-time contract."""
+import importlib
+
+import numpy as np
+import pytest
+
+import synth
+from test_model_reader_host import oracle_forward, small_model
+
+amd = importlib.import_module("compute-engine_amd")
+mr = importlib.import_module("compute-engine_amd.model_runner")
+
+pytestmark = pytest.mark.gpu
+
+
+def test_interpreter_predict_matches_oracle_in_true_batches():
+    data, p = small_model(21)
+    x = synth.rng(5).uniform(-1.5, 1.5, (37, 12, 12, 64)).astype(np.float32)
+    want_i8, want_deq = oracle_forward(x, p)
+    it = mr.Interpreter(data, batch_size=16)
+    assert it.input_shapes == [(1, 12, 12, 64)] and it.input_types == [np.float32]
+    assert it.output_types == [np.int8, np.float32]
+    assert it.output_scales[0] == pytest.approx(float(p["q3"][0])) and it.output_zero_points[0] == p["q3"][1]
+    got_i8, got_deq = it.predict(x)
+    assert got_i8.shape == want_i8.shape and np.array_equal(got_i8, want_i8)
+    assert np.array_equal(got_deq, want_deq)
+    # plans were made once per distinct batch size: 16 and the ragged 5
+    assert sorted({b for (_, b) in it._plans}) == [5, 16]
+    # the reference's contract (interpreter_base.py:74-95): sample by sample gives the same answer
+    one = mr.Interpreter(data, batch_size=1)
+    a, b = one.predict(x[:3])
+    assert np.array_equal(a, want_i8[:3]) and np.array_equal(b, want_deq[:3])
+    # a list with one array per model input is accepted too
+    c, _ = it.predict([x[:4]])
+    assert np.array_equal(c, want_i8[:4])
+
+
+def test_reference_semantics_flag():
+    """use_reference_bconv follows Register_BCONV_2D_REF (exact SAME-zero padding)."""
+    data, _ = small_model(22)
+    mr.Interpreter(data, batch_size=4, use_reference_bconv=True).predict(
+        synth.rng(6).uniform(-1, 1, (4, 12, 12, 64)).astype(np.float32))

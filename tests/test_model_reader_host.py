@@ -1,0 +1,205 @@
+"""The .tflite reader and the plan-from-operator helper (include/lce_tflite_model.h, SURVEY.md 8(f)
+row n3) on the CPU: field round trip against tests/tflite_writer.py, the reference's own
+flexbuffer option bytes inside a model, plans built from a file equal plans built by hand, and
+malformed buffers are refused instead of crashing.  No real converter output exists in this image;
+see the header of csrc/tflite/tflite_flatbuffer_reader.h."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import flexbuf
+import oracle_lib as O
+import synth
+from tflite_writer import ModelBuilder
+
+amd = importlib.import_module("compute-engine_amd")
+mr = importlib.import_module("compute-engine_amd.model_runner")
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def bconv_options(spec: O.ConvSpec) -> bytes:
+    return flexbuf.bconv2d_options(channels_in=spec.channels_in, dilation_height_factor=spec.dilation_h,
+                                   dilation_width_factor=spec.dilation_w, fused_activation_function=spec.activation,
+                                   pad_values=spec.pad_values, padding=spec.padding, stride_height=spec.stride_h,
+                                   stride_width=spec.stride_w)
+
+
+def small_model(seed=0):
+    """float in -> LceQuantize -> LceBconv2d(float) -> LceQuantize -> LceBconv2d(bitpacked, RELU)
+    -> LceBMaxPool2d -> LceBconv2d(int8) ; second output: LceDequantize of the pooled bits."""
+    H, C0 = 12, 64
+    s1 = O.ConvSpec(1, H, H, C0, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1)
+    s2 = O.ConvSpec(1, H, H, 96, 3, 3, 40, 1, 2, 2, 1, 1, O.PADDING_VALID, 0, O.ACT_RELU)
+    oh = s2.out_h
+    s3 = O.ConvSpec(1, oh // 2, oh // 2, 40, 1, 1, 33)
+    _, w1, m1, b1 = synth.conv_inputs(s1, seed + 1)
+    _, w2, m2, b2 = synth.conv_inputs(s2, seed + 2)
+    _, w3, m3, b3 = synth.conv_inputs(s3, seed + 3)
+    thr2 = O.thresholds_converter(s2, m2, b2)
+    sc3, zp3 = synth.int8_quant_params(seed + 3)
+    b = ModelBuilder()
+    t_in = b.tensor([1, H, H, C0], np.float32, "input")
+    t_q1 = b.tensor([1, H, H, 2], np.int32, "q1")
+    t_w1 = b.tensor(w1.shape, np.int32, "w1", w1)
+    t_m1 = b.tensor([96], np.float32, "m1", m1)
+    t_b1 = b.tensor([96], np.float32, "b1", b1)
+    t_y1 = b.tensor([1, H, H, 96], np.float32, "y1")
+    t_q2 = b.tensor([1, H, H, 3], np.int32, "q2")
+    t_w2 = b.tensor(w2.shape, np.int32, "w2", w2)
+    t_t2 = b.tensor([40], np.int32, "thr2", thr2)
+    t_y2 = b.tensor([1, oh, oh, 2], np.int32, "y2")
+    t_p = b.tensor([1, oh // 2, oh // 2, 2], np.int32, "pooled")
+    t_w3 = b.tensor(w3.shape, np.int32, "w3", w3)
+    t_m3 = b.tensor([33], np.float32, "m3", m3)
+    t_b3 = b.tensor([33], np.float32, "b3", b3)
+    t_y3 = b.tensor([1, oh // 2, oh // 2, 33], np.int8, "y3", scale=float(sc3), zero_point=zp3)
+    t_d = b.tensor([1, oh // 2, oh // 2, 40], np.float32, "dequantized")
+    b.inputs, b.outputs = [t_in], [t_y3, t_d]
+    b.custom_op("LceQuantize", [t_in], [t_q1], b"")
+    b.custom_op("LceBconv2d", [t_q1, t_w1, t_m1, t_b1, -1], [t_y1], bconv_options(s1))
+    b.custom_op("LceQuantize", [t_y1], [t_q2], b"")
+    b.custom_op("LceBconv2d", [t_q2, t_w2, -1, -1, t_t2], [t_y2], bconv_options(s2))
+    b.custom_op("LceBMaxPool2d", [t_y2], [t_p], flexbuf.bmaxpool_options(2, 2, 2, 2, O.PADDING_VALID))
+    b.custom_op("LceBconv2d", [t_p, t_w3, t_m3, t_b3, -1], [t_y3], bconv_options(s3))
+    b.custom_op("LceDequantize", [t_p], [t_d], b"")
+    params = dict(s1=s1, s2=s2, s3=s3, w=(w1, w2, w3), m=(m1, m2, m3), b=(b1, b2, b3), thr2=thr2, q3=(sc3, zp3))
+    return b.finish(), params
+
+
+def oracle_forward(x, p):
+    n = x.shape[0]
+    s1, s2, s3 = (s.with_batch(n) for s in (p["s1"], p["s2"], p["s3"]))
+    y1 = O.bconv2d(s1, O.DST_F32, O.bitpack(x), p["w"][0], p["m"][0], p["b"][0])
+    y2 = O.bconv2d(s2, O.DST_BITPACKED, O.bitpack(y1), p["w"][1], thresholds=p["thr2"])
+    pooled = O.bmaxpool(y2, 2, 2, 2, 2, O.PADDING_VALID)
+    y3 = O.bconv2d(s3, O.DST_I8, pooled, p["w"][2], p["m"][2], p["b"][2], out_scale=float(p["q3"][0]),
+                   out_zero_point=p["q3"][1])
+    return y3, O.unpack(pooled, 40, np.float32)
+
+
+def test_reader_round_trips_every_field():
+    data, p = small_model()
+    assert data[4:8] == b"TFL3"
+    m = mr.LceModel(data)
+    assert [t.name for t in m.tensors][:3] == ["input", "q1", "w1"]
+    assert m.tensors[0].shape == (1, 12, 12, 64) and m.tensors[0].type == mr.FLOAT32 and not m.tensors[0].constant
+    assert m.tensors[2].constant and m.tensors[2].shape == p["w"][0].shape and m.tensors[2].type == mr.INT32
+    y3 = m.tensors[m.outputs[0]]
+    assert y3.type == mr.INT8 and y3.scale == pytest.approx(float(p["q3"][0])) and y3.zero_point == p["q3"][1]
+    assert m.tensors[1].scale is None
+    assert [o.custom_code for o in m.operators] == ["LceQuantize", "LceBconv2d", "LceQuantize", "LceBconv2d",
+                                                    "LceBMaxPool2d", "LceBconv2d", "LceDequantize"]
+    assert all(o.builtin_code == 32 for o in m.operators)
+    assert m.operators[1].inputs[4] == -1 and m.operators[3].inputs[2:4] == [-1, -1]
+    assert m.inputs == [0] and len(m.outputs) == 2
+    o = m.operators[3]
+    assert (o.option("stride_height"), o.option("padding"), o.option("fused_activation_function"),
+            o.option("channels_in")) == (2, O.PADDING_VALID, O.ACT_RELU, 96)
+    assert o.option("no_such_key") is None
+    assert m.operators[4].option("filter_height") == 2
+
+
+def test_reference_option_bytes_survive_inside_a_model():
+    """The exact custom_options blob of mlir/tests/legalize-lce.mlir:9 as an operator's options."""
+    k = KATS["bconv2d_custom_options"]
+    blob = bytes.fromhex(k["flexbuffer_hex"])
+    b = ModelBuilder()
+    t0 = b.tensor([1, 4, 4, 1], np.int32, "x")
+    t1 = b.tensor([8, 2, 2, 1], np.int32, "w", np.zeros((8, 2, 2, 1), np.int32))
+    t2 = b.tensor([1, 3, 3, 8], np.float32, "y")
+    b.inputs, b.outputs = [t0], [t2]
+    b.custom_op("LceBconv2d", [t0, t1, -1, -1, -1], [t2], blob)
+    m = mr.LceModel(b.finish())
+    for key, want in k["expected"].items():
+        assert m.operators[0].option(key) == want, key
+
+
+def test_plan_from_model_equals_plan_built_by_hand():
+    data, p = small_model(5)
+    m = mr.LceModel(data)
+    for op_index, spec, dst, kw in ((1, p["s1"], amd.F32, {}), (5, p["s3"], amd.I8,
+                                    dict(out_scale=float(p["q3"][0]), out_zero_point=p["q3"][1]))):
+        plan = m.bconv2d_plan(op_index, batch=7)
+        assert plan.output_shape[0] == 7
+        by_hand = amd.Bconv2dPlan(amd.ConvParams(7, spec.in_h, spec.in_w, spec.channels_in, spec.filter_h, spec.filter_w,
+                                                 spec.channels_out, spec.groups, spec.stride_h, spec.stride_w,
+                                                 spec.dilation_h, spec.dilation_w, spec.padding, spec.pad_values,
+                                                 spec.activation, dst, amd.SEM_OPTIMIZED, **kw))
+        i = {1: 0, 5: 2}[op_index]
+        by_hand.set_weights(p["w"][i], p["m"][i], p["b"][i])
+        assert plan.output_shape == by_hand.output_shape and plan.kernel_name() == by_hand.kernel_name()
+        for a, b in zip(plan.folded(), by_hand.folded()):
+            assert np.array_equal(a, b)
+    with pytest.raises(amd.LceHipError, match="not an LceBconv2d"):
+        m.bconv2d_plan(0, batch=1)
+
+
+def test_prepare_errors_surface_through_the_model_path():
+    """SAME padding with pad_values 0 and a fused RELU is refused by Prepare (bconv2d.cc:188-200)."""
+    s = O.ConvSpec(1, 6, 6, 32, 3, 3, 8, padding=O.PADDING_SAME, pad_values=0, activation=O.ACT_RELU)
+    _, w, mul, bias = synth.conv_inputs(s, 1)
+    b = ModelBuilder()
+    t0 = b.tensor([1, 6, 6, 1], np.int32, "x")
+    t1 = b.tensor(w.shape, np.int32, "w", w)
+    t2 = b.tensor([8], np.float32, "m", mul)
+    t3 = b.tensor([8], np.float32, "b", bias)
+    t4 = b.tensor([1, 6, 6, 8], np.float32, "y")
+    b.inputs, b.outputs = [t0], [t4]
+    b.custom_op("LceBconv2d", [t0, t1, t2, t3, -1], [t4], bconv_options(s))
+    with pytest.raises(amd.LceHipError, match="Zero-padding is only supported by"):
+        mr.LceModel(b.finish()).bconv2d_plan(0, batch=1)
+
+
+def test_malformed_buffers_are_refused_not_crashed_on():
+    data, _ = small_model(9)
+    for bad in (b"", b"\0" * 7, b"\x08\0\0\0XXXX" + data[8:], data[:8]):
+        with pytest.raises(ValueError, match="not a readable TFLite model"):
+            mr.LceModel(bad)
+    g = synth.rng(4)
+    opened = 0
+    for cut in list(range(8, len(data), 97)) + [len(data) - 1]:
+        try:
+            mr.LceModel(data[:cut])
+            opened += 1
+        except ValueError:
+            pass
+    # random corruption: any outcome but a crash; a model that still opens must stay walkable
+    for _ in range(300):
+        d = bytearray(data)
+        for pos in g.integers(8, len(d), 6):
+            d[pos] = int(g.integers(0, 256))
+        try:
+            m = mr.LceModel(bytes(d))
+        except ValueError:
+            continue
+        for i, op in enumerate(m.operators):
+            op.option("padding")
+            if op.custom_code == "LceBconv2d":
+                try:
+                    m.bconv2d_plan(i, batch=1)
+                except amd.LceHipError:
+                    pass
+
+
+def test_interpreter_refuses_graphs_with_builtin_ops():
+    b = ModelBuilder()
+    t0 = b.tensor([1, 4, 4, 32], np.float32, "x")
+    t1 = b.tensor([1, 4, 4, 32], np.float32, "y")
+    b.inputs, b.outputs = [t0], [t1]
+    b.builtin_op(19, [t0], [t1])      # RELU
+    with pytest.raises(NotImplementedError, match="only LCE custom ops"):
+        mr.Interpreter(b.finish())
+
+
+def test_model_abi_exports_every_declared_symbol():
+    """include/lce_tflite_model.h <-> liblce_tflite_ops.so."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lce_tflite_model.h")).read()
+    names = sorted(set(re.findall(r"\b(lce_tflite_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 11
+    lib = mr.tflite_lib()
+    for n in names:
+        assert hasattr(lib, n), n
