@@ -428,9 +428,11 @@ const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan) {
 }
 
 lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, void* output_dev, void* stream) {
-  if (!plan || !input_dev || !output_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: null argument");
+  if (!plan) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: null argument");
   lce::HostPlan& h = plan->host;
   if (!h.have_weights) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: plan_set_weights was not called");
+  if (h.d.batch == 0) return LCE_HIP_OK;   // empty batch: tensors may legitimately be null
+  if (!input_dev || !output_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: null argument");
   if (lce_hip_status s = require_device()) return s;
   const int chunk = lce::max_batch_per_launch(h);
   if (lce_hip_status s = ensure_selected(plan, chunk)) return s;
@@ -505,7 +507,9 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
 }
 
 lce_hip_status lce_hip_bconv2d_run_host(lce_hip_bconv2d_plan* plan, const int32_t* input_host, void* output_host) {
-  if (!plan || !input_host || !output_host) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_host: null argument");
+  if (!plan) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_host: null argument");
+  if (plan->host.d.batch == 0) return LCE_HIP_OK;   // empty batch
+  if (!input_host || !output_host) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_host: null argument");
   if (lce_hip_status s = require_device()) return s;
   const lce::HostPlan& h = plan->host;
   const size_t in_bytes = (size_t)h.d.batch * h.d.in_height * h.d.in_width * h.cw * 4;
@@ -554,8 +558,9 @@ lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t
                                 int32_t padding, int32_t* output_dev, void* stream) {
   int32_t oh = 0, ow = 0;
   if (lce_hip_status s = lce_hip_bmaxpool_output_shape(in_h, in_w, fh, fw, sh, sw, padding, &oh, &ow)) return s;
+  if (batch == 0) return LCE_HIP_OK;   // empty batch: nothing to do (core/bmaxpool.h:43 loops zero times)
   if (!input_dev || !output_dev) return fail(LCE_HIP_ERR_INVALID, "bmaxpool: null tensor");
-  if (oh < 1 || ow < 1 || batch < 1 || words < 1) return fail(LCE_HIP_ERR_INVALID, "bmaxpool: empty tensor");
+  if (oh < 1 || ow < 1 || batch < 0 || words < 1) return fail(LCE_HIP_ERR_INVALID, "bmaxpool: empty tensor");
   if (lce_hip_status s = require_device()) return s;
   const int ph = std::max(0, (oh - 1) * sh + fh - in_h) / 2;
   const int pw = std::max(0, (ow - 1) * sw + fw - in_w) / 2;

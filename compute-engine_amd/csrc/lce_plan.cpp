@@ -31,7 +31,9 @@ static int pad_before(int stride, int dilation, int in, int filter, int out) {
 std::string validate_and_infer(HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
   char buf[256];
-  if (d.batch < 1 || d.in_height < 1 || d.in_width < 1 || d.channels_in < 1 ||
+  // an EMPTY batch is legal (the reference's loops simply do not run, reference.h:84); every
+  // other extent must be positive
+  if (d.batch < 0 || d.in_height < 1 || d.in_width < 1 || d.channels_in < 1 ||
       d.filter_height < 1 || d.filter_width < 1 || d.channels_out < 1)
     return "bconv2d: all tensor dimensions must be positive";
   if (d.stride_height < 1 || d.stride_width < 1 || d.dilation_height < 1 || d.dilation_width < 1)

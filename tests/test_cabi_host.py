@@ -148,3 +148,17 @@ def test_compute_fails_loudly_without_a_gpu():
     rc = amd.lib().lce_hip_bitpack(amd.F32, buf.ctypes.data_as(C.c_void_p), 1, 64, 0,
                                    out.ctypes.data_as(C.c_void_p), None)
     assert rc == amd.ERR_NO_DEVICE
+
+
+def test_empty_batch_is_legal_and_a_no_op():
+    """TFLite tensors may have a zero batch; the reference's loops then do not run
+    (core/bconv2d/reference.h:84, core/bmaxpool.h:43).  No GPU is needed for nothing."""
+    spec = O.ConvSpec(1, 5, 5, 64, 3, 3, 16)
+    _, filt, mul, bias = synth.conv_inputs(spec, 1)
+    plan = amd.Bconv2dPlan(amd.ConvParams(0, 5, 5, 64, 3, 3, 16))
+    assert plan.output_shape == (0, 3, 3, 16)
+    plan.set_weights(filt, mul, bias)
+    plan.run_ptr(0, 0)                                   # returns OK without touching anything
+    assert amd.lib().lce_hip_bmaxpool(None, 0, 4, 4, 2, 2, 2, 2, 2, amd.PADDING_VALID, None, None) == 0
+    with pytest.raises(amd.LceHipError):
+        amd.Bconv2dPlan(amd.ConvParams(-1, 5, 5, 64, 3, 3, 16))
