@@ -181,6 +181,10 @@ LCE_DEVICE void interleave_mfma_ldsread() {
 // Streaming (non-temporal) 16-byte store for outputs that are written once and not re-read
 // by this kernel: keeps the L2 for the operands that ARE re-read.
 LCE_DEVICE void store_streaming(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }
+LCE_DEVICE void store_streaming(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+// ... and the matching load for inputs that are read exactly once
+LCE_DEVICE f32x4 load_streaming(const f32x4* p) { return __builtin_nontemporal_load(p); }
+LCE_DEVICE u32x4 load_streaming(const u32x4* p) { return __builtin_nontemporal_load(p); }
 LCE_DEVICE float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {hi (4-7), lo (0-3)}; 0x0c = 0x00
 LCE_DEVICE uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }

@@ -166,6 +166,9 @@ inline void sched_fence() {}
 inline void pin(f32x16&) {}
 template <int N> inline void interleave_mfma_ldsread() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
+inline void store_streaming(u32x4* p, u32x4 v) { *p = v; }
+inline f32x4 load_streaming(const f32x4* p) { return *p; }
+inline u32x4 load_streaming(const u32x4* p) { return *p; }
 inline float med3(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 inline uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
   const uint64_t pool = ((uint64_t)hi << 32) | lo;
