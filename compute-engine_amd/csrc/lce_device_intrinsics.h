@@ -67,7 +67,6 @@ LCE_DEVICE uint32_t write_lane(uint32_t value, uint32_t old) {
   return old;
 }
 LCE_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
-LCE_DEVICE float round_half_away(float y) { return roundf(y); }  // std::round semantics
 
 // a * b + c with TWO roundings, as the reference's portable C++ computes it
 // (core/bconv2d/output_transform.h:105).  hipcc contracts `a * b + c` -- and even
@@ -139,11 +138,10 @@ LCE_DEVICE uint8_t* lds_base() {
 // Asynchronous global -> LDS copy (buffer_load_dwordx4 ... lds): every lane fetches 16 bytes
 // at its own buffer offset; the wave's 64 x 16 bytes land CONTIGUOUSLY at lds_dst + 16*lane
 // (lds_dst is wave-uniform).  No VGPR round trip, no ds_write.  Completion is tracked by
-// vmcnt; block_sync() (= __syncthreads) waits for it.
+// vmcnt: wait_vmcnt<N>() below, then a barrier, before another wave reads the bytes.
 LCE_DEVICE void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, byte_off, 0, 0, 0);
 }
-LCE_DEVICE void block_sync() { __syncthreads(); }
 // Barrier that does NOT drain the VM counter: LDS-DMA copies issued for later pipeline
 // stages stay in flight across it.  Pair with wait_vmcnt<N>() for the stage being consumed.
 // (The waits use the s_waitcnt BUILTIN, not inline asm, so that hipcc's own wait-count
@@ -162,9 +160,6 @@ LCE_DEVICE void wait_vmcnt() {
 // accesses go through differently-typed pointers: wait for the LDS queue, and stop the
 // compiler from moving LDS accesses across.
 LCE_DEVICE void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-LCE_DEVICE void set_wave_priority_high() { __builtin_amdgcn_s_setprio(1); }
-LCE_DEVICE void set_wave_priority_normal() { __builtin_amdgcn_s_setprio(0); }
-LCE_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Pins an accumulator tile at this point of the program: the MFMAs that produce it cannot
 // be sunk below (hipcc otherwise moves the register-only MFMAs of a K-step past the NEXT
 // step's barrier, which serialises LDS latency and matrix work).

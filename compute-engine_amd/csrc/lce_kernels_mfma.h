@@ -10,21 +10,31 @@
 // magnitude < 2^24), at 4.2e15 MAC/s measured (tools/probes/mfma_fp4_peak.hip).  So this
 // engine is bit-exact to the xor-popcount one and ~5x higher in ceiling.
 //
-// Pipeline of one call:
-//   1. expand_fp4: bitpacked activations [B,H,W,Cw] -> FP4, spatially PADDED workspace laid
-//      out as word planes [Cpad/32][B,Hp,Wp][16 bytes] (one 16-byte element = the 32 channels
-//      of one input word), so that 64 consecutive pixels of one K-half are one contiguous
-//      KiB; border pixels hold +1 (pad_values 1) or 0 (exact SAME-zero
-//      padding: an outside tap then contributes 0 to <a,w>, which is what
-//      reference.h:100-103 adds as (Cin/G)/2 in popcount units); channels >= Cin hold 0.
-//      After this no kernel needs a bounds check.
-//   2. bconv2d_mfma: implicit GEMM, M = B*OH*OW pixels, N = Cout, K = KH*KW*Cpad, in K-steps
-//      of 64 (one v_mfma_scale_f32_32x32x64_f8f6f4 deep).  A block is WGM x WGN waves, each
-//      wave owns WM x WN MFMA tiles of 32x32; A (pixels) and B (weights, pre-expanded and
-//      pre-tiled by the planner) tiles go global -> LDS by asynchronous LDS-DMA
-//      (buffer_load_dwordx4 ... lds, no VGPR round trip) into two stages, fragments are
-//      read with conflict-free ds_read_b128, and the output transform
-//      (output_transform.h:93-168) is fused on the fp32 accumulators:
+// Two variants of one kernel template (bconv2d_mfma<..., DIRECT>):
+//
+//   DIRECT (the default; "direct variant" below): a block's tile is BM consecutive output
+//      pixels of one image (or several whole small images).  The block reads the bitpacked
+//      input rows the tile needs once, expands them to FP4 in registers and keeps them in
+//      LDS for the whole K loop; only the weights stream through an LDS-DMA ring.  One launch
+//      per call, no workspace.
+//
+//   workspace GEMM (engine=mfma; chosen when the LDS halo would not leave room for two blocks
+//      per CU, or too little of a tile would be real pixels):
+//      1. expand_fp4: bitpacked activations [B,H,W,Cw] -> FP4, spatially PADDED workspace
+//         laid out as word planes [Cpad/32][B,Hp,Wp][16 bytes] (one 16-byte element = the 32
+//         channels of one input word), so that 64 consecutive pixels of one K-half are one
+//         contiguous KiB; border pixels hold +1 (pad_values 1) or 0 (exact SAME-zero padding:
+//         an outside tap then contributes 0 to <a,w>, which is what reference.h:100-103 adds
+//         as (Cin/G)/2 in popcount units); channels >= Cin hold 0.  After this no kernel
+//         needs a bounds check.
+//      2. bconv2d_mfma: implicit GEMM over M = B*OH*OW pixels; A and B tiles both go
+//         global -> LDS through the ring.
+//
+// Common: N = Cout, K = KH*KW*Cpad in K-steps of 64 (one v_mfma_scale_f32_32x32x64_f8f6f4
+// deep).  A block is WGM x WGN waves, each wave owns WM x WN MFMA tiles of 32x32; operands
+// arrive by asynchronous LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR round trip) into a
+// 3- or 4-stage ring, fragments are read with ds_read_b128, and the output transform
+// (output_transform.h:93-168) is fused on the fp32 accumulators:
 //         2*accum = K_bt - d  ->  clamp -> * mul + bias   (two roundings)
 #pragma once
 #include <lce_device_intrinsics.h>

@@ -74,7 +74,6 @@ inline u32x4 buf_load(rsrc_t r, uint32_t off, u32x4*) { return buf_load_impl<u32
 
 inline uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline int popc(uint32_t x) { return __builtin_popcount(x); }
-inline float round_half_away(float y) { return roundf(y); }
 inline float mul_then_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
 
 inline unsigned long long wave_ballot(bool p) {
@@ -151,7 +150,6 @@ inline void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
   memset(p.dst, 0xEE, 16);
   g_ctx.dma.push_back(p);
 }
-inline void block_sync() { g_ctx.block_bar->arrive_and_wait(); }
 inline void block_barrier_keep_vm() { g_ctx.block_bar->arrive_and_wait(); }
 template <int N> inline void wait_vmcnt() {     // retire the oldest pieces until at most N are in flight
   while ((int)g_ctx.dma.size() > N) {
@@ -160,9 +158,6 @@ template <int N> inline void wait_vmcnt() {     // retire the oldest pieces unti
   }
 }
 inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
-inline void set_wave_priority_high() {}
-inline void set_wave_priority_normal() {}
-inline void sched_fence() {}
 inline void pin(f32x16&) {}
 template <int N> inline void interleave_mfma_ldsread() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
