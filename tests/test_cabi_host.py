@@ -162,3 +162,31 @@ def test_empty_batch_is_legal_and_a_no_op():
     assert amd.lib().lce_hip_bmaxpool(None, 0, 4, 4, 2, 2, 2, 2, 2, amd.PADDING_VALID, None, None) == 0
     with pytest.raises(amd.LceHipError):
         amd.Bconv2dPlan(amd.ConvParams(-1, 5, 5, 64, 3, 3, 16))
+
+
+@pytest.mark.parametrize("hw,c,dst,want", [
+    (56, 256, "F32", "bconv2d_mfma_direct<f32,256x128>"),          # BASELINE L0
+    (56, 256, "I8", "bconv2d_mfma_direct<i8,256x128>"),
+    (56, 256, "BITPACKED", "bconv2d_mfma_direct<bitpacked,256x128>"),
+    (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
+    (28, 128, "F32", "bconv2d_mfma_direct<f32,128x128>"),
+    (14, 256, "F32", "bconv2d_mfma_direct<f32,256x128>"),
+    (7, 512, "F32", "bconv2d_mfma_direct<f32,128x128>"),           # two whole images per tile
+])
+def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
+    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v5.jsonl); this pins what it
+    picks for the BASELINE.json layers at batch 256 so that a planner edit shows up as a diff."""
+    p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=getattr(amd, dst))
+    assert amd.Bconv2dPlan(p).kernel_name() == want
+
+
+def test_planner_fallbacks():
+    def name(**kw):
+        base = dict(batch=256, in_height=28, in_width=28, channels_in=128, filter_height=3, filter_width=3,
+                    channels_out=128)
+        base.update(kw)
+        return amd.Bconv2dPlan(amd.ConvParams(**base)).kernel_name()
+    assert name(groups=2).startswith("bconv2d_tiled<")                 # grouped: xor-popcount engine
+    assert name(batch=1, in_height=4, in_width=4, channels_out=8).startswith("bconv2d_tiled<")   # too small for the matrix cores
+    assert name(channels_in=2048, batch=8).startswith("bconv2d_mfma<")  # LDS halo too large: workspace GEMM
+    assert name(channels_in=100, channels_out=33, stride_height=2, stride_width=2).startswith("bconv2d_mfma_direct<")
