@@ -189,4 +189,8 @@ def test_planner_fallbacks():
     assert name(groups=2).startswith("bconv2d_tiled<")                 # grouped: xor-popcount engine
     assert name(batch=1, in_height=4, in_width=4, channels_out=8).startswith("bconv2d_tiled<")   # too small for the matrix cores
     assert name(channels_in=2048, batch=8).startswith("bconv2d_mfma<")  # LDS halo too large: workspace GEMM
-    assert name(channels_in=100, channels_out=33, stride_height=2, stride_width=2).startswith("bconv2d_mfma_direct<")
+    # 13x13 outputs: a 128-pixel tile would be 34 % padding -> workspace GEMM (tiles span images)
+    assert name(channels_in=100, channels_out=33, stride_height=2, stride_width=2).startswith("bconv2d_mfma<")
+    # 27x27 outputs: 6 tiles of 128 pixels pad 5 % -> direct
+    assert name(in_height=56, in_width=56, channels_in=100, channels_out=33, stride_height=2,
+                stride_width=2).startswith("bconv2d_mfma_direct<")
