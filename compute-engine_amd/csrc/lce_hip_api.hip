@@ -608,4 +608,12 @@ lce_hip_status lce_hip_prepare_bitpack_filter(const float* filter_ohwi, int32_t 
   return prep_status(lce::bitpack_filter(filter_ohwi, kh, kw, cin, cout, filter_words));
 }
 
+#ifdef LCE_TIMELINE
+// profiling aid (tools/timeline.py), not part of the ABI: the K-loop time stamps of the last launch
+int lce_hip_debug_read_timeline(void* host, size_t bytes) {
+  if (bytes > sizeof(lce::lce_timeline)) bytes = sizeof(lce::lce_timeline);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lce::lce_timeline), bytes);
+}
+#endif
+
 }  // extern "C"

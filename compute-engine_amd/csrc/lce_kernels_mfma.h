@@ -131,6 +131,20 @@ expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaA
 //   wq : FP4 weights [KS][2 halves][Npad][16 bytes]
 //   thrf : bitpacked output: per-channel float t with  bit = (d < t)   (= accum > threshold)
 // ---------------------------------------------------------------------------------
+#ifdef LCE_TIMELINE
+// Profiling aid (tools/timeline.py builds the library with -DLCE_TIMELINE; never defined in the
+// product build): s_memtime stamps of the K loop of two blocks from the middle of the grid,
+// [block][wave][K-step][4 stamps].  A stamp waits for lgkmcnt, so a segment that issues
+// ds_reads includes their latency.
+__device__ unsigned long long lce_timeline[2 * 8 * 80 * 4];
+#define LCE_TL(slot)                                                                          \
+  do {                                                                                        \
+    if (tl_on && ks < 80 && lane == 0)                                                        \
+      lce_timeline[((tl_blk * 8 + wave) * 80 + ks) * 4 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define LCE_TL(slot) do {} while (0)
+#endif
 template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
@@ -152,6 +166,12 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   constexpr int A_PIECES = BM / 32;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tiles are filled in 64-row pieces");
 
+#ifdef LCE_TIMELINE
+  const uint32_t tl_lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
+  const uint32_t tl_first = ((uint32_t)grid_dim_x() * (uint32_t)gridDim.y) / 2u;
+  const bool tl_on = tl_lin - tl_first < 2u;
+  const int tl_blk = (int)(tl_lin - tl_first);
+#endif
   uint8_t* const lds0 = lds_base();
   uint8_t* const lds = lds0 + (DIRECT ? G.halo_bytes : 0);   // the K-step ring
   const int tid = thread_idx_x();
@@ -389,10 +409,13 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   auto step = [&](auto steady, int ks, u32x4 (&af)[WM], u32x4 (&bf)[WN], u32x4 (&af_next)[WM],
                   u32x4 (&bf_next)[WN]) {
     if constexpr (decltype(steady)::value) {
+      LCE_TL(0);
       wait_vmcnt<NP * (STAGES - 2)>();          // own pieces of step ks+1 have landed
       block_barrier_keep_vm();
+      LCE_TL(1);
       fill(ks % STAGES);                         // step ks+STAGES into the stage just vacated
       load_frags(ks + 1, af_next, bf_next);
+      LCE_TL(2);
     } else {
       wait_vmcnt<0>();                           // tail: fewer fills in flight than the exact count
       block_barrier_keep_vm();
@@ -408,6 +431,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) pin(acc[i][j]);  // ... and the MFMAs stay in front of the next barrier
+    if constexpr (decltype(steady)::value) LCE_TL(3);
   };
 
   if (STAGES <= KS) wait_vmcnt<NP * (STAGES - 1)>();
