@@ -35,7 +35,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import synthetic_layers as SL  # noqa: E402  (NumPy-only layer descriptions + seeded operands)
 
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP4_PEAK_TFLOPS = 10000.0                         # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
@@ -45,18 +46,9 @@ L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_ou
 QUICKNET = [(56, 64), (28, 128), (14, 256), (7, 512)]  # (H=W, C): 4 layers each in QuickNet
 
 
-def algorithmic_bytes(spec, dst) -> int:
+def algorithmic_bytes(layer, dst) -> int:
     """input words + weights + params + output, each counted once."""
-    import oracle_lib as O
-    inp = spec.batch * spec.in_h * spec.in_w * spec.in_words * 4
-    wts = spec.channels_out * spec.filter_h * spec.filter_w * spec.filter_words * 4
-    if dst == O.DST_BITPACKED:
-        params = spec.channels_out * 4
-        out = spec.batch * spec.out_h * spec.out_w * spec.out_words * 4
-    else:
-        params = spec.channels_out * 8
-        out = spec.batch * spec.out_h * spec.out_w * spec.channels_out * (4 if dst == O.DST_F32 else 1)
-    return inp + wts + params + out
+    return layer.algorithmic_bytes(dst)
 
 
 def _event_time(torch, dev, fn, steps):
@@ -69,24 +61,13 @@ def _event_time(torch, dev, fn, steps):
     return e0.elapsed_time(e1) / 1e3 / steps
 
 
-def time_layer(amd, torch, spec, dst, steps, warmup, seed, dev, scale=1.0, zp=0, engine="auto"):
-    """Returns (mean seconds per step from stream events, kernel name, plan, x, out)."""
-    import oracle_lib as O
-    import synth
-    one = O.ConvSpec(**{**{k: getattr(spec, k) for k in (
-        "in_h", "in_w", "channels_in", "filter_h", "filter_w", "channels_out", "groups", "stride_h",
-        "stride_w", "dilation_h", "dilation_w", "padding", "pad_values", "activation", "semantics")},
-        "batch": 1})
-    _, w, mul, bias = synth.conv_inputs(one, seed)
-    g = synth.rng(seed + 7)
-    x = torch.from_numpy(synth.random_words(g, spec.input_shape(), spec.channels_in)).to(dev)
-    p = amd.ConvParams(spec.batch, spec.in_h, spec.in_w, spec.channels_in, spec.filter_h, spec.filter_w,
-                       spec.channels_out, spec.groups, spec.stride_h, spec.stride_w, spec.dilation_h,
-                       spec.dilation_w, spec.padding, spec.pad_values, spec.activation, dst,
-                       amd.SEM_OPTIMIZED, float(scale), int(zp))
-    plan = amd.Bconv2dPlan(p)
-    thr = O.thresholds_converter(one, mul, bias) if dst == amd.BITPACKED else None
-    plan.set_weights(w, mul, bias, thr)
+def time_layer(amd, torch, layer, dst, steps, warmup, seed, dev, scale=1.0, zp=0, engine="auto"):
+    """Returns (mean seconds per step from stream events, kernel name, plan, x, out).
+    Synthetic operands from tools/synthetic_layers.py -- the oracle is not involved."""
+    w, mul, bias, thr = SL.weights(layer, seed)
+    x = torch.from_numpy(SL.activations(layer, seed)).to(dev)
+    plan = amd.Bconv2dPlan(layer.params(amd, dst, scale, zp))
+    plan.set_weights(w, mul, bias, thr if dst == amd.BITPACKED else None)
     plan.set_option("engine", engine)
     dt = {amd.F32: torch.float32, amd.I8: torch.int8, amd.BITPACKED: torch.int32}[dst]
     out = torch.empty(plan.output_shape, dtype=dt, device=dev)
@@ -98,6 +79,7 @@ def time_layer(amd, torch, spec, dst, steps, warmup, seed, dev, scale=1.0, zp=0,
 
 def cpu_baseline(target_seconds=12.0):
     """Time the CPU oracle (port of the reference's portable path) on the L0 layer."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))   # the oracle's ctypes wrapper lives with the tests
     import oracle_lib as O
     import synth
     cores = os.cpu_count() or 1
@@ -131,7 +113,6 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import oracle_lib as O
     amd = importlib.import_module("compute-engine_amd")
     shard = importlib.import_module("compute-engine_amd.batch_shard")
 
@@ -151,7 +132,7 @@ def main():
     # weak scaling: the global batch grows with N, every rank owns a contiguous slab of it
     global_batch = args.batch * world
     _, my_batch = shard.shard_range(global_batch, world, rank)
-    spec = O.ConvSpec(batch=my_batch, padding=O.PADDING_SAME, pad_values=1, **L0)
+    spec = SL.Layer(batch=my_batch, padding=SL.PADDING_SAME, pad_values=1, **L0)
     # warm up + per-step time from stream events (a step = every kernel of one LceBconv2d call)
     step_sec, kname, plan, x, out = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev)
 
@@ -178,7 +159,7 @@ def main():
 
     total_bmacs = spec.binary_macs * args.steps * world
     value = total_bmacs / elapsed
-    abytes = algorithmic_bytes(spec, O.DST_F32)
+    abytes = algorithmic_bytes(spec, SL.DST_F32)
     mfma = kname.startswith("bconv2d_mfma")
     direct = kname.startswith("bconv2d_mfma_direct")   # single kernel: the block expands its own input halo
 
@@ -240,7 +221,7 @@ def main():
             extra = {}
             st, wu = max(5, args.steps // 5), 3
             sc, zp = 0.125, 3
-            for nm, dst, od in (("l0_int8_out", amd.I8, O.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, O.DST_BITPACKED)):
+            for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
                 s_, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
                 extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
                              "GBps_algorithmic": algorithmic_bytes(spec, od) / s_ / 1e9}
@@ -253,14 +234,14 @@ def main():
                                            "valu_pair_frac": spec.binary_macs / s_ / VALU_BMAC_PEAK}
             tot = 0.0
             for hw, c in QUICKNET:
-                sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
-                                channels_out=c, padding=O.PADDING_SAME, pad_values=1)
+                sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                              channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
                 s_, kn, *_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
                 tot += 4 * s_
                 extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {
                     "ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
-                    "GBps_algorithmic": algorithmic_bytes(sp, O.DST_F32) / s_ / 1e9,
-                    "hbm_frac": algorithmic_bytes(sp, O.DST_F32) / s_ / 1e9 / HBM_PEAK_GBS}
+                    "GBps_algorithmic": algorithmic_bytes(sp, SL.DST_F32) / s_ / 1e9,
+                    "hbm_frac": algorithmic_bytes(sp, SL.DST_F32) / s_ / 1e9 / HBM_PEAK_GBS}
             extra["quicknet_16_layers_ms"] = tot * 1e3
             # BASELINE config 4: QuickNetLarge = blocks (6, 8, 12, 6) of the same four layer shapes
             extra["quicknet_large_32_layers_ms"] = sum(
@@ -271,8 +252,8 @@ def main():
             try:
                 chain = []
                 for hw, c in QUICKNET:
-                    sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
-                                    channels_out=c, padding=O.PADDING_SAME, pad_values=1)
+                    sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                                  channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
                     _, _, pl, xq, yo = time_layer(amd, torch, sp, amd.F32, 1, 1, hw, dev)
                     chain.append((pl, xq, yo))
 
@@ -302,10 +283,10 @@ def main():
                 extra["quicknet_16_layers_with_lcequantize_chain_ms"] = {"error": repr(e)[:200]}
             # BASELINE config 5 flavour: 1x1 int8-output layers with a RELU clamp (the HBM-bound cases)
             for hw, c in QUICKNET:
-                sp = O.ConvSpec(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
-                                channels_out=c, activation=O.ACT_RELU)
+                sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
+                              channels_out=c, activation=SL.ACT_RELU)
                 s_, kn, *_ = time_layer(amd, torch, sp, amd.I8, st, wu, hw + 1, dev, sc, zp)
-                ab = algorithmic_bytes(sp, O.DST_I8)
+                ab = algorithmic_bytes(sp, SL.DST_I8)
                 extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {
                     "ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
                     "GBps_algorithmic": ab / s_ / 1e9, "hbm_frac": ab / s_ / 1e9 / HBM_PEAK_GBS}

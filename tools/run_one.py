@@ -8,10 +8,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
-import oracle_lib as O  # noqa: E402
-import synth  # noqa: E402
+import synthetic_layers as SL  # noqa: E402
 
 amd = importlib.import_module("compute-engine_amd")
 hw, dname, engine, tile = int(sys.argv[1]), sys.argv[3], sys.argv[4], sys.argv[5]
@@ -21,17 +20,14 @@ steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 B = int(sys.argv[7]) if len(sys.argv) > 7 else 256
 dst = {"f32": amd.F32, "i8": amd.I8, "bp": amd.BITPACKED}[dname]
 K = int(os.environ.get("LCE_K", "3"))   # filter height = width
-one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=K, filter_w=K, channels_out=cout,
-                 padding=O.PADDING_SAME, pad_values=1)
-_, w, mul, bias = synth.conv_inputs(one, 3)
-x = torch.from_numpy(synth.random_words(synth.rng(4), (B, hw, hw, (c + 31) // 32), c)).to("cuda:0")
+layer = SL.Layer(B, hw, hw, c, K, K, cout, padding=SL.PADDING_SAME, pad_values=1)
+w, mul, bias, thr = SL.weights(layer, 3)
+x = torch.from_numpy(SL.activations(layer, 4)).to("cuda:0")
 if os.environ.get("LCE_ZERO"):   # constant operands: how much of the time is the power budget?
     x.zero_()
     w = np.zeros_like(w)
-p = amd.ConvParams(B, hw, hw, c, K, K, cout, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
-                   out_scale=0.125, out_zero_point=3)
-plan = amd.Bconv2dPlan(p)
-plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
+plan = amd.Bconv2dPlan(layer.params(amd, dst, 0.125, 3))
+plan.set_weights(w, mul, bias, thr)
 plan.set_option("engine", engine)
 if tile != "auto":
     if engine == "valu":

@@ -8,23 +8,23 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
-import oracle_lib as O  # noqa: E402
 import bench  # noqa: E402
+import synthetic_layers as SL  # noqa: E402
 
 amd = importlib.import_module("compute-engine_amd")
 dev = torch.device("cuda:0")
 B = int(os.environ.get("SWEEP_BATCH", "256"))
 steps = int(os.environ.get("SWEEP_STEPS", "10"))
 layers = [("L0_56x56x256", 56, 256)] + [(f"qn_{hw}x{hw}x{c}", hw, c) for hw, c in bench.QUICKNET]
-dsts = [("f32", amd.F32, O.DST_F32), ("i8", amd.I8, O.DST_I8), ("bp", amd.BITPACKED, O.DST_BITPACKED)]
+dsts = [("f32", amd.F32, SL.DST_F32), ("i8", amd.I8, SL.DST_I8), ("bp", amd.BITPACKED, SL.DST_BITPACKED)]
 tiles = ["4x16", "2x32", "2x16", "1x32", "1x16", "m256x256", "m256x128", "m512x64", "m128x256", "m128x128", "m256x64", "m128x64",
          "d256x256", "d256x128", "d512x64", "d128x256", "d128x128", "d256x64", "d128x64"]
 only = set(sys.argv[1:])
 for lname, hw, c in layers:
-    spec = O.ConvSpec(batch=B, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=c,
-                      padding=O.PADDING_SAME, pad_values=1)
+    spec = SL.Layer(batch=B, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=c,
+                    padding=SL.PADDING_SAME, pad_values=1)
     for dname, dst, od in dsts:
         if only and dname not in only and lname not in only:
             continue
@@ -34,15 +34,10 @@ for lname, hw, c in layers:
             if not mfma and dst == amd.BITPACKED and not tile.endswith("32"):
                 continue
             os.environ["LCE_SWEEP_TILE"] = tile
-            import synth
-            one = O.ConvSpec(batch=1, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
-                             channels_out=c, padding=O.PADDING_SAME, pad_values=1)
-            _, w, mul, bias = synth.conv_inputs(one, 3)
-            x = torch.from_numpy(synth.random_words(synth.rng(4), spec.input_shape(), c)).to(dev)
-            p = amd.ConvParams(B, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst,
-                               out_scale=0.125, out_zero_point=3)
-            plan = amd.Bconv2dPlan(p)
-            plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
+            w, mul, bias, thr = SL.weights(spec, 3)
+            x = torch.from_numpy(SL.activations(spec, 4)).to(dev)
+            plan = amd.Bconv2dPlan(spec.params(amd, dst, 0.125, 3))
+            plan.set_weights(w, mul, bias, thr)
             plan.set_option("engine", "direct" if direct else "mfma" if mfma else "valu")
             if not mfma:
                 plan.set_option("kernel", "tiled")

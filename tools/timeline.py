@@ -22,20 +22,19 @@ print(out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[
 # run_one ran in a child; repeat one launch here to read the symbol from THIS process
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 amd = importlib.import_module("compute-engine_amd")
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
-import oracle_lib as O  # noqa: E402
-import synth  # noqa: E402
+import synthetic_layers as SL  # noqa: E402
 
 hw, dname, engine, tile = int(sys.argv[1]), sys.argv[3], sys.argv[4], sys.argv[5]
 cin, cout = (int(v) for v in sys.argv[2].split("x"))
 dst = {"f32": amd.F32, "i8": amd.I8, "bp": amd.BITPACKED}[dname]
-one = O.ConvSpec(1, hw, hw, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1)
-_, w, mul, bias = synth.conv_inputs(one, 3)
 B = 256
-x = torch.from_numpy(synth.random_words(synth.rng(4), (B, hw, hw, (cin + 31) // 32), cin)).to("cuda:0")
-plan = amd.Bconv2dPlan(amd.ConvParams(B, hw, hw, cin, 3, 3, cout, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst))
-plan.set_weights(w, mul, bias, O.thresholds_converter(one, mul, bias))
+layer = SL.Layer(B, hw, hw, cin, 3, 3, cout, padding=SL.PADDING_SAME, pad_values=1)
+w, mul, bias, thr = SL.weights(layer, 3)
+x = torch.from_numpy(SL.activations(layer, 4)).to("cuda:0")
+plan = amd.Bconv2dPlan(layer.params(amd, dst))
+plan.set_weights(w, mul, bias, thr)
 plan.set_option("engine", engine)
 if tile != "auto":
     plan.set_option("tile", tile)
