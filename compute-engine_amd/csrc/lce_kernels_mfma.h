@@ -511,6 +511,44 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
       }
     }
+  } else if (DST == kDstInt8 && G.i8_wide && (((size_t)out) & 15) == 0) {
+    // int8, wide path: a pixel's WN*32 channels of this wave are contiguous bytes, so the WN
+    // tiles of a row block are transposed together ([32 rows][WN*32] floats of scratch) and a
+    // lane converts 16 consecutive channels into ONE 16-byte store: 2*WN lanes cover a row
+    // segment (WN = 4: a full 128-byte line) instead of 4-byte stores in 32-byte pieces.
+    constexpr int RW = WN * 32;                                  // floats per scratch row
+    constexpr int GPR = WN * 2, RPI = 64 / GPR;                  // 16-channel groups per row, rows per store instruction
+    float* scratch = (float*)(lds0 + wave * (WN * 4096));
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float x = med3(a_bt - acc[i][j][r], cminf, cmaxf);
+          scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
+        }
+      wave_lds_fence();
+      const int g = lane % GPR;
+      const int n = n0 + wn * RW + g * 16;
+#pragma unroll
+      for (int k = 0; k < 32 / RPI; ++k) {
+        const int row = lane / GPR + k * RPI;
+        const int m = m0 + (wm * WM + i) * 32 + row;
+        const f32x4* src = (const f32x4*)(scratch + row * RW + g * 16);
+        u32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 y = src[q];
+          pk[q] = pack4_u8(round_sat_i8(y[0]), round_sat_i8(y[1]), round_sat_i8(y[2]), round_sat_i8(y[3]));
+        }
+        if (m < m_end && n < A.N) {                                // N % 16 == 0: whole group or nothing
+          *(u32x4*)((int8_t*)out + (size_t)m * (size_t)A.N + (size_t)n) = pk;
+        }
+      }
+      wave_lds_fence();
+    }
   } else {
     float* scratch = (float*)(lds0 + wave * 4096);              // [32 rows][32 channels]
     const int trow = lane >> 3, tcol = (lane & 7) * 4;          // after the transpose

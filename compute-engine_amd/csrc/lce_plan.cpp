@@ -327,7 +327,13 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
 // better there.
 bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out) {
   const int ohow = p.out_h * p.out_w;
-  const int bn = p.d.channels_out > 64 ? 128 : 64;
+  // int8 rows are bytes: with 256 channels per block a wave's 16-byte stores fill whole 128-byte
+  // lines (measured on L0: 128x256 0.268 ms vs 256x128 0.274 ms; float output prefers the latter)
+  // -- but only on long launches (>= 8 rounds of 128-pixel blocks); on short ones more, smaller
+  // blocks win (28x28x256: 128x128 0.082 ms vs 128x256 0.089; 14x14, 7x7 likewise)
+  const bool wide_i8 = p.d.dst_type == LCE_HIP_I8 && p.d.channels_out > 128 &&
+                       (int64_t)p.d.batch * ceil_div(ohow, 128) >= 4096;
+  const int bn = wide_i8 ? 256 : p.d.channels_out > 64 ? 128 : 64;
   struct Cand { const MfmaCfg* c; double padded; int64_t blocks; };
   Cand cand[2];
   int n = 0;
@@ -371,6 +377,13 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   G.a_bt = (float)p.backtransform_add;
   G.cmin = (float)p.clamp_min;
   G.cmax = (float)p.clamp_max;
+  // the wide int8 epilogue transposes WN tiles at once: only where the block's LDS allocation
+  // already covers waves * WN * 4 KiB (it must not cost a resident block)
+  {
+    const int lds = p.use_direct ? p.mfma.direct_lds_bytes(p.halo_bytes) : p.mfma.lds_bytes();
+    G.i8_wide = (p.d.dst_type == LCE_HIP_I8 && p.d.channels_out % 16 == 0 &&
+                 (p.mfma.threads() / 64) * p.mfma.wn * 4096 <= lds) ? 1 : 0;
+  }
   if (p.use_direct) {
     G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;
     G.halo_bytes = p.halo_bytes; G.QG = (G.CPW + 3) / 4;

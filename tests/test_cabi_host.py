@@ -166,7 +166,8 @@ def test_empty_batch_is_legal_and_a_no_op():
 
 @pytest.mark.parametrize("hw,c,dst,want", [
     (56, 256, "F32", "bconv2d_mfma_direct<f32,256x128>"),          # BASELINE L0
-    (56, 256, "I8", "bconv2d_mfma_direct<i8,256x128>"),
+    (56, 256, "I8", "bconv2d_mfma_direct<i8,128x256>"),           # bytes: 256 channels = whole 128-byte lines
+    (14, 256, "I8", "bconv2d_mfma_direct<i8,256x128>"),           # ... but not on short launches
     (56, 256, "BITPACKED", "bconv2d_mfma_direct<bitpacked,256x128>"),
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
     (28, 128, "F32", "bconv2d_mfma_direct<f32,128x128>"),

@@ -295,6 +295,24 @@ def test_mfma_direct_variant_small_images_share_a_tile():
                       engine="direct", max_batch=4)   # launches of 4, 4, 1 images
 
 
+def test_mfma_int8_wide_epilogue():
+    """int8 output with 16-byte row stores (WN tiles transposed together): taken when
+    channels_out % 16 == 0 and the block's LDS already holds waves*WN*4 KiB of scratch; ragged
+    channel tiles (48 of 128) and ragged pixel tiles included; both variants."""
+    scale, zp = synth.int8_quant_params(77)
+    for spec, engine, tile in [
+        (O.ConvSpec(2, 20, 20, 256, 3, 3, 48, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU), "direct", (128, 128)),
+        (O.ConvSpec(2, 20, 20, 256, 3, 3, 272, padding=O.PADDING_SAME, pad_values=1), "direct", (128, 256)),
+        (O.ConvSpec(3, 9, 11, 64, 3, 3, 80), "mfma", (128, 256)),
+        (O.ConvSpec(3, 9, 11, 64, 1, 1, 64), "mfma", (256, 128)),
+    ]:
+        x, w, mul, bias = synth.conv_inputs(spec, 78 + spec.channels_out, negative_mul_fraction=0.2)
+        want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
+        got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp,
+                              tile=tile, engine=engine)
+        assert np.array_equal(got, want), name
+
+
 def test_mfma_engine_refuses_grouped():
     spec = O.ConvSpec(1, 6, 6, 128, 3, 3, 64, groups=2)
     x, w, mul, bias = synth.conv_inputs(spec, 1)
