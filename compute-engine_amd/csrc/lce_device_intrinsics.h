@@ -173,6 +173,21 @@ LCE_DEVICE void interleave_mfma_ldsread() {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
   }
 }
+// Issue pattern of a steady K-step: MFMA, [one LDS-DMA], [share of the LDS reads], MFMA, ...
+// (masks: 0x8 MFMA, 0x10 vector memory, 0x100 LDS read).  Scalar / vector ALU instructions are
+// left to the scheduler; the ones an address depends on end up in front of that access.
+template <int M, int NMFMA, int NDS, int NVMEM>
+LCE_DEVICE void interleave_step_from() {
+  if constexpr (M < NMFMA) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (M < NVMEM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    constexpr int ds = (NDS * (M + 1)) / NMFMA - (NDS * M) / NMFMA;   // NDS reads spread over the MFMAs
+    if constexpr (ds > 0) __builtin_amdgcn_sched_group_barrier(0x100, ds, 0);
+    interleave_step_from<M + 1, NMFMA, NDS, NVMEM>();
+  }
+}
+template <int NMFMA, int NDS, int NVMEM>
+LCE_DEVICE void interleave_step() { interleave_step_from<0, NMFMA, NDS, NVMEM>(); }
 // Streaming (non-temporal) 16-byte store for outputs that are written once and not re-read
 // by this kernel: keeps the L2 for the operands that ARE re-read.
 LCE_DEVICE void store_streaming(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }

@@ -327,13 +327,12 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
 // better there.
 bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out) {
   const int ohow = p.out_h * p.out_w;
-  // int8 rows are bytes: with 256 channels per block a wave's 16-byte stores fill whole 128-byte
-  // lines (measured on L0: 128x256 0.268 ms vs 256x128 0.274 ms; float output prefers the latter)
-  // -- but only on long launches (>= 8 rounds of 128-pixel blocks); on short ones more, smaller
-  // blocks win (28x28x256: 128x128 0.082 ms vs 128x256 0.089; 14x14, 7x7 likewise)
-  const bool wide_i8 = p.d.dst_type == LCE_HIP_I8 && p.d.channels_out > 128 &&
-                       (int64_t)p.d.batch * ceil_div(ohow, 128) >= 4096;
-  const int bn = wide_i8 ? 256 : p.d.channels_out > 64 ? 128 : 64;
+  // 256 channels per block (4 waves of 2x4 tiles) on long launches (>= 8 rounds of 128-pixel
+  // blocks): int8 rows then fill whole 128-byte lines (L0 0.283 -> 0.268 ms) and, with the
+  // MFMA-first K-step, float / bitpacked output gains 2-3 % over 256x128 (0.2955 -> 0.288 ms).  On
+  // short launches more, smaller blocks win (28x28x256 int8: 128x128 0.082 ms vs 128x256 0.089).
+  const bool wide = p.d.channels_out > 128 && (int64_t)p.d.batch * ceil_div(ohow, 128) >= 4096;
+  const int bn = wide ? 256 : p.d.channels_out > 64 ? 128 : 64;
   struct Cand { const MfmaCfg* c; double padded; int64_t blocks; };
   Cand cand[2];
   int n = 0;

@@ -160,6 +160,7 @@ template <int N> inline void wait_vmcnt() {     // retire the oldest pieces unti
 inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
 inline void pin(f32x16&) {}
 template <int N> inline void interleave_mfma_ldsread() {}
+template <int NMFMA, int NDS, int NVMEM> inline void interleave_step() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
 inline void store_streaming(u32x4* p, u32x4 v) { *p = v; }
 inline f32x4 load_streaming(const f32x4* p) { return *p; }

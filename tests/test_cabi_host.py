@@ -101,7 +101,7 @@ def test_kernel_selection_is_host_side_and_named():
     _, filt, mul, bias = synth.conv_inputs(O.ConvSpec(1, 3, 3, 256, 3, 3, 256), 1)
     plan = amd.Bconv2dPlan(_params(spec, amd.F32))
     plan.set_weights(filt, mul, bias)
-    assert plan.kernel_name() == "bconv2d_mfma_direct<f32,256x128>"   # auto: matrix cores, LDS-halo variant
+    assert plan.kernel_name() == "bconv2d_mfma_direct<f32,128x256>"   # auto: matrix cores, LDS-halo variant
     plan.set_option("engine", "valu")
     assert plan.kernel_name().startswith("bconv2d_tiled<f32,TM=")     # xor-popcount engine
     plan.set_option("kernel", "general")
@@ -165,10 +165,10 @@ def test_empty_batch_is_legal_and_a_no_op():
 
 
 @pytest.mark.parametrize("hw,c,dst,want", [
-    (56, 256, "F32", "bconv2d_mfma_direct<f32,256x128>"),          # BASELINE L0
+    (56, 256, "F32", "bconv2d_mfma_direct<f32,128x256>"),          # BASELINE L0: long launch, 256 channels per block
     (56, 256, "I8", "bconv2d_mfma_direct<i8,128x256>"),           # bytes: 256 channels = whole 128-byte lines
     (14, 256, "I8", "bconv2d_mfma_direct<i8,256x128>"),           # ... but not on short launches
-    (56, 256, "BITPACKED", "bconv2d_mfma_direct<bitpacked,256x128>"),
+    (56, 256, "BITPACKED", "bconv2d_mfma_direct<bitpacked,128x256>"),
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
     (28, 128, "F32", "bconv2d_mfma_direct<f32,128x128>"),
     (14, 256, "F32", "bconv2d_mfma_direct<f32,256x128>"),
