@@ -159,10 +159,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // WGM x WGN waves per block, each owning WM x WN MFMA tiles of 32x32
   constexpr int NWAVES = WGM * WGN;
   constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
-  // K-step order, from same-box A/Bs on L0: waves with 8 MFMAs per step (2x4 tiles, two waves per
-  // SIMD) gain 2-3.5 % when the MFMAs lead and DMA / fragment reads are woven between them; waves
-  // with 4 MFMAs (2x2 tiles, four waves per SIMD) lose 2 % that way and keep the loads in front.
-  constexpr bool kMfmaFirst = WM * WN >= 8;
   // DIRECT: the A operand is not staged per K-step at all (see "direct variant" below)
   constexpr int A_BYTES = DIRECT ? 0 : BM * 32, B_BYTES = BN * 32, STAGE = A_BYTES + B_BYTES;
   // LDS image of a stage: A as [k-half][row][16 B], B as [k-half][channel][16 B]; a wave
@@ -260,18 +256,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const uint32_t b_step = (uint32_t)G.Npad * 32u;
   auto fill = [&](int stage) {
     uint8_t* base = lds + stage * STAGE;
-    // The counted vmcnt waits assume every wave issues exactly NP pieces per fill -- or none
-    // at all.  So a surplus slot (fewer pieces than waves) may only be skipped when that leaves
-    // the wave with nothing: the direct variant with one B slot.  Otherwise it re-copies an
-    // earlier piece (same bytes to the same address).
-    // (only for the configurations that keep the loads-first K-step below: the branch splits the
-    // step's scheduling region, which the MFMA-first order needs whole)
-    constexpr bool kSkipSurplus = !kMfmaFirst && DIRECT && NPB == 1 && B_PIECES < NWAVES;
+    // Every wave issues exactly NP pieces per fill (the counted vmcnt waits rely on it); when a
+    // block has fewer pieces than waves, a surplus slot re-copies an earlier piece (same bytes to
+    // the same address) -- skipping it would need a branch, and a branch would split the K-step's
+    // scheduling region.
 #pragma unroll
     for (int i = 0; i < NPA; ++i) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
 #pragma unroll
-    for (int i = 0; i < NPB; ++i)
-      if (!kSkipSurplus || wave < B_PIECES) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
+    for (int i = 0; i < NPB; ++i) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
     // cursor to the next K-step, branch-free (selects, not jumps: a branch here would split the
     // K-step's basic block and with it the scheduling region the MFMA interleave needs)
     b_off += b_step;
@@ -417,10 +409,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       wait_vmcnt<NP * (STAGES - 2)>();          // own pieces of step ks+1 have landed
       block_barrier_keep_vm();
       LCE_TL(1);
-      if constexpr (!kMfmaFirst) {
-        fill(ks % STAGES);                       // step ks+STAGES into the stage just vacated
-        load_frags(ks + 1, af_next, bf_next);
-      }
       LCE_TL(2);
     } else {
       wait_vmcnt<0>();                           // tail: fewer fills in flight than the exact count
@@ -432,7 +420,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     for (int i = 0; i < WM; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[i][j] = mfma_fp4_32x32x64(af[i], bf[j], acc[i][j]);
-    if constexpr (decltype(steady)::value && kMfmaFirst) {
+    if constexpr (decltype(steady)::value) {
       // everything that prepares LATER steps comes after the MFMAs in program order and is woven
       // between them: the wave's matrix work starts right behind the barrier, and the expensive
       // issues (LDS-DMA, ds_read) overlap the MFMAs' execution instead of preceding it
