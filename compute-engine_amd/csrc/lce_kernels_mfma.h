@@ -378,9 +378,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * 32u;
   const uint32_t c_step_fy = (uint32_t)((A.DH * G.Wp - A.KW * A.DW) * G.PS);
 
-  // load_frags is always called with consecutive ks (0, 1, 2, ...), once each
-  auto load_frags = [&](int ks, u32x4 (&af)[WM], u32x4 (&bf)[WN]) {
-    const uint8_t* base = lds + (ks % STAGES) * STAGE;
+  // load_frags is always called for consecutive K-steps (0, 1, 2, ...), once each; `stage` = ks % STAGES
+  auto load_frags = [&](int stage, u32x4 (&af)[WM], u32x4 (&bf)[WN]) {
+    const uint8_t* base = lds + stage * STAGE;
     if constexpr (DIRECT) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) af[i] = *(const u32x4*)(lds0 + (a_base[i] + a_cur));
@@ -402,8 +402,10 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   };
   // One K-step.  `steady` (compile-time) = the ring is full: a refill is due and exactly
   // STAGES-1 younger fills are in flight, so the wait count is exact and nothing branches.
-  auto step = [&](auto steady, int ks, u32x4 (&af)[WM], u32x4 (&bf)[WN], u32x4 (&af_next)[WM],
-                  u32x4 (&bf_next)[WN]) {
+  // fs = ks % STAGES (the stage this step vacates and refills), rs = (ks + 1) % STAGES (the stage
+  // the next step's fragments are read from): compile-time constants in the unrolled steady loop
+  auto step = [&](auto steady, int ks, int fs, int rs, u32x4 (&af)[WM], u32x4 (&bf)[WN], u32x4 (&af_next)[WM],
+                  u32x4 (&bf_next)[WN]) LCE_LAMBDA_INLINE {
     if constexpr (decltype(steady)::value) {
       LCE_TL(0);
       wait_vmcnt<NP * (STAGES - 2)>();          // own pieces of step ks+1 have landed
@@ -413,8 +415,8 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     } else {
       wait_vmcnt<0>();                           // tail: fewer fills in flight than the exact count
       block_barrier_keep_vm();
-      if (ks + STAGES < KS) fill(ks % STAGES);
-      if (ks + 1 < KS) load_frags(ks + 1, af_next, bf_next);
+      if (ks + STAGES < KS) fill(fs);
+      if (ks + 1 < KS) load_frags(rs, af_next, bf_next);
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -424,8 +426,8 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       // everything that prepares LATER steps comes after the MFMAs in program order and is woven
       // between them: the wave's matrix work starts right behind the barrier, and the expensive
       // issues (LDS-DMA, ds_read) overlap the MFMAs' execution instead of preceding it
-      fill(ks % STAGES);                         // step ks+STAGES into the stage just vacated
-      load_frags(ks + 1, af_next, bf_next);
+      fill(fs);                                  // step ks+STAGES into the stage just vacated
+      load_frags(rs, af_next, bf_next);
       interleave_step<WM * WN, WM + WN, NP>();
     } else {
       interleave_mfma_ldsread<WM + WN>();        // tail: only fragment reads ride between the MFMAs
@@ -441,15 +443,26 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   else wait_vmcnt<0>();
   block_barrier_keep_vm();
   u32x4 af0[WM], bf0[WN], af1[WM], bf1[WN];
-  load_frags(0, af0, bf0);
+  load_frags(0, af0, bf0);   // stage 0 = K-step 0
+  // Steady loop, unrolled over one full cycle of (fragment-set parity) x (ring position) so that
+  // every stage index is a literal -- no `% STAGES` arithmetic in the K-step.
+  constexpr int UNROLL = (STAGES % 2 == 0) ? STAGES : 2 * STAGES;
   int ks = 0;
-  for (; ks + 1 + STAGES < KS; ks += 2) {       // both steps of the pair are steady
-    step(StepSteady{}, ks, af0, bf0, af1, bf1);
-    step(StepSteady{}, ks + 1, af1, bf1, af0, bf0);
+  auto steady_step = [&](auto uc) LCE_LAMBDA_INLINE {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u < UNROLL) {
+      if constexpr (u % 2 == 0) step(StepSteady{}, ks + u, u % STAGES, (u + 1) % STAGES, af0, bf0, af1, bf1);
+      else step(StepSteady{}, ks + u, u % STAGES, (u + 1) % STAGES, af1, bf1, af0, bf0);
+    }
+  };
+  for (; ks + UNROLL - 1 + STAGES < KS; ks += UNROLL) {   // all UNROLL steps are steady
+    steady_step(IntC<0>{}); steady_step(IntC<1>{}); steady_step(IntC<2>{}); steady_step(IntC<3>{});
+    steady_step(IntC<4>{}); steady_step(IntC<5>{}); steady_step(IntC<6>{}); steady_step(IntC<7>{});
   }
-  for (; ks < KS; ks += 2) {
-    step(StepTail{}, ks, af0, bf0, af1, bf1);
-    if (ks + 1 < KS) step(StepTail{}, ks + 1, af1, bf1, af0, bf0);
+  static_assert(UNROLL <= 8, "steady_step calls above");
+  for (; ks < KS; ks += 2) {                              // ks stays even: fragment set 0 first
+    step(StepTail{}, ks, ks % STAGES, (ks + 1) % STAGES, af0, bf0, af1, bf1);
+    if (ks + 1 < KS) step(StepTail{}, ks + 1, (ks + 1) % STAGES, (ks + 2) % STAGES, af1, bf1, af0, bf0);
   }
 
   // ------------------------------ fused output transform ------------------------------
