@@ -80,6 +80,7 @@ struct MfmaArgs {
   int32_t IPT;             // whole images per tile (> 1 only when OH*OW <= BM / 2; then TPI == 1)
   int32_t B;               // images of this launch
   int32_t HPIX;            // halo pixels per image = halo_rows * Wp
+  int32_t f32_wide;        // float epilogue may transpose the WN tiles of a row block together
   int32_t i8_wide;         // int8 epilogue may use WN*4 KiB of LDS scratch per wave (16-byte row stores)
   FastDiv div_tpi, div_qg, div_ohow, div_hpix;
 };

@@ -527,6 +527,36 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
       }
     }
+  } else if (DST == kDstFloat && !CORR && G.f32_wide && (((size_t)out) & 15) == 0) {
+    // float, wide path: the WN tiles of a 32-row block are transposed together
+    // ([32 rows][WN*32] floats of scratch), so there is one LDS fence pair per row block instead of
+    // one per tile, and a store instruction covers whole row segments of WN*128 bytes.
+    constexpr int RW = WN * 32;                                  // floats per scratch row
+    constexpr int LPR = RW / 4, RPI = 64 / LPR;                  // lanes per row (16 bytes each), rows per store instruction
+    float* scratch = (float*)(lds0 + wave * (WN * 4096));
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const float x = med3(a_bt - acc[i][j][r], cminf, cmaxf);
+          scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
+        }
+      wave_lds_fence();
+      const int g = lane % LPR;
+      const int n = n0 + wn * RW + g * 4;
+#pragma unroll
+      for (int k = 0; k < 32 / RPI; ++k) {
+        const int row = lane / LPR + k * RPI;
+        const int m = m0 + (wm * WM + i) * 32 + row;
+        const f32x4 y = *(const f32x4*)(scratch + row * RW + g * 4);
+        if (m < m_end && n < A.N)                                  // N % 4 == 0: whole group or nothing
+          store_streaming((f32x4*)((float*)out + (size_t)m * (size_t)A.N + (size_t)n), y);
+      }
+      wave_lds_fence();
+    }
   } else if (DST == kDstInt8 && G.i8_wide && (((size_t)out) & 15) == 0) {
     // int8, wide path: a pixel's WN*32 channels of this wave are contiguous bytes, so the WN
     // tiles of a row block are transposed together ([32 rows][WN*32] floats of scratch) and a

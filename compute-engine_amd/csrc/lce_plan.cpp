@@ -380,8 +380,12 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   // already covers waves * WN * 4 KiB (it must not cost a resident block)
   {
     const int lds = p.use_direct ? p.mfma.direct_lds_bytes(p.halo_bytes) : p.mfma.lds_bytes();
-    G.i8_wide = (p.d.dst_type == LCE_HIP_I8 && p.d.channels_out % 16 == 0 &&
-                 (p.mfma.threads() / 64) * p.mfma.wn * 4096 <= lds) ? 1 : 0;
+    const bool room = (p.mfma.threads() / 64) * p.mfma.wn * 4096 <= lds;
+    G.i8_wide = (p.d.dst_type == LCE_HIP_I8 && p.d.channels_out % 16 == 0 && room) ? 1 : 0;
+    // float: same joint transpose (one LDS fence pair per 32-row block instead of one per tile);
+    // not with the SAME-zero correction variant, whose epilogue is per tile
+    G.f32_wide = (p.d.dst_type == LCE_HIP_F32 && p.d.channels_out % 4 == 0 && room &&
+                  p.zero_pad_mode != kZeroPadCorrection) ? 1 : 0;
   }
   if (p.use_direct) {
     G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;
