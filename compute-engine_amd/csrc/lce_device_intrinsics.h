@@ -123,6 +123,12 @@ LCE_DEVICE f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
   i32x8 vb = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
+LCE_DEVICE f32x16 f32x16_fill(float v) {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = v;
+  return z;
+}
 LCE_DEVICE f32x16 f32x16_zero() {
   f32x16 z;
 #pragma unroll

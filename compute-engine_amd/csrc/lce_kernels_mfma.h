@@ -35,7 +35,8 @@
 // arrive by asynchronous LDS-DMA (buffer_load_dwordx4 ... lds, no VGPR round trip) into a
 // 3- or 4-stage ring, fragments are read with ds_read_b128, and the output transform
 // (output_transform.h:93-168) is fused on the fp32 accumulators:
-//         2*accum = K_bt - d  ->  clamp -> * mul + bias   (two roundings)
+//         2*accum (= K_bt - <a,w>, accumulated directly: weights negated, start value K_bt)
+//                 ->  clamp -> * mul + bias   (two roundings)
 #pragma once
 #include <lce_device_intrinsics.h>
 #include "lce_kernel_args.h"
@@ -129,7 +130,8 @@ expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaA
 //   xp : FP4 workspace, 16-byte element (plane cc, pixel (b, yp, xp)) at
 //        (cc * NPIX + (b*Hp + yp)*Wp + xp) * 16 bytes; K-step kc uses planes 2kc, 2kc+1
 //   wq : FP4 weights [KS][2 halves][Npad][16 bytes]
-//   thrf : bitpacked output: per-channel float t with  bit = (d < t)   (= accum > threshold)
+//   wq : ... holding the NEGATED weights: the accumulators start at K_bt and end as 2 * accum
+//   thrf : bitpacked output: per-channel float t = 2 * threshold with  bit = (2 * accum > t)
 // ---------------------------------------------------------------------------------
 #ifdef LCE_TIMELINE
 // Profiling aid (tools/timeline.py builds the library with -DLCE_TIMELINE; never defined in the
@@ -241,7 +243,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = f32x16_zero();
+    for (int j = 0; j < WN; ++j) acc[i][j] = f32x16_fill(G.a_bt);   // + <a, -w> = K_bt - <a, w> = 2 * accum
 
   const int KS = A.KH * A.KW * G.KCH;
 
@@ -473,7 +475,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   //     channels of one pixel and 8 lanes write a full 128-byte line with 16-byte stores;
   //   * bitpacked: the 32 channel bits of a pixel are one v_cmp + ballot; the words are
   //     gathered so that lane p owns pixel row p and stores its WN words at once.
-  const float a_bt = G.a_bt, cminf = G.cmin, cmaxf = G.cmax;
+  const float cminf = G.cmin, cmaxf = G.cmax;
   float mj[WN], bj[WN], tj[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
@@ -490,14 +492,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
       for (int j = 0; j < WN; ++j) words[j] = 0u;
       // register r holds pixel rows q (lanes 0-31) and q + 4 (lanes 32-63) of the tile,
-      // q = (r & 3) + 8 * (r >> 2);  accum > threshold <=> d < K_bt - 2*threshold
+      // q = (r & 3) + 8 * (r >> 2);  accum > threshold <=> 2*accum > 2*threshold
       // (output_transform.h:160-168).  v_writelane drops each 32-channel word into the lane
       // that will store it.
       auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
         constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          const unsigned long long bits = wave_ballot(acc[i][j][r] < tj[j]);
+          const unsigned long long bits = wave_ballot(acc[i][j][r] > tj[j]);
           words[j] = write_lane<q>((uint32_t)bits, words[j]);              // lane q     <- row q
           words[j] = write_lane<q + 4>((uint32_t)(bits >> 32), words[j]);  // lane q + 4 <- row q + 4
         }
@@ -541,7 +543,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float x = med3(a_bt - acc[i][j][r], cminf, cmaxf);
+          const float x = med3(acc[i][j][r], cminf, cmaxf);
           scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
         }
       wave_lds_fence();
@@ -572,7 +574,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float x = med3(a_bt - acc[i][j][r], cminf, cmaxf);
+          const float x = med3(acc[i][j][r], cminf, cmaxf);
           scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
         }
       wave_lds_fence();
@@ -607,7 +609,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float x = med3(a_bt - acc[i][j][r], cminf, cmaxf);  // = float(clamp(accum << 1))
+          const float x = med3(acc[i][j][r], cminf, cmaxf);  // = float(clamp(accum << 1))
           scratch[row * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
         }
         wave_lds_fence();

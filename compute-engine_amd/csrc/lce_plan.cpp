@@ -249,7 +249,10 @@ static void pack_for_mfma(HostPlan& p) {
     for (int t = 0; t < taps; ++t)
       for (int c = 0; c < d.channels_in; ++c) {
         const uint32_t w = p.filter[((size_t)oc * taps + t) * p.cwg + c / 32];
-        const uint8_t nib = ((w >> (c % 32)) & 1u) ? 0xA : 0x2;  // bit 1 = -1, bit 0 = +1
+        // the NEGATED weight: bit 1 (-1) -> +1 = 0x2, bit 0 (+1) -> -1 = 0xA.  The kernel starts its
+        // accumulators at K_bt, so they hold K_bt - <a, w> = 2 * popcount-accumulator directly, the
+        // value the output transform clamps (output_transform.h:62-91,105) -- no subtraction later.
+        const uint8_t nib = ((w >> (c % 32)) & 1u) ? 0x2 : 0xA;
         const int ks = t * kch + c / 64, j = c % 64, half = j / 32, jj = j % 32;
         uint8_t& byte = p.wq[(((size_t)ks * 2 + half) * p.npad + oc) * 16 + jj / 2];
         byte |= (uint8_t)(nib << (4 * (jj & 1)));
@@ -258,13 +261,13 @@ static void pack_for_mfma(HostPlan& p) {
   p.bias_q.assign(p.npad, 0.0f);
   std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
   std::copy(p.bias.begin(), p.bias.end(), p.bias_q.begin());
-  // bit = (accum > thr)  <=>  d < K_bt - 2*thr; clamp so the float is exact, keep the
-  // always / never cases (|d| <= K_bt)
+  // bit = (accum > thr)  <=>  2*accum > 2*thr, and the kernel's accumulator IS 2*accum (an integer
+  // in [0, 2*K_bt]); clamp so the float is exact, keep the always / never cases
   const int64_t a = p.backtransform_add;
-  p.thr_q.assign(p.npad, -(float)(a + 1));  // padded channels: never
+  p.thr_q.assign(p.npad, (float)(2 * a + 2));  // padded channels: never
   for (size_t i = 0; i < p.thresholds.size(); ++i) {
-    int64_t t = a - 2 * (int64_t)p.thresholds[i];
-    t = std::max<int64_t>(-(a + 1), std::min<int64_t>(a + 1, t));
+    int64_t t = 2 * (int64_t)p.thresholds[i];
+    t = std::max<int64_t>(-1, std::min<int64_t>(2 * a + 2, t));
     p.thr_q[i] = (float)t;
   }
 }

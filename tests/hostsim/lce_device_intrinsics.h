@@ -134,6 +134,7 @@ inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
   g_ctx.bar->arrive_and_wait();
   return c;
 }
+inline f32x16 f32x16_fill(float v) { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = v; return z; }
 inline f32x16 f32x16_zero() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.0f; return z; }
 inline uint8_t* lds_base() { return g_ctx.lds; }
 // The simulated LDS-DMA is as asynchronous as the hardware allows, in the most hostile legal
