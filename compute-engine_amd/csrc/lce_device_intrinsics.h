@@ -57,14 +57,30 @@ LCE_DEVICE uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 LCE_DEVICE int popc(uint32_t x) { return __popc(x); }
 LCE_DEVICE bool wave_any(bool p) { return __ballot(p) != 0ull; }
 LCE_DEVICE unsigned long long wave_ballot(bool p) { return __ballot(p); }
-// v_writelane_b32: returns `old` with lane `lane_index` (a compile-time constant here)
-// replaced by the wave-uniform `value`.
+// v_writelane_b32: returns `old` with lane LANE (a compile-time constant) replaced by the
+// wave-uniform `value`.  HAZARD: an SGPR written by a VALU compare must not be read by
+// v_writelane for 4 wait states, and hipcc pads nothing inside or in front of inline asm (without
+// the padding lanes came back stale on gfx950).  write_lane() pads itself; write_lane_settled()
+// does not and may only take values that went through settle_ballots() after the compares.
 template <int LANE>
 LCE_DEVICE uint32_t write_lane(uint32_t value, uint32_t old) {
-  // s_nop: the SGPR holding `value` was just written by a VALU compare; hipcc does not pad
-  // hazards inside or in front of inline asm (without it lanes came back stale on gfx950).
   asm("s_nop 4\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
   return old;
+}
+template <int LANE>
+LCE_DEVICE uint32_t write_lane_settled(uint32_t value, uint32_t old) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
+  return old;
+}
+// One padded point for a group of ballot results: the "+s" operands order every compare in front
+// of it and every write_lane_settled() of these values behind it.
+template <int N>
+LCE_DEVICE void settle_ballots(unsigned long long (&b)[N]) {
+  static_assert(N >= 1 && N <= 4, "one operand list per N below");
+  if constexpr (N == 1) asm("s_nop 4" : "+s"(b[0]));
+  else if constexpr (N == 2) asm("s_nop 4" : "+s"(b[0]), "+s"(b[1]));
+  else if constexpr (N == 3) asm("s_nop 4" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]));
+  else asm("s_nop 4" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]), "+s"(b[3]));
 }
 LCE_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
 

@@ -497,11 +497,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       // that will store it.
       auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
         constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
+        unsigned long long bits[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bits[j] = wave_ballot(acc[i][j][r] > tj[j]);
+        settle_ballots(bits);                    // ONE hazard pad for the WN compares, not one per v_writelane
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-          const unsigned long long bits = wave_ballot(acc[i][j][r] > tj[j]);
-          words[j] = write_lane<q>((uint32_t)bits, words[j]);              // lane q     <- row q
-          words[j] = write_lane<q + 4>((uint32_t)(bits >> 32), words[j]);  // lane q + 4 <- row q + 4
+          words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);              // lane q     <- row q
+          words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);  // lane q + 4 <- row q + 4
         }
       };
       gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
