@@ -161,11 +161,14 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
                                            float* bias, int32_t* clamp_min, int32_t* clamp_max);
 
 /* Tuning/testing knobs (defaults are all "auto"):
- *   "engine" = "auto" | "valu" (v_xor + v_bcnt popcount kernels) | "mfma" (FP4 matrix cores);
+ *   "engine" = "auto" | "valu" (v_xor + v_bcnt popcount kernels) | "mfma" (FP4 matrix cores, FP4
+ *              workspace + GEMM whose tiles span images) | "direct" (FP4 matrix cores, each block
+ *              expands its own input halo into LDS; what "auto" picks whenever it fits);
  *   "kernel" = "auto" | "tiled" | "general"                        (valu engine);
  *   "tile"   = "auto" | valu lane tile "4x16"|"2x32"|"2x16"|"1x32"|"1x16"
- *                     | mfma block tile "256x256"|"256x128"|"512x64"|"128x256"|"128x128"|"256x64"|"128x64";
- *   "phase"  = "all" | "expand" | "gemm"   (mfma engine, profiling aid: run one of its two kernels). */
+ *                     | matrix-core block tile "256x256"|"256x128"|"512x64"|"128x256"|"128x128"|"256x64"|"128x64"
+ *                       (pixels x channels; with engine = mfma or direct);
+ *   "phase"  = "all" | "expand" | "gemm"   (engine = mfma, profiling aid: run one of its two kernels). */
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key,
                                                const char* value);
 /* Name of the kernel variant the next run will launch (static string owned by the plan). */
