@@ -545,3 +545,52 @@ def test_batch_larger_than_one_buffer_resource(engine):
     # every image equals the run of its source image
     ok = (out[:B] == ref8[torch.from_numpy(idx).to(DEV)]).flatten(1).all(1)
     assert bool(ok.all()), "first differing image: %d (%s)" % (int((~ok).nonzero()[0]), plan.kernel_name())
+
+
+# ------------------------------------------------------------------------------------ randomized specs
+
+def _random_spec(g):
+    """A legal LceBconv2d configuration drawn at random (sizes the oracle finishes instantly)."""
+    groups = int(g.choice([1, 1, 1, 2, 4]))
+    cin = int(g.choice([32, 64, 96, 128, 160, 256, 320])) * groups if groups > 1 else int(g.choice([3, 20, 32, 64, 70, 96, 128, 192, 256, 300, 512]))
+    cout = int(g.choice([1, 7, 16, 33, 40, 64, 100, 128, 136, 256])) * (groups if groups > 1 else 1)
+    kh, kw = int(g.integers(1, 6)), int(g.integers(1, 6))
+    sh, sw = int(g.integers(1, 4)), int(g.integers(1, 4))
+    dh, dw = int(g.integers(1, 4)), int(g.integers(1, 4))
+    pad = str(g.choice(["VALID", "SAME", "ONE"]))
+    h = int(g.integers((kh - 1) * dh + 1, (kh - 1) * dh + 24))
+    w = int(g.integers((kw - 1) * dw + 1, (kw - 1) * dw + 24))
+    b = int(g.integers(1, 7))
+    act = int(g.choice([O.ACT_NONE, O.ACT_RELU, O.ACT_RELU_N1_TO_1, O.ACT_RELU6]))
+    sem = int(g.choice([O.SEM_REFERENCE, O.SEM_OPTIMIZED]))
+    padding, pv = PADS[pad]
+    if pad == "SAME":   # bconv2d.cc:188-200
+        if sem == O.SEM_REFERENCE and (cin // groups) % 2:
+            pad, (padding, pv) = "ONE", PADS["ONE"]
+        elif sem == O.SEM_OPTIMIZED:
+            act = O.ACT_NONE
+    return O.ConvSpec(b, h, w, cin, kh, kw, cout, groups, sh, sw, dh, dw, padding, pv, act, sem)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_specs(seed):
+    """Randomized sweep on top of the reference's grid: 12 x 12 seeded configurations (odd sizes,
+    5x5 filters, stride/dilation up to 3, ragged channel counts, groups) through the planner's own
+    choice of engine, all three output types, against the oracle."""
+    g = synth.rng(7000 + seed)
+    seen = set()
+    for k in range(12):
+        spec = _random_spec(g)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        names = _check_all_dst(spec, 9000 + seed * 100 + k, engine="auto")
+        seen.update(n.split("<")[0] for n in names)
+        if spec.groups == 1:   # both matrix-core variants, whatever the planner would have picked
+            for engine in ("mfma", "direct"):
+                try:
+                    names = _check_all_dst(spec, 9000 + seed * 100 + k, engine=engine)
+                except amd.LceHipError as e:
+                    assert engine == "direct" and "halo in LDS" in str(e), e
+                    continue
+                seen.update(n.split("<")[0] for n in names)
+    assert seen   # at least something ran; which kernels were hit varies by seed
