@@ -313,6 +313,37 @@ def test_mfma_int8_wide_epilogue():
         assert np.array_equal(got, want), name
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_mfma_random_specs(seed):
+    """A small randomized sweep through both matrix-core variants under the hostile LDS-DMA
+    emulation (the GPU suite runs the large one): odd sizes, 1..4-wide filters, strides and
+    dilations up to 3, ragged channel counts."""
+    g = synth.rng(5000 + seed)
+    done = 0
+    while done < 3:
+        cin = int(g.choice([3, 20, 32, 64, 70, 96, 160]))
+        cout = int(g.choice([1, 7, 16, 33, 40, 64]))
+        kh, kw = int(g.integers(1, 5)), int(g.integers(1, 5))
+        sh, sw, dh, dw = (int(v) for v in g.integers(1, 4, 4))
+        pad = str(g.choice(["VALID", "SAME", "ONE"]))
+        sem = int(g.choice([O.SEM_REFERENCE, O.SEM_OPTIMIZED]))
+        act = int(g.choice([O.ACT_NONE, O.ACT_RELU]))
+        padding, pv = PADS[pad]
+        if pad == "SAME":
+            if sem == O.SEM_REFERENCE and cin % 2:
+                padding, pv = PADS["ONE"]
+            elif sem == O.SEM_OPTIMIZED:
+                act = O.ACT_NONE
+        h = int(g.integers((kh - 1) * dh + 1, (kh - 1) * dh + 12))
+        w = int(g.integers((kw - 1) * dw + 1, (kw - 1) * dw + 12))
+        spec = O.ConvSpec(int(g.integers(1, 4)), h, w, cin, kh, kw, cout, 1, sh, sw, dh, dw, padding, pv, act, sem)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        for engine in ("mfma", "direct"):
+            _run_all_dst_mfma(spec, 6000 + seed * 10 + done, tile=(128, 64), engine=engine)
+        done += 1
+
+
 def test_mfma_engine_refuses_grouped():
     spec = O.ConvSpec(1, 6, 6, 128, 3, 3, 64, groups=2)
     x, w, mul, bias = synth.conv_inputs(spec, 1)
