@@ -467,19 +467,21 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       if (tiled_supports(p, p.tile_pref.tn)) chosen = p.tile_pref;
       else if (p.kernel_pref == 1) return "bconv2d: the requested tile cannot run this convolution";
     } else {
-      // One wave task = 64*TM pixels x TN channels.  Keep the per-lane accumulator tile
-      // as large as possible (fewer activation re-reads, better VALU density) while
-      // still producing enough tasks to fill 256 CUs x 4 SIMDs with several waves each.
-      const int64_t want_tasks = 256 * 4 * 4;
-      const TileShape order_f[] = {{4, 16}, {2, 32}, {2, 16}, {1, 32}, {1, 16}};
-      const TileShape order_b[] = {{2, 32}, {1, 32}};
+      // One wave task = 64*TM pixels x TN channels.  Measured on MI355X
+      // (profiles/r01/tile_sweep_v7.jsonl): one pixel per lane wins on every BASELINE layer --
+      // the bigger accumulator tiles (4x16, 2x32) run out of scalar registers for the weight
+      // words and spill -- with 32 channels per task on long launches (L0: 1x32 0.80 ms vs 4x16
+      // 0.90) and 16 on short ones (14x14x256: 1x16 0.060 vs 1x32 0.071; 7x7x512: 0.064 vs 0.085).
+      const TileShape order_f[] = {{1, 32}, {1, 16}, {2, 16}, {2, 32}, {4, 16}};
+      const TileShape order_b[] = {{1, 32}, {2, 32}};
       const TileShape* order = bp ? order_b : order_f;
       const int count = bp ? 2 : 5;
       for (int k = 0; k < count && chosen.tm == 0; ++k) {
         const TileShape t = order[k];
         if (!tiled_supports(p, t.tn)) continue;
         const int64_t tasks = ((pixels + 64 * t.tm - 1) / (64 * t.tm)) * ceil_div(d.channels_out, t.tn);
-        if (tasks >= want_tasks || k == count - 1) chosen = t;
+        if (!bp && k == 0 && tasks < 32768 && tiled_supports(p, 16)) continue;   // short launch: 1x16
+        chosen = t;
       }
       if (chosen.tm == 0) {  // nothing large enough: take the smallest supported tile
         for (int k = count - 1; k >= 0 && chosen.tm == 0; --k)
