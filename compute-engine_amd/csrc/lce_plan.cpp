@@ -468,7 +468,7 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       else if (p.kernel_pref == 1) return "bconv2d: the requested tile cannot run this convolution";
     } else {
       // One wave task = 64*TM pixels x TN channels.  Measured on MI355X
-      // (profiles/r01/tile_sweep_v7.jsonl): one pixel per lane wins on every BASELINE layer --
+      // (profiles/r01/tile_sweep_v8.jsonl): one pixel per lane wins on every BASELINE layer --
       // the bigger accumulator tiles (4x16, 2x32) run out of scalar registers for the weight
       // words and spill -- with 32 channels per task on long launches (L0: 1x32 0.80 ms vs 4x16
       // 0.90) and 16 on short ones (14x14x256: 1x16 0.060 vs 1x32 0.071; 7x7x512: 0.064 vs 0.085).

@@ -175,7 +175,7 @@ def test_empty_batch_is_legal_and_a_no_op():
     (7, 512, "F32", "bconv2d_mfma_direct<f32,128x128>"),           # two whole images per tile
 ])
 def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
-    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v7.jsonl); this pins what it
+    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v8.jsonl); this pins what it
     picks for the BASELINE.json layers at batch 256 so that a planner edit shows up as a diff."""
     p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=getattr(amd, dst))
     assert amd.Bconv2dPlan(p).kernel_name() == want
