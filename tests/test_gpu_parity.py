@@ -594,3 +594,13 @@ def test_random_specs(seed):
                     continue
                 seen.update(n.split("<")[0] for n in names)
     assert seen   # at least something ran; which kernels were hit varies by seed
+
+
+def test_wide_image_falls_back_to_the_workspace_variant():
+    """A 1500-pixel-wide image: even one tile's input halo (4 rows x 1502 pixels) is far beyond LDS,
+    so the planner must leave the direct variant; results still match the oracle."""
+    spec = O.ConvSpec(2, 5, 1500, 64, 3, 3, 40, padding=O.PADDING_SAME, pad_values=1)
+    names = _check_all_dst(spec, 4242, engine="auto")
+    assert all(n.startswith("bconv2d_mfma<") for n in names), names
+    with pytest.raises(amd.LceHipError, match="halo in LDS"):
+        _check_all_dst(spec, 4242, engine="direct")
