@@ -604,3 +604,37 @@ def test_wide_image_falls_back_to_the_workspace_variant():
     assert all(n.startswith("bconv2d_mfma<") for n in names), names
     with pytest.raises(amd.LceHipError, match="halo in LDS"):
         _check_all_dst(spec, 4242, engine="direct")
+
+
+def test_two_plans_on_two_streams_from_two_threads():
+    """Plans are independent (SURVEY 8b 'Threading': one OpData per node, no globals besides the static
+    registrations): two host threads drive two plans on two streams at the same time, many launches
+    each, and both get the oracle's answer."""
+    import threading
+    specs = [O.ConvSpec(8, 28, 28, 128, 3, 3, 128, padding=O.PADDING_SAME, pad_values=1),
+             O.ConvSpec(6, 14, 14, 256, 3, 3, 96, 1, 2, 2, 1, 1, O.PADDING_VALID, 0, O.ACT_RELU)]
+    work, errors = [], []
+    for k, spec in enumerate(specs):
+        x, w, mul, bias = synth.conv_inputs(spec, 70 + k)
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=4)
+        plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+        plan.set_weights(w, mul, bias)
+        work.append((plan, torch.from_numpy(x).to(DEV), want, torch.cuda.Stream()))
+
+    def drive(plan, xd, want, stream):
+        try:
+            with torch.cuda.stream(stream):
+                outs = [plan.run(xd) for _ in range(40)]
+            stream.synchronize()
+            for o in (outs[0], outs[17], outs[-1]):
+                if not np.array_equal(o.cpu().numpy().view(np.int32), want.view(np.int32)):
+                    errors.append(plan.kernel_name())
+        except Exception as e:   # surfaced below: a thread must not die silently
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=drive, args=wk) for wk in work]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
