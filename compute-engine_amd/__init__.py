@@ -171,8 +171,8 @@ class Bconv2dPlan:
         return self
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            lib().lce_hip_bconv2d_plan_destroy(self._h)
+        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None:
+            _lib.lce_hip_bconv2d_plan_destroy(self._h)   # (_lib is None again during interpreter teardown)
             self._h = C.c_void_p()
 
     __del__ = close

@@ -220,6 +220,11 @@ LCE_DEVICE void interleave_step() { interleave_step_from<0, NMFMA, NDS, NVMEM>()
 // by this kernel: keeps the L2 for the operands that ARE re-read.
 LCE_DEVICE void store_streaming(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }
 LCE_DEVICE void store_streaming(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+// Non-temporal 4-byte store through a buffer resource: per-lane byte offset + wave-uniform (SGPR) byte
+// offset; a store whose per-lane offset falls outside the resource is dropped by the hardware range check.
+LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off, uniform_off, /*nt*/ 2);
+}
 // ... and the matching load for inputs that are read exactly once
 LCE_DEVICE f32x4 load_streaming(const f32x4* p) { return __builtin_nontemporal_load(p); }
 LCE_DEVICE u32x4 load_streaming(const u32x4* p) { return __builtin_nontemporal_load(p); }

@@ -394,6 +394,14 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     else if (!strcmp(value, "gemm")) h.phase = 2;
     else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: phase must be all|expand|gemm");
     return LCE_HIP_OK;
+  } else if (!strcmp(key, "epilogue")) {
+    // tuning aid for the matrix-core engine's float / int8 epilogues
+    if (!strcmp(value, "auto")) h.epilogue_pref = 0;
+    else if (!strcmp(value, "tile")) h.epilogue_pref = 1;
+    else if (!strcmp(value, "wide")) h.epilogue_pref = 2;
+    else if (!strcmp(value, "direct")) h.epilogue_pref = 3;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: epilogue must be auto|tile|wide|direct");
+    return LCE_HIP_OK;
   } else if (!strcmp(key, "kernel")) {
     if (!strcmp(value, "auto")) h.kernel_pref = 0;
     else if (!strcmp(value, "tiled")) h.kernel_pref = 1;
@@ -613,6 +621,19 @@ lce_hip_status lce_hip_prepare_bitpack_filter(const float* filter_ohwi, int32_t 
 int lce_hip_debug_read_timeline(void* host, size_t bytes) {
   if (bytes > sizeof(lce::lce_timeline)) bytes = sizeof(lce::lce_timeline);
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lce::lce_timeline), bytes);
+}
+#endif
+
+#ifdef LCE_PHASES
+// profiling aid (tools/phases.py), not part of the ABI: the per-block phase stamps of the last launch
+int lce_hip_debug_read_phases(void* host, size_t bytes) {
+  if (bytes > sizeof(lce::lce_phase_tl)) bytes = sizeof(lce::lce_phase_tl);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lce::lce_phase_tl), bytes);
+}
+int lce_hip_debug_clear_phases(void) {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(lce::lce_phase_tl)) != hipSuccess) return 1;
+  return (int)hipMemset(p, 0, sizeof(lce::lce_phase_tl));
 }
 #endif
 

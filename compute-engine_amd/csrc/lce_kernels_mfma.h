@@ -147,6 +147,22 @@ __device__ unsigned long long lce_timeline[2 * 8 * 80 * 4];
 #else
 #define LCE_TL(slot) do {} while (0)
 #endif
+#ifdef LCE_PHASES
+// Profiling aid (tools/phases.py builds the library with -DLCE_PHASES; never defined in the product
+// build): six s_memtime stamps per BLOCK (wave 0, lane 0) -- entry, halo in LDS, K loop entered, K loop
+// done, epilogue issued -- plus the hardware id of the CU it ran on, for all blocks of the launch.
+__device__ unsigned long long lce_phase_tl[16384 * 16];
+#define LCE_PH(slot)                                                                              \
+  do {                                                                                            \
+    if (thread_idx_x() == 0 && ph_lin < 16384u)                                                   \
+      lce_phase_tl[ph_lin * 16 + (slot)] = (slot) == 7                                             \
+          ? (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) |            \
+                (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)                     \
+          : __builtin_readcyclecounter();                                                         \
+  } while (0)
+#else
+#define LCE_PH(slot) do {} while (0)
+#endif
 template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
@@ -174,6 +190,11 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const bool tl_on = tl_lin - tl_first < 2u;
   const int tl_blk = (int)(tl_lin - tl_first);
 #endif
+#ifdef LCE_PHASES
+  const uint32_t ph_lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
+#endif
+  LCE_PH(0);
+  LCE_PH(7);
   uint8_t* const lds0 = lds_base();
   uint8_t* const lds = lds0 + (DIRECT ? G.halo_bytes : 0);   // the K-step ring
   const int tid = thread_idx_x();
@@ -262,10 +283,12 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     // block has fewer pieces than waves, a surplus slot re-copies an earlier piece (same bytes to
     // the same address) -- skipping it would need a branch, and a branch would split the K-step's
     // scheduling region.
+#ifndef LCE_ABL_NODMA   // timing ablation (results are wrong): the K loop without its LDS-DMA instructions
 #pragma unroll
     for (int i = 0; i < NPA; ++i) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
 #pragma unroll
     for (int i = 0; i < NPB; ++i) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
+#endif
     // cursor to the next K-step, branch-free (selects, not jumps: a branch here would split the
     // K-step's basic block and with it the scheduling region the MFMA interleave needs)
     b_off += b_step;
@@ -290,9 +313,12 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const int half = lane >> 5, l31 = lane & 31;
 
   // start the pipeline: the first STAGES K-steps are on their way before anything else happens
+  // (direct variant: right behind the halo's global loads, see below)
+  if constexpr (!DIRECT) {
 #pragma unroll
-  for (int d = 0; d < STAGES; ++d)
-    if (d < KS) fill(d);
+    for (int d = 0; d < STAGES; ++d)
+      if (d < KS) fill(d);
+  }
 
   // ---- direct variant: the tile's input halo, expanded to FP4 once, stays in LDS ---------
   // The GEMM variant re-fetches every pixel of the tile once per filter tap (KH*KW times,
@@ -311,60 +337,80 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   if constexpr (DIRECT) {
     const int oy0 = (int)fastdiv((uint32_t)p0, A.div_ow);
     const int iy_first = oy0 * A.SH - G.PH;
-    const size_t img_words = (size_t)G.H * G.W * (size_t)G.Cw;
-    const uint32_t* src_img0 = (const uint32_t*)xp + (size_t)img * img_words;
+    const uint32_t img_bytes = (uint32_t)G.H * (uint32_t)G.W * (uint32_t)G.Cw * 4u;
+    // the rows come through a buffer resource over [first image of the tile, end of the launch's
+    // input): a tap outside the image (or an image past the batch) is steered to an out-of-range
+    // offset and reads 0 = the "+1" padding word, so the loads need no branches
+    const rsrc_t rin = make_rsrc(xp + (size_t)img * img_bytes, (uint32_t)(G.B - img) * img_bytes);
     const int items = G.IPT * G.HPIX * G.QG;
     const bool vec = (G.Cw & 3) == 0;
     // Loads first, arithmetic second: a thread's (up to) PRE 16-byte loads are all in flight
     // before the first one is consumed, so the block pays one memory latency for its halo
-    // instead of one per item.
+    // instead of one per item.  The weight ring's first fills are issued BEHIND these loads:
+    // the memory counter retires in order, so waiting for the halo rows does not wait for them.
     constexpr int PRE = 4, NT = 64 * NWAVES;
-    for (int e0 = 0; e0 < items; e0 += PRE * NT) {
-      u32x4 wv[PRE];
-      int pixv[PRE], c0v[PRE];
-      bool inv[PRE];
+    LCE_PH(8);
+    // FAST (compile-time): every item is four full words (Cin % 128 == 0, no zero border) -- the
+    // BASELINE layers -- so neither the loads nor the expansion carry per-word conditions.
+    auto halo_pass = [&](auto fast_c) LCE_LAMBDA_INLINE {
+      constexpr bool FAST = decltype(fast_c)::value;
+      for (int e0 = 0; e0 < items; e0 += PRE * NT) {
+        u32x4 wv[PRE];
+        int pixv[PRE], c0v[PRE];
+        bool inv[PRE];
 #pragma unroll
-      for (int k = 0; k < PRE; ++k) {
-        const int e = e0 + k * NT + tid;
-        wv[k] = u32x4{0u, 0u, 0u, 0u};                           // outside: bit 0 = +1 (pad_values 1)
-        pixv[k] = -1; c0v[k] = 0; inv[k] = false;
-        if (e < items) {
-          const int pix = (int)fastdiv((uint32_t)e, G.div_qg);   // (image * halo_rows + slot) * Wp + x
+        for (int k = 0; k < PRE; ++k) {
+          const int e = e0 + k * NT + tid;
+          const int pix = (int)fastdiv((uint32_t)e, G.div_qg);     // (image * halo_rows + slot) * Wp + x
           const int c0 = (e - pix * G.QG) * 4;
           const int li = (int)fastdiv((uint32_t)pix, G.div_hpix);  // image of the tile (0 unless IPT > 1)
           const int ipix = pix - li * G.HPIX;
           const int slot = (int)fastdiv((uint32_t)ipix, G.div_wp);
           const int iy = iy_first + slot, ix = ipix - slot * G.Wp - G.PW;
-          const bool inside = (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W && img + li < G.B;
-          pixv[k] = pix; c0v[k] = c0; inv[k] = inside;
-          if (inside) {
-            const uint32_t* src = src_img0 + (size_t)li * img_words + ((size_t)iy * G.W + ix) * (size_t)G.Cw + c0;
-            if (vec && c0 + 4 <= G.Cw) {
-              wv[k] = *(const u32x4*)src;
-            } else {
+          const bool inside = e < items && (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W && img + li < G.B;
+          pixv[k] = e < items ? pix : -1; c0v[k] = c0; inv[k] = inside;
+          const uint32_t off = (uint32_t)li * img_bytes + (uint32_t)((iy * G.W + ix) * G.Cw + c0) * 4u;
+          if (FAST || vec) {
+            wv[k] = buf_load(rin, inside ? off : kOobOffset, (u32x4*)nullptr);
+          } else {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (c0 + q < G.Cw) wv[k][q] = src[q];
+            for (int q = 0; q < 4; ++q)
+              wv[k][q] = buf_load(rin, inside && c0 + q < G.Cw ? off + 4u * q : kOobOffset, (uint32_t*)nullptr);
+          }
+        }
+        if (e0 == 0) {
+          LCE_PH(9);
+#pragma unroll
+          for (int d = 0; d < STAGES; ++d)
+            if (d < KS) fill(d);
+          LCE_PH(10);
+        }
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+#ifdef LCE_PHASES
+          if (e0 == 0 && k == 1) LCE_PH(11);
+#endif
+          if (pixv[k] < 0) continue;
+          uint8_t* dst = lds0 + (size_t)pixv[k] * G.PS + c0v[k] * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (FAST) {
+              *(u32x4*)(dst + q * 16) = fp4_of_full_word(wv[k][q]);
+            } else {
+              const int cc = c0v[k] + q;
+              if (cc < G.CPW) {
+                int valid = G.Cin - cc * 32;                         // channels of this word that exist
+                valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
+                if (!inv[k] && G.zero_border) valid = 0;             // exact SAME-zero: 0 contributes 0
+                *(u32x4*)(dst + q * 16) = valid == 32 ? fp4_of_full_word(wv[k][q]) : fp4_of_word(wv[k][q], valid);
+              }
             }
           }
         }
       }
-#pragma unroll
-      for (int k = 0; k < PRE; ++k) {
-        if (pixv[k] < 0) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cc = c0v[k] + q;
-          if (cc < G.CPW) {
-            int valid = G.Cin - cc * 32;                         // channels of this word that exist
-            valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
-            if (!inv[k] && G.zero_border) valid = 0;             // exact SAME-zero: 0 contributes 0
-            *(u32x4*)(lds0 + (size_t)pixv[k] * G.PS + cc * 16) =
-                valid == 32 ? fp4_of_full_word(wv[k][q]) : fp4_of_word(wv[k][q], valid);
-          }
-        }
-      }
-    }
+    };
+    if ((G.Cin & 127) == 0 && !G.zero_border) halo_pass(StepSteady{});
+    else halo_pass(StepTail{});
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       int p = p0 + (wm * WM + i) * 32 + l31;   // pixel of the tile's first image, or beyond it
@@ -377,6 +423,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
     }
   }
+  LCE_PH(1);
   const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * 32u;
   const uint32_t c_step_fy = (uint32_t)((A.DH * G.Wp - A.KW * A.DW) * G.PS);
 
@@ -411,7 +458,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     if constexpr (decltype(steady)::value) {
       LCE_TL(0);
       wait_vmcnt<NP * (STAGES - 2)>();          // own pieces of step ks+1 have landed
+#ifndef LCE_ABL_NOBAR   // timing ablation (results are wrong): no barrier in the steady K-step
       block_barrier_keep_vm();
+#endif
       LCE_TL(1);
       LCE_TL(2);
     } else {
@@ -446,6 +495,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   block_barrier_keep_vm();
   u32x4 af0[WM], bf0[WN], af1[WM], bf1[WN];
   load_frags(0, af0, bf0);   // stage 0 = K-step 0
+  LCE_PH(2);
   // Steady loop, unrolled over one full cycle of (fragment-set parity) x (ring position) so that
   // every stage index is a literal -- no `% STAGES` arithmetic in the K-step.
   constexpr int UNROLL = (STAGES % 2 == 0) ? STAGES : 2 * STAGES;
@@ -467,6 +517,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     if (ks + 1 < KS) step(StepTail{}, ks + 1, (ks + 1) % STAGES, (ks + 2) % STAGES, af1, bf1, af0, bf0);
   }
 
+  LCE_PH(3);
   // ------------------------------ fused output transform ------------------------------
   // An accumulator tile is held "one channel per lane" (column = lane & 31, 16 pixel rows in
   // 16 registers), which would make every global store a 4-byte-per-lane affair.  Instead:
@@ -532,12 +583,37 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
       }
     }
+  } else if (DST == kDstFloat && !CORR && G.f32_wide == 2) {
+    // float, direct path: no transpose at all.  Register r of a tile IS two full 128-byte lines (the 32
+    // channels of pixel rows q and q + 4), so a 4-byte-per-lane store is perfectly coalesced; measured
+    // alone (tools/probes/store_overlap.hip) this pattern writes 5.7 TB/s against 6.0 TB/s for 16-byte
+    // rows -- and it needs no LDS round trip, no fences and no scratch.  Rows past the tile's last pixel
+    // fall off the end of the buffer resource (bound to the tile's real rows), so nothing is predicated per
+    // store (the resource's range check covers the per-lane offset, which therefore carries the row).
+    const int tile_rows = m_end - m0 < BM ? m_end - m0 : BM;
+    const uint32_t row_bytes = (uint32_t)A.N * 4u;
+    const rsrc_t ro = make_rsrc((float*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows * row_bytes);
+    const uint32_t lane_off = (uint32_t)(4 * half) * row_bytes + (uint32_t)(n0 + wn * WN * 32 + l31) * 4u;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t row_off = (uint32_t)((wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if (n0 + (wn * WN + j) * 32 >= A.N) continue;              // N % 32 == 0: whole tile or nothing
+          const float x = med3(acc[i][j][r], cminf, cmaxf);
+          buf_store_streaming(ro, lane_off + row_off + (uint32_t)(j * 128), 0u, mul_then_add(x, mj[j], bj[j]));
+        }
+      }
+    }
   } else if (DST == kDstFloat && !CORR && G.f32_wide && (((size_t)out) & 15) == 0) {
     // float, wide path: the WN tiles of a 32-row block are transposed together
     // ([32 rows][WN*32] floats of scratch), so there is one LDS fence pair per row block instead of
     // one per tile, and a store instruction covers whole row segments of WN*128 bytes.
     constexpr int RW = WN * 32;                                  // floats per scratch row
     constexpr int LPR = RW / 4, RPI = 64 / LPR;                  // lanes per row (16 bytes each), rows per store instruction
+    constexpr int NK = 32 / RPI, KB = NK < 8 ? NK : 8;           // store instructions per row block, in batches of KB
     float* scratch = (float*)(lds0 + wave * (WN * 4096));
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -552,13 +628,19 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       wave_lds_fence();
       const int g = lane % LPR;
       const int n = n0 + wn * RW + g * 4;
+      // the LDS reads of a batch are all issued before the first store needs its data (one LDS latency
+      // per batch, not one per store)
 #pragma unroll
-      for (int k = 0; k < 32 / RPI; ++k) {
-        const int row = lane / LPR + k * RPI;
-        const int m = m0 + (wm * WM + i) * 32 + row;
-        const f32x4 y = *(const f32x4*)(scratch + row * RW + g * 4);
-        if (m < m_end && n < A.N)                                  // N % 4 == 0: whole group or nothing
-          store_streaming((f32x4*)((float*)out + (size_t)m * (size_t)A.N + (size_t)n), y);
+      for (int k0 = 0; k0 < NK; k0 += KB) {
+        f32x4 y[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) y[k] = *(const f32x4*)(scratch + (lane / LPR + (k0 + k) * RPI) * RW + g * 4);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int m = m0 + (wm * WM + i) * 32 + lane / LPR + (k0 + k) * RPI;
+          if (m < m_end && n < A.N)                                // N % 4 == 0: whole group or nothing
+            store_streaming((f32x4*)((float*)out + (size_t)m * (size_t)A.N + (size_t)n), y[k]);
+        }
       }
       wave_lds_fence();
     }
@@ -583,19 +665,28 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       wave_lds_fence();
       const int g = lane % GPR;
       const int n = n0 + wn * RW + g * 16;
+      // all LDS reads of a batch first (one LDS latency per batch, not one per store), then convert + store
+      constexpr int NK = 32 / RPI, KB = NK < 4 ? NK : 4;
 #pragma unroll
-      for (int k = 0; k < 32 / RPI; ++k) {
-        const int row = lane / GPR + k * RPI;
-        const int m = m0 + (wm * WM + i) * 32 + row;
-        const f32x4* src = (const f32x4*)(scratch + row * RW + g * 16);
-        u32x4 pk;
+      for (int k0 = 0; k0 < NK; k0 += KB) {
+        f32x4 y[KB][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 y = src[q];
-          pk[q] = pack4_u8(round_sat_i8(y[0]), round_sat_i8(y[1]), round_sat_i8(y[2]), round_sat_i8(y[3]));
+        for (int k = 0; k < KB; ++k) {
+          const f32x4* src = (const f32x4*)(scratch + (lane / GPR + (k0 + k) * RPI) * RW + g * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[k][q] = src[q];
         }
-        if (m < m_end && n < A.N) {                                // N % 16 == 0: whole group or nothing
-          *(u32x4*)((int8_t*)out + (size_t)m * (size_t)A.N + (size_t)n) = pk;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          const int m = m0 + (wm * WM + i) * 32 + lane / GPR + (k0 + k) * RPI;
+          u32x4 pk;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pk[q] = pack4_u8(round_sat_i8(y[k][q][0]), round_sat_i8(y[k][q][1]), round_sat_i8(y[k][q][2]),
+                             round_sat_i8(y[k][q][3]));
+          if (m < m_end && n < A.N) {                              // N % 16 == 0: whole group or nothing
+            *(u32x4*)((int8_t*)out + (size_t)m * (size_t)A.N + (size_t)n) = pk;
+          }
         }
       }
       wave_lds_fence();
@@ -660,6 +751,11 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       }
     }
   }
+  LCE_PH(4);
+#ifdef LCE_PHASES
+  __builtin_amdgcn_s_waitcnt(0);   // the block's stores have been acknowledged
+  LCE_PH(5);
+#endif
 }
 
 }  // namespace lce

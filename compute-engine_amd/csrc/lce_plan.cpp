@@ -389,6 +389,11 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
     // not with the SAME-zero correction variant, whose epilogue is per tile
     G.f32_wide = (p.d.dst_type == LCE_HIP_F32 && p.d.channels_out % 4 == 0 && room &&
                   p.zero_pad_mode != kZeroPadCorrection) ? 1 : 0;
+    // float: 4-byte stores straight from the accumulators (a register is two full 128-byte lines)
+    const bool direct_ok = p.d.dst_type == LCE_HIP_F32 && p.d.channels_out % 32 == 0 &&
+                           p.zero_pad_mode != kZeroPadCorrection;
+    if (p.epilogue_pref == 3 && direct_ok) G.f32_wide = 2;
+    if (p.epilogue_pref == 1) { G.f32_wide = 0; G.i8_wide = 0; }
   }
   if (p.use_direct) {
     G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;

@@ -64,6 +64,7 @@ struct HostPlan {
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
+  int epilogue_pref = 0;                   // float/int8 epilogue: 0 auto, 1 per-tile transpose, 2 joint transpose, 3 direct 4-byte stores
   bool use_mfma = false;
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
   int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count

@@ -166,6 +166,10 @@ template <int N> inline void interleave_mfma_ldsread() {}
 template <int NMFMA, int NDS, int NVMEM> inline void interleave_step() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
 inline void store_streaming(u32x4* p, u32x4 v) { *p = v; }
+inline void buf_store_streaming(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, float v) {
+  const uint64_t off = (uint64_t)lane_off + uniform_off;
+  if (off + 4 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + off, &v, 4);
+}
 inline f32x4 load_streaming(const f32x4* p) { return *p; }
 inline u32x4 load_streaming(const u32x4* p) { return *p; }
 inline float med3(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }

@@ -32,12 +32,14 @@ def _params(spec, dst, **kw):
 
 
 def _gpu_conv(spec, dst, x, w, mul=None, bias=None, thr=None, scale=1.0, zp=0, kernel="auto", tile="auto",
-              poison=True, engine="valu"):
+              poison=True, engine="valu", opts=()):
     plan = amd.Bconv2dPlan(_params(spec, dst, out_scale=float(scale), out_zero_point=int(zp)))
     plan.set_weights(w, mul, bias, thr)
     plan.set_option("engine", engine)
     plan.set_option("kernel", kernel)
     plan.set_option("tile", tile)
+    for k, v in opts:
+        plan.set_option(k, v)
     xd = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
     dt = {amd.F32: torch.float32, amd.I8: torch.int8, amd.BITPACKED: torch.int32}[dst]
     out = torch.full(plan.output_shape, 0x5A if dst == amd.I8 else -7, dtype=dt, device=DEV)
@@ -237,6 +239,26 @@ def test_conv_every_tile_shape(tile, cin, cout, groups, pad):
         spec = O.ConvSpec(3, 9, 11, cin, 3, 3, cout, groups, st[0], st[1], dil[0], dil[1], padding, pv, act, sem)
         names = _check_all_dst(spec, cin * 7 + cout, kernel="tiled", tile=tile)
         assert all(("TM=%s,TN=%s" % tuple(tile.split("x"))) in n for n in names), names
+
+
+@pytest.mark.parametrize("epilogue", ["tile", "wide", "direct"])
+@pytest.mark.parametrize("engine", ["mfma", "direct"])
+@pytest.mark.parametrize("shape", [(3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 320), (2, 30, 9, 40, 96),
+                                   (1, 56, 56, 128, 32)])
+def test_float_and_int8_epilogue_variants(shape, engine, epilogue):
+    """Every epilogue of the matrix-core engine (per-tile LDS transpose, joint transpose with 16-byte row
+    stores, 4-byte stores straight from the accumulators) writes the oracle's bits, including the partial
+    last tile of an image and channel counts that do not fill the block."""
+    b, h, w_, cin, cout = shape
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    x, w, mul, bias = synth.conv_inputs(spec, sum(shape), negative_mul_fraction=0.2)
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=4)
+    got, name = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine=engine, opts=(("epilogue", epilogue),))
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+    scale, zp = synth.int8_quant_params(7)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=4)
+    got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, engine=engine, opts=(("epilogue", epilogue),))
+    assert np.array_equal(got, want), name
 
 
 def test_conv_accumulator_overflow_shape():

@@ -29,6 +29,8 @@ if os.environ.get("LCE_ZERO"):   # constant operands: how much of the time is th
 plan = amd.Bconv2dPlan(layer.params(amd, dst, 0.125, 3))
 plan.set_weights(w, mul, bias, thr)
 plan.set_option("engine", engine)
+for kv in filter(None, os.environ.get("LCE_OPTS", "").split(",")):   # e.g. LCE_OPTS=epilogue=direct
+    plan.set_option(*kv.split("="))
 if tile != "auto":
     if engine == "valu":
         plan.set_option("kernel", "tiled")
