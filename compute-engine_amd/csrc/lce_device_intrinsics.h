@@ -220,10 +220,16 @@ LCE_DEVICE void interleave_step() { interleave_step_from<0, NMFMA, NDS, NVMEM>()
 // by this kernel: keeps the L2 for the operands that ARE re-read.
 LCE_DEVICE void store_streaming(f32x4* p, f32x4 v) { __builtin_nontemporal_store(v, p); }
 LCE_DEVICE void store_streaming(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
-// Non-temporal 4-byte store through a buffer resource: per-lane byte offset + wave-uniform (SGPR) byte
-// offset; a store whose per-lane offset falls outside the resource is dropped by the hardware range check.
-LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off, uniform_off, /*nt*/ 2);
+// 16-byte stores through a buffer resource (the per-lane offset is range-checked by the hardware):
+// non-temporal for float rows that are written once, plain for the rest
+#ifndef LCE_STORE_AUX
+#define LCE_STORE_AUX 2   /* nt */
+#endif
+LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, 0, LCE_STORE_AUX);
+}
+LCE_DEVICE void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, 0, 0);
 }
 // ... and the matching load for inputs that are read exactly once
 LCE_DEVICE f32x4 load_streaming(const f32x4* p) { return __builtin_nontemporal_load(p); }

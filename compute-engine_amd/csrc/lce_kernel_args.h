@@ -82,6 +82,7 @@ struct MfmaArgs {
   int32_t HPIX;            // halo pixels per image = halo_rows * Wp
   int32_t f32_wide;        // float epilogue may transpose the WN tiles of a row block together
   int32_t i8_wide;         // int8 epilogue may use WN*4 KiB of LDS scratch per wave (16-byte row stores)
+  int32_t noclamp;         // the output transform's clamp is the identity on [0, 2*K_bt] (activation NONE)
   FastDiv div_tpi, div_qg, div_ohow, div_hpix;
 };
 

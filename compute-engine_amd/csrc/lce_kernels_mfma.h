@@ -167,7 +167,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
 
-template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, bool DIRECT = false,
+template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, bool DIRECT = false, bool BITS = false,
           int STAGES = DIRECT ? 3 : 4>
 LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
@@ -183,6 +183,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // fills it in 1-KiB pieces (64 rows of one half) with one LDS-DMA instruction each.
   constexpr int A_PIECES = BM / 32;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tiles are filled in 64-row pieces");
+  static_assert(!BITS || DIRECT, "the bit halo is a form of the direct variant");
 
 #ifdef LCE_TIMELINE
   const uint32_t tl_lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
@@ -391,6 +392,15 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           if (e0 == 0 && k == 1) LCE_PH(11);
 #endif
           if (pixv[k] < 0) continue;
+          if constexpr (BITS) {
+            // bit halo: the raw words, one pixel every PS = 4*Cw + 4 bytes (an odd number of dwords, so the
+            // 32 pixels a fragment read touches fall on 32 different banks)
+            uint8_t* dstb = lds0 + (size_t)pixv[k] * G.PS + c0v[k] * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (FAST || c0v[k] + q < G.Cw) *(uint32_t*)(dstb + q * 4) = wv[k][q];
+            continue;
+          }
           uint8_t* dst = lds0 + (size_t)pixv[k] * G.PS + c0v[k] * 16;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -420,35 +430,57 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       p -= li * G.OHOW;
       const int oy = (int)fastdiv((uint32_t)p, A.div_ow);
       const int ox = p - oy * A.OW;
-      a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
+      a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * (BITS ? 4 : 16));
     }
   }
   LCE_PH(1);
-  const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * 32u;
+  constexpr uint32_t kAStep = BITS ? 8u : 32u;   // bytes of halo per K-step and pixel: 2 words, or 64 FP4 codes
+  const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * kAStep;
   const uint32_t c_step_fy = (uint32_t)((A.DH * G.Wp - A.KW * A.DW) * G.PS);
 
-  // load_frags is always called for consecutive K-steps (0, 1, 2, ...), once each; `stage` = ks % STAGES
-  auto load_frags = [&](int stage, u32x4 (&af)[WM], u32x4 (&bf)[WN]) {
-    const uint8_t* base = lds + stage * STAGE;
+  // A-operand cursor of the direct variants: advances by one K-step (branch-free, as in fill())
+  auto advance_a = [&]() LCE_LAMBDA_INLINE {
+    ++c_kc;
+    const bool wrap_kc = c_kc == G.KCH;
+    c_kc = wrap_kc ? 0 : c_kc;
+    c_fx += wrap_kc ? 1 : 0;
+    const bool wrap_fx = c_fx == A.KW;
+    c_fx = wrap_fx ? 0 : c_fx;
+    a_cur += kAStep + (wrap_kc ? c_step_fx : 0u) + (wrap_fx ? c_step_fy : 0u);
+  };
+  // load_a / load_raw / load_b are always called for consecutive K-steps (0, 1, 2, ...), once each;
+  // `stage` = ks % STAGES
+  auto load_a = [&](int stage, u32x4 (&af)[WM]) LCE_LAMBDA_INLINE {
     if constexpr (DIRECT) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) af[i] = *(const u32x4*)(lds0 + (a_base[i] + a_cur));
-      ++c_kc;                                   // branch-free, as in fill()
-      const bool wrap_kc = c_kc == G.KCH;
-      c_kc = wrap_kc ? 0 : c_kc;
-      c_fx += wrap_kc ? 1 : 0;
-      const bool wrap_fx = c_fx == A.KW;
-      c_fx = wrap_fx ? 0 : c_fx;
-      a_cur += 32u + (wrap_kc ? c_step_fx : 0u) + (wrap_fx ? c_step_fy : 0u);
+      advance_a();
     } else {
+      const uint8_t* base = lds + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
         af[i] = *(const u32x4*)(base + half * (BM * 16) + ((wm * WM + i) * 32 + l31) * 16);
     }
+  };
+  // bit halo: a fragment is ONE raw word per lane (the 32 channels of its k-half), expanded to FP4 in
+  // registers (17 VALU) -- a quarter of the LDS bytes of a 16-byte fragment read, and the halo itself is
+  // a quarter of the FP4 one, which is what lets four blocks share a CU
+  auto load_raw = [&](uint32_t (&raw)[WM]) LCE_LAMBDA_INLINE {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) raw[i] = *(const uint32_t*)(lds0 + (a_base[i] + a_cur));
+    advance_a();
+  };
+  auto expand_raw = [&](const uint32_t (&raw)[WM], u32x4 (&af)[WM]) LCE_LAMBDA_INLINE {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) af[i] = fp4_of_full_word(raw[i]);
+  };
+  auto load_b = [&](int stage, u32x4 (&bf)[WN]) LCE_LAMBDA_INLINE {
+    const uint8_t* base = lds + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < WN; ++j)
       bf[j] = *(const u32x4*)(base + A_BYTES + half * (BN * 16) + ((wn * WN + j) * 32 + l31) * 16);
   };
+  uint32_t rawp[WM];   // bit halo: the raw words of the NEXT step's A fragments (read one step ahead of their expansion)
   // One K-step.  `steady` (compile-time) = the ring is full: a refill is due and exactly
   // STAGES-1 younger fills are in flight, so the wait count is exact and nothing branches.
   // fs = ks % STAGES (the stage this step vacates and refills), rs = (ks + 1) % STAGES (the stage
@@ -467,7 +499,15 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       wait_vmcnt<0>();                           // tail: fewer fills in flight than the exact count
       block_barrier_keep_vm();
       if (ks + STAGES < KS) fill(fs);
-      if (ks + 1 < KS) load_frags(rs, af_next, bf_next);
+      if (ks + 1 < KS) {
+        if constexpr (BITS) {
+          expand_raw(rawp, af_next);
+          if (ks + 2 < KS) load_raw(rawp);
+        } else {
+          load_a(rs, af_next);
+        }
+        load_b(rs, bf_next);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -478,7 +518,15 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       // between them: the wave's matrix work starts right behind the barrier, and the expensive
       // issues (LDS-DMA, ds_read) overlap the MFMAs' execution instead of preceding it
       fill(fs);                                  // step ks+STAGES into the stage just vacated
-      load_frags(rs, af_next, bf_next);
+#ifndef LCE_ABL_NOFRAG   // timing ablation (results are wrong): no fragment reads in the steady K-step
+      if constexpr (BITS) {
+        expand_raw(rawp, af_next);               // step ks+1's words arrived a step ago ...
+        load_raw(rawp);                          // ... and step ks+2's are on their way (the halo does not change)
+      } else {
+        load_a(rs, af_next);
+      }
+      load_b(rs, bf_next);
+#endif
       interleave_step<WM * WN, WM + WN, NP>();
     } else {
       interleave_mfma_ldsread<WM + WN>();        // tail: only fragment reads ride between the MFMAs
@@ -494,7 +542,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   else wait_vmcnt<0>();
   block_barrier_keep_vm();
   u32x4 af0[WM], bf0[WN], af1[WM], bf1[WN];
-  load_frags(0, af0, bf0);   // stage 0 = K-step 0
+  if constexpr (BITS) {
+    load_raw(rawp);            // K-step 0
+    expand_raw(rawp, af0);
+    if (KS > 1) load_raw(rawp);   // K-step 1
+  } else {
+    load_a(0, af0);
+  }
+  load_b(0, bf0);              // stage 0 = K-step 0
   LCE_PH(2);
   // Steady loop, unrolled over one full cycle of (fragment-set parity) x (ring position) so that
   // every stage index is a literal -- no `% STAGES` arithmetic in the K-step.
@@ -583,53 +638,42 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
       }
     }
-  } else if (DST == kDstFloat && !CORR && G.f32_wide == 2) {
-    // float, direct path: no transpose at all.  Register r of a tile IS two full 128-byte lines (the 32
-    // channels of pixel rows q and q + 4), so a 4-byte-per-lane store is perfectly coalesced; measured
-    // alone (tools/probes/store_overlap.hip) this pattern writes 5.7 TB/s against 6.0 TB/s for 16-byte
-    // rows -- and it needs no LDS round trip, no fences and no scratch.  Rows past the tile's last pixel
-    // fall off the end of the buffer resource (bound to the tile's real rows), so nothing is predicated per
-    // store (the resource's range check covers the per-lane offset, which therefore carries the row).
-    const int tile_rows = m_end - m0 < BM ? m_end - m0 : BM;
-    const uint32_t row_bytes = (uint32_t)A.N * 4u;
-    const rsrc_t ro = make_rsrc((float*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows * row_bytes);
-    const uint32_t lane_off = (uint32_t)(4 * half) * row_bytes + (uint32_t)(n0 + wn * WN * 32 + l31) * 4u;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t row_off = (uint32_t)((wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          if (n0 + (wn * WN + j) * 32 >= A.N) continue;              // N % 32 == 0: whole tile or nothing
-          const float x = med3(acc[i][j][r], cminf, cmaxf);
-          buf_store_streaming(ro, lane_off + row_off + (uint32_t)(j * 128), 0u, mul_then_add(x, mj[j], bj[j]));
-        }
-      }
-    }
   } else if (DST == kDstFloat && !CORR && G.f32_wide && (((size_t)out) & 15) == 0) {
     // float, wide path: the WN tiles of a 32-row block are transposed together
     // ([32 rows][WN*32] floats of scratch), so there is one LDS fence pair per row block instead of
     // one per tile, and a store instruction covers whole row segments of WN*128 bytes.
+    // Everything outside the K loop runs beside the co-resident block's MFMA stream at ~8-10 cycles per
+    // instruction (tools/probes/coissue.hip), so the epilogue is written for instruction COUNT: no clamp
+    // when the clamp is the identity (activation NONE), no per-store predicates -- the stores go through
+    // a buffer resource over the tile's real rows, rows past it fall off its end and lanes past the last
+    // channel carry an out-of-range offset -- and the LDS reads of a batch are issued together.
     constexpr int RW = WN * 32;                                  // floats per scratch row
     constexpr int LPR = RW / 4, RPI = 64 / LPR;                  // lanes per row (16 bytes each), rows per store instruction
     constexpr int NK = 32 / RPI, KB = NK < 8 ? NK : 8;           // store instructions per row block, in batches of KB
     float* scratch = (float*)(lds0 + wave * (WN * 4096));
+    const int tile_rows = m_end - m0 < BM ? m_end - m0 : BM;
+    const uint32_t row_bytes = (uint32_t)A.N * 4u;
+    const rsrc_t ro = make_rsrc((float*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows * row_bytes);
+    const int g = lane % LPR;
+    const int n = n0 + wn * RW + g * 4;
+    const uint32_t lane_off = n < A.N ? (uint32_t)(lane / LPR) * row_bytes + (uint32_t)n * 4u : kOobOffset;   // N % 4 == 0
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+      if (G.noclamp) {
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float x = med3(acc[i][j][r], cminf, cmaxf);
-          scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
-        }
+          for (int r = 0; r < 16; ++r)
+            scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] = mul_then_add(acc[i][j][r], mj[j], bj[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] =
+                mul_then_add(med3(acc[i][j][r], cminf, cmaxf), mj[j], bj[j]);
+      }
       wave_lds_fence();
-      const int g = lane % LPR;
-      const int n = n0 + wn * RW + g * 4;
-      // the LDS reads of a batch are all issued before the first store needs its data (one LDS latency
-      // per batch, not one per store)
 #pragma unroll
       for (int k0 = 0; k0 < NK; k0 += KB) {
         f32x4 y[KB];
@@ -637,9 +681,10 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         for (int k = 0; k < KB; ++k) y[k] = *(const f32x4*)(scratch + (lane / LPR + (k0 + k) * RPI) * RW + g * 4);
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-          const int m = m0 + (wm * WM + i) * 32 + lane / LPR + (k0 + k) * RPI;
-          if (m < m_end && n < A.N)                                // N % 4 == 0: whole group or nothing
-            store_streaming((f32x4*)((float*)out + (size_t)m * (size_t)A.N + (size_t)n), y[k]);
+          buf_store_streaming(ro, lane_off + (uint32_t)((wm * WM + i) * 32 + (k0 + k) * RPI) * row_bytes, y[k]);
+#ifdef LCE_STORE_PACE   // experiment: spread the stores of the epilogue out in time
+          __builtin_amdgcn_s_sleep(LCE_STORE_PACE);
+#endif
         }
       }
       wave_lds_fence();
@@ -652,6 +697,12 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     constexpr int RW = WN * 32;                                  // floats per scratch row
     constexpr int GPR = WN * 2, RPI = 64 / GPR;                  // 16-channel groups per row, rows per store instruction
     float* scratch = (float*)(lds0 + wave * (WN * 4096));
+    // stores through a buffer resource over the tile's real rows (no per-store predicates, as in the float path)
+    const int tile_rows8 = m_end - m0 < BM ? m_end - m0 : BM;
+    const rsrc_t ro8 = make_rsrc((int8_t*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows8 * (uint32_t)A.N);
+    const uint32_t lane_off8 = n0 + wn * RW + (lane % GPR) * 16 < A.N
+                                   ? (uint32_t)(lane / GPR) * (uint32_t)A.N + (uint32_t)(n0 + wn * RW + (lane % GPR) * 16)
+                                   : kOobOffset;                  // N % 16 == 0: whole group or nothing
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -664,7 +715,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
       wave_lds_fence();
       const int g = lane % GPR;
-      const int n = n0 + wn * RW + g * 16;
       // all LDS reads of a batch first (one LDS latency per batch, not one per store), then convert + store
       constexpr int NK = 32 / RPI, KB = NK < 4 ? NK : 4;
 #pragma unroll
@@ -678,15 +728,12 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-          const int m = m0 + (wm * WM + i) * 32 + lane / GPR + (k0 + k) * RPI;
           u32x4 pk;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             pk[q] = pack4_u8(round_sat_i8(y[k][q][0]), round_sat_i8(y[k][q][1]), round_sat_i8(y[k][q][2]),
                              round_sat_i8(y[k][q][3]));
-          if (m < m_end && n < A.N) {                              // N % 16 == 0: whole group or nothing
-            *(u32x4*)((int8_t*)out + (size_t)m * (size_t)A.N + (size_t)n) = pk;
-          }
+          buf_store(ro8, lane_off8 + (uint32_t)((wm * WM + i) * 32 + (k0 + k) * RPI) * (uint32_t)A.N, pk);
         }
       }
       wave_lds_fence();

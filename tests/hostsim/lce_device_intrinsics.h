@@ -166,9 +166,11 @@ template <int N> inline void interleave_mfma_ldsread() {}
 template <int NMFMA, int NDS, int NVMEM> inline void interleave_step() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }
 inline void store_streaming(u32x4* p, u32x4 v) { *p = v; }
-inline void buf_store_streaming(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, float v) {
-  const uint64_t off = (uint64_t)lane_off + uniform_off;
-  if (off + 4 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + off, &v, 4);
+inline void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
+  if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 16);
+}
+inline void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
+  if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 16);
 }
 inline f32x4 load_streaming(const f32x4* p) { return *p; }
 inline u32x4 load_streaming(const u32x4* p) { return *p; }

@@ -241,14 +241,14 @@ def test_conv_every_tile_shape(tile, cin, cout, groups, pad):
         assert all(("TM=%s,TN=%s" % tuple(tile.split("x"))) in n for n in names), names
 
 
-@pytest.mark.parametrize("epilogue", ["tile", "wide", "direct"])
+@pytest.mark.parametrize("epilogue", ["tile", "wide"])
 @pytest.mark.parametrize("engine", ["mfma", "direct"])
 @pytest.mark.parametrize("shape", [(3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 320), (2, 30, 9, 40, 96),
                                    (1, 56, 56, 128, 32)])
 def test_float_and_int8_epilogue_variants(shape, engine, epilogue):
-    """Every epilogue of the matrix-core engine (per-tile LDS transpose, joint transpose with 16-byte row
-    stores, 4-byte stores straight from the accumulators) writes the oracle's bits, including the partial
-    last tile of an image and channel counts that do not fill the block."""
+    """Both epilogues of the matrix-core engine (per-tile LDS transpose with predicated stores, joint
+    transpose with range-checked 16-byte row stores) write the oracle's bits, including the partial last
+    tile of an image and channel counts that do not fill the block."""
     b, h, w_, cin, cout = shape
     spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
     x, w, mul, bias = synth.conv_inputs(spec, sum(shape), negative_mul_fraction=0.2)
@@ -660,3 +660,16 @@ def test_two_plans_on_two_streams_from_two_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("tile", ["128x256", "128x128", "256x64", "128x64"])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 40), (256, 256), (192, 130), (512, 96)])
+@pytest.mark.parametrize("pad", ["VALID", "ONE"])
+def test_conv_bit_halo_variant(tile, cin, cout, pad):
+    """The bit-halo variant of the matrix-core engine (raw words in LDS, A fragments expanded in registers):
+    every tile, 1 to 8 K-steps per tap, strides / dilation, partial last tiles, all output types."""
+    padding, pv = PADS[pad]
+    for st, dil, act in [((1, 1), (1, 1), O.ACT_NONE), ((2, 1), (1, 2), O.ACT_RELU)]:
+        spec = O.ConvSpec(3, 19, 23, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pv, act)
+        names = _check_all_dst(spec, cin * 7 + cout, tile=tile, engine="bits")
+        assert all(n.startswith("bconv2d_mfma_bits<") and ("," + tile + ">") in n for n in names), names

@@ -167,6 +167,13 @@ int main() {
     snprintf(nm, sizeof nm, "tile4_lds%dk", lds / 1024);
     TIME(nm, 0.0, (fill_tile<2><<<tiles, 256, lds>>>(out, tiles)));
   }
+  // one wave per SIMD (1 block per CU, 150 KiB of LDS) vs two: can a lone wave keep the matrix pipe busy?
+  {
+    hipFuncSetAttribute((const void*)mfma_store<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const double m1 = (double)256 * 4 * 2000 * 8 * 32.0 * 32 * 64;
+    TIME("mfma_only_1_wave_per_simd", m1, (mfma_store<0, true><<<256, 256, 150 * 1024>>>(out, 256, 2000)));
+    TIME("mfma_only_2_waves_per_simd", 2 * m1, (mfma_store<0, true><<<512, 256, 74 * 1024>>>(out, 512, 2000)));
+  }
   // matrix work + stores, 2 blocks per CU as in the real kernel (74 KiB of LDS each)
   const double macs = (double)tiles * 4 * 36 * 8 * 32.0 * 32 * 64;
   const int lds = 74 * 1024;
