@@ -186,6 +186,9 @@ LCE_DEVICE void wait_vmcnt() {
 // accesses go through differently-typed pointers: wait for the LDS queue, and stop the
 // compiler from moving LDS accesses across.
 LCE_DEVICE void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// s_sleep N: the wave gives up its issue slots for ~64*N cycles
+template <int N>
+LCE_DEVICE void yield_issue_slots() { __builtin_amdgcn_s_sleep(N); }
 // Pins an accumulator tile at this point of the program: the MFMAs that produce it cannot
 // be sunk below (hipcc otherwise moves the register-only MFMAs of a K-step past the NEXT
 // step's barrier, which serialises LDS latency and matrix work).

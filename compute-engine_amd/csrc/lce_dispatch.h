@@ -56,38 +56,32 @@ typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const ui
 
 // CORR = the optimized kernels' SAME-zero float correction in the epilogue (float output only)
 // DIRECT = LDS-resident input halo instead of the FP4 workspace (lce_kernels_mfma.h)
-// BITS = ... kept as raw bits, A fragments expanded in registers (4-wave block tiles only)
-template <int DST, bool CORR, bool DIRECT, bool BITS>
+template <int DST, bool CORR, bool DIRECT>
 mfma_fn mfma_by_tile(int bm, int bn) {
-  if constexpr (!BITS) {
-    if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR, DIRECT, false>;
-    if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR, DIRECT, false>;
-    if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR, DIRECT, false>;
-  }
-  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR, DIRECT, BITS>;
-  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR, DIRECT, BITS>;
-  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR, DIRECT, BITS>;
-  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR, DIRECT, BITS>;
+  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR, DIRECT>;
+  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR, DIRECT>;
+  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR, DIRECT>;
+  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR, DIRECT>;
+  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR, DIRECT>;
+  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR, DIRECT>;
+  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR, DIRECT>;
   return nullptr;
 }
 
-template <bool DIRECT, bool BITS>
+template <bool DIRECT>
 mfma_fn find_mfma_v(int dst, int bm, int bn, bool zero_pad_correction) {
   switch (dst) {
     case LCE_HIP_F32:
-      if constexpr (!BITS) {
-        if (zero_pad_correction) return mfma_by_tile<kDstFloat, true, DIRECT, false>(bm, bn);
-      }
-      return mfma_by_tile<kDstFloat, false, DIRECT, BITS>(bm, bn);
-    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false, DIRECT, BITS>(bm, bn);
-    default: return mfma_by_tile<kDstBitpacked, false, DIRECT, BITS>(bm, bn);
+      return zero_pad_correction ? mfma_by_tile<kDstFloat, true, DIRECT>(bm, bn)
+                                 : mfma_by_tile<kDstFloat, false, DIRECT>(bm, bn);
+    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false, DIRECT>(bm, bn);
+    default: return mfma_by_tile<kDstBitpacked, false, DIRECT>(bm, bn);
   }
 }
 
-inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false, bool bits = false) {
-  if (bits) return zero_pad_correction ? nullptr : find_mfma_v<true, true>(dst, bm, bn, false);
-  return direct ? find_mfma_v<true, false>(dst, bm, bn, zero_pad_correction)
-                : find_mfma_v<false, false>(dst, bm, bn, zero_pad_correction);
+inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false) {
+  return direct ? find_mfma_v<true>(dst, bm, bn, zero_pad_correction)
+                : find_mfma_v<false>(dst, bm, bn, zero_pad_correction);
 }
 
 }  // namespace lce

@@ -386,8 +386,7 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     else if (!strcmp(value, "valu")) h.engine_pref = 1;
     else if (!strcmp(value, "mfma")) h.engine_pref = 2;
     else if (!strcmp(value, "direct")) h.engine_pref = 3;
-    else if (!strcmp(value, "bits")) h.engine_pref = 4;
-    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|bits");
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct");
   } else if (!strcmp(key, "phase")) {
     // profiling aid for the matrix-core engine: time its two kernels separately
     if (!strcmp(value, "all")) h.phase = 0;
@@ -458,13 +457,13 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
     void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
     if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
-                             h.use_direct, h.use_bits);
+                             h.use_direct);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
       if (h.use_direct) {
         // no workspace: every block expands its own input halo into LDS
-        const size_t lds = (size_t)h.mfma.direct_lds_bytes(h.halo_bytes, h.use_bits);
+        const size_t lds = (size_t)h.mfma.direct_lds_bytes(h.halo_bytes);
         if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
           LCE_HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
           plan->lds_opt_in = (void*)fn;

@@ -167,7 +167,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
 
-template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, bool DIRECT = false, bool BITS = false,
+template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, bool DIRECT = false,
           int STAGES = DIRECT ? 3 : 4>
 LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
@@ -183,7 +183,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // fills it in 1-KiB pieces (64 rows of one half) with one LDS-DMA instruction each.
   constexpr int A_PIECES = BM / 32;
   static_assert(BM % 64 == 0 && BN % 64 == 0, "tiles are filled in 64-row pieces");
-  static_assert(!BITS || DIRECT, "the bit halo is a form of the direct variant");
 
 #ifdef LCE_TIMELINE
   const uint32_t tl_lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
@@ -392,15 +391,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           if (e0 == 0 && k == 1) LCE_PH(11);
 #endif
           if (pixv[k] < 0) continue;
-          if constexpr (BITS) {
-            // bit halo: the raw words, one pixel every PS = 4*Cw + 4 bytes (an odd number of dwords, so the
-            // 32 pixels a fragment read touches fall on 32 different banks)
-            uint8_t* dstb = lds0 + (size_t)pixv[k] * G.PS + c0v[k] * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (FAST || c0v[k] + q < G.Cw) *(uint32_t*)(dstb + q * 4) = wv[k][q];
-            continue;
-          }
           uint8_t* dst = lds0 + (size_t)pixv[k] * G.PS + c0v[k] * 16;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -430,11 +420,11 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       p -= li * G.OHOW;
       const int oy = (int)fastdiv((uint32_t)p, A.div_ow);
       const int ox = p - oy * A.OW;
-      a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * (BITS ? 4 : 16));
+      a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
     }
   }
   LCE_PH(1);
-  constexpr uint32_t kAStep = BITS ? 8u : 32u;   // bytes of halo per K-step and pixel: 2 words, or 64 FP4 codes
+  constexpr uint32_t kAStep = 32u;               // bytes of halo per K-step and pixel: 64 FP4 codes
   const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * kAStep;
   const uint32_t c_step_fy = (uint32_t)((A.DH * G.Wp - A.KW * A.DW) * G.PS);
 
@@ -448,7 +438,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     c_fx = wrap_fx ? 0 : c_fx;
     a_cur += kAStep + (wrap_kc ? c_step_fx : 0u) + (wrap_fx ? c_step_fy : 0u);
   };
-  // load_a / load_raw / load_b are always called for consecutive K-steps (0, 1, 2, ...), once each;
+  // load_a / load_b are always called for consecutive K-steps (0, 1, 2, ...), once each;
   // `stage` = ks % STAGES
   auto load_a = [&](int stage, u32x4 (&af)[WM]) LCE_LAMBDA_INLINE {
     if constexpr (DIRECT) {
@@ -462,25 +452,12 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         af[i] = *(const u32x4*)(base + half * (BM * 16) + ((wm * WM + i) * 32 + l31) * 16);
     }
   };
-  // bit halo: a fragment is ONE raw word per lane (the 32 channels of its k-half), expanded to FP4 in
-  // registers (17 VALU) -- a quarter of the LDS bytes of a 16-byte fragment read, and the halo itself is
-  // a quarter of the FP4 one, which is what lets four blocks share a CU
-  auto load_raw = [&](uint32_t (&raw)[WM]) LCE_LAMBDA_INLINE {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) raw[i] = *(const uint32_t*)(lds0 + (a_base[i] + a_cur));
-    advance_a();
-  };
-  auto expand_raw = [&](const uint32_t (&raw)[WM], u32x4 (&af)[WM]) LCE_LAMBDA_INLINE {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) af[i] = fp4_of_full_word(raw[i]);
-  };
   auto load_b = [&](int stage, u32x4 (&bf)[WN]) LCE_LAMBDA_INLINE {
     const uint8_t* base = lds + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < WN; ++j)
       bf[j] = *(const u32x4*)(base + A_BYTES + half * (BN * 16) + ((wn * WN + j) * 32 + l31) * 16);
   };
-  uint32_t rawp[WM];   // bit halo: the raw words of the NEXT step's A fragments (read one step ahead of their expansion)
   // One K-step.  `steady` (compile-time) = the ring is full: a refill is due and exactly
   // STAGES-1 younger fills are in flight, so the wait count is exact and nothing branches.
   // fs = ks % STAGES (the stage this step vacates and refills), rs = (ks + 1) % STAGES (the stage
@@ -500,12 +477,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       block_barrier_keep_vm();
       if (ks + STAGES < KS) fill(fs);
       if (ks + 1 < KS) {
-        if constexpr (BITS) {
-          expand_raw(rawp, af_next);
-          if (ks + 2 < KS) load_raw(rawp);
-        } else {
-          load_a(rs, af_next);
-        }
+        load_a(rs, af_next);
         load_b(rs, bf_next);
       }
     }
@@ -519,12 +491,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       // issues (LDS-DMA, ds_read) overlap the MFMAs' execution instead of preceding it
       fill(fs);                                  // step ks+STAGES into the stage just vacated
 #ifndef LCE_ABL_NOFRAG   // timing ablation (results are wrong): no fragment reads in the steady K-step
-      if constexpr (BITS) {
-        expand_raw(rawp, af_next);               // step ks+1's words arrived a step ago ...
-        load_raw(rawp);                          // ... and step ks+2's are on their way (the halo does not change)
-      } else {
-        load_a(rs, af_next);
-      }
+      load_a(rs, af_next);
       load_b(rs, bf_next);
 #endif
       interleave_step<WM * WN, WM + WN, NP>();
@@ -542,14 +509,8 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   else wait_vmcnt<0>();
   block_barrier_keep_vm();
   u32x4 af0[WM], bf0[WN], af1[WM], bf1[WN];
-  if constexpr (BITS) {
-    load_raw(rawp);            // K-step 0
-    expand_raw(rawp, af0);
-    if (KS > 1) load_raw(rawp);   // K-step 1
-  } else {
-    load_a(0, af0);
-  }
-  load_b(0, bf0);              // stage 0 = K-step 0
+  load_a(0, af0);              // stage 0 = K-step 0
+  load_b(0, bf0);
   LCE_PH(2);
   // Steady loop, unrolled over one full cycle of (fragment-set parity) x (ring position) so that
   // every stage index is a literal -- no `% STAGES` arithmetic in the K-step.
@@ -682,9 +643,10 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
           buf_store_streaming(ro, lane_off + (uint32_t)((wm * WM + i) * 32 + (k0 + k) * RPI) * row_bytes, y[k]);
-#ifdef LCE_STORE_PACE   // experiment: spread the stores of the epilogue out in time
-          __builtin_amdgcn_s_sleep(LCE_STORE_PACE);
-#endif
+          // pace the burst: 128 KiB per block pushed out back to back fills the CU's memory pipeline and
+          // the co-resident block's weight DMAs queue behind it (its K loop 18.7k -> 16.4k cycles with the
+          // pause, L0 float -2.5 %, tools/phases.py); the sleeping wave also leaves its issue slots to it
+          yield_issue_slots<2>();
         }
       }
       wave_lds_fence();

@@ -290,14 +290,8 @@ static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
 // Direct variant: geometry of a BM-pixel tile and whether its input halo (plus the weight ring)
 // fits LDS.  Images of at most BM/2 pixels are tiled IPT whole images at a time, larger ones
 // in BM-pixel pieces of ONE image.
-bool bits_supported(const HostPlan& p, const MfmaCfg& c) {
-  // every K-step is two FULL words per pixel, out-of-image taps are the bit value 0 (= +1: one-padding, or
-  // VALID where there are none), and the kernel instances exist for the 4-wave-or-fewer tiles only
-  return mfma_supported(p) && p.d.channels_in % 64 == 0 && p.zero_pad_mode == kZeroPadNone && c.threads() <= 256;
-}
-
 bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
-                     int* ipt, int lds_budget, bool bits) {
+                     int* ipt, int lds_budget) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!mfma_supported(p)) return false;
   const int cpad = ceil_div(d.channels_in, 64) * 64;
@@ -305,8 +299,7 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
                                        (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
   const int bm = c.bm(), ohow = p.out_h * p.out_w;
   const int64_t ring = (int64_t)MfmaCfg::kDirectStages * c.bn() * 32;
-  // bytes per halo pixel: FP4 codes + 16 (bank stagger), or the raw words + 4 (an odd number of dwords)
-  const int64_t stride = bits ? (int64_t)p.cw * 4 + 4 : (cpad / 32) * 16 + 16;
+  const int64_t stride = (cpad / 32) * 16 + 16;
   int images = 1;
   int64_t rows;
   if (ohow * 2 <= bm) {
@@ -390,7 +383,7 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   // the wide int8 epilogue transposes WN tiles at once: only where the block's LDS allocation
   // already covers waves * WN * 4 KiB (it must not cost a resident block)
   {
-    const int lds = p.use_direct ? p.mfma.direct_lds_bytes(p.halo_bytes, p.use_bits) : p.mfma.lds_bytes();
+    const int lds = p.use_direct ? p.mfma.direct_lds_bytes(p.halo_bytes) : p.mfma.lds_bytes();
     const bool room = (p.mfma.threads() / 64) * p.mfma.wn * 4096 <= lds;
     G.i8_wide = (p.d.dst_type == LCE_HIP_I8 && p.d.channels_out % 16 == 0 && room) ? 1 : 0;
     // float: same joint transpose (one LDS fence pair per 32-row block instead of one per tile);
@@ -401,7 +394,7 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   }
   if (p.use_direct) {
     G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;
-    G.halo_bytes = p.halo_bytes; G.QG = p.use_bits ? (p.cw + 3) / 4 : (G.CPW + 3) / 4;
+    G.halo_bytes = p.halo_bytes; G.QG = (G.CPW + 3) / 4;
     G.IPT = p.ipt; G.B = batch_chunk; G.HPIX = p.halo_rows * p.wp;
     G.div_tpi = make_fastdiv((uint32_t)G.TPI);
     G.div_qg = make_fastdiv((uint32_t)G.QG);
@@ -419,7 +412,6 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
   // ---- engine: matrix cores vs xor-popcount VALU ----
   p.use_mfma = false;
   p.use_direct = false;
-  p.use_bits = false;
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (grouped, or too deep)";
   if (p.engine_pref >= 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
@@ -427,18 +419,12 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     p.use_mfma = true;
     p.use_tiled = false;
     MfmaCfg want = choose_mfma_cfg(p, pixels);
-    bool direct = false, bits = false;
+    bool direct = false;
     if (p.engine_pref >= 2 && p.tile_pref.tm != 0) {
       const MfmaCfg* forced = mfma_cfg_by_tile(p.tile_pref.tm, p.tile_pref.tn);
       if (!forced) return "bconv2d: no matrix-core kernel instance for the requested block tile";
       want = *forced;
-      direct = p.engine_pref >= 3;
-      bits = p.engine_pref == 4;
-    } else if (p.engine_pref == 4) {
-      // forced bit halo without a tile: the largest 4-wave tile for the channel count
-      const MfmaCfg* c = mfma_cfg_by_tile(d.channels_out > 64 ? 128 : 256, d.channels_out > 64 ? 128 : 64);
-      want = *c;
-      direct = bits = true;
+      direct = p.engine_pref == 3;
     } else if (p.engine_pref != 2) {
       // auto / engine=direct without a tile: the direct variant when a good tile exists
       MfmaCfg dc;
@@ -464,17 +450,14 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     p.wp = (int)std::max<int64_t>(p.pad_w + d.in_width,
                                   (int64_t)(p.out_w - 1) * d.stride_width + (d.filter_width - 1) * d.dilation_width + 1);
     if (repack && p.have_weights) pack_for_mfma(p);
-    if (bits && (!bits_supported(p, want) || p.zero_pad_mode == kZeroPadCorrection))
-      return "bconv2d: the bit-halo variant needs channels_in % 64 == 0, VALID or one-padding, and a 4-wave tile";
     if (direct) {
       if (!direct_geometry(p, want, &p.tpi, &p.halo_rows, &p.ps, &p.halo_bytes, &p.ipt,
-                           p.engine_pref >= 3 ? kDirectLdsMax : kDirectLdsAuto, bits))
+                           p.engine_pref == 3 ? kDirectLdsMax : kDirectLdsAuto))
         return "bconv2d: the direct matrix-core variant cannot hold this tile's input halo in LDS";
       p.use_direct = true;
-      p.use_bits = bits;
     }
     char nm[96];
-    snprintf(nm, sizeof nm, "bconv2d_mfma%s<%s,%dx%d>", p.use_bits ? "_bits" : p.use_direct ? "_direct" : "",
+    snprintf(nm, sizeof nm, "bconv2d_mfma%s<%s,%dx%d>", p.use_direct ? "_direct" : "",
              d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", want.bm(), want.bn());
     p.kernel_name = nm;
     return "";

@@ -26,10 +26,8 @@ struct MfmaCfg {
   static constexpr int kStages = 4;        // LDS ring depth of bconv2d_mfma (A + B per stage)
   static constexpr int kDirectStages = 3;  // ... of its direct variant (B only; the halo is extra)
   int lds_bytes() const { return kStages * (bm() + bn()) * 32; }
-  // wide_scratch: also room for the joint-transpose epilogues (waves x WN x 4 KiB); the bit-halo variant asks
-  // for it because its halo is small enough that the extra LDS does not cost a resident block
-  int direct_lds_bytes(int halo_bytes, bool wide_scratch = false) const {
-    const int need = halo_bytes + kDirectStages * bn() * 32, scratch = (threads() / 64) * 4096 * (wide_scratch ? wn : 1);
+  int direct_lds_bytes(int halo_bytes) const {
+    const int need = halo_bytes + kDirectStages * bn() * 32, scratch = (threads() / 64) * 4096;
     return need > scratch ? need : scratch;
   }
 };
@@ -62,9 +60,8 @@ struct HostPlan {
   std::string kernel_name;
 
   // matrix-core engine (lce_kernels_mfma.h)
-  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (FP4 LDS halo), 4 bits (bit LDS halo)
+  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo)
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
-  bool use_bits = false;                   // with use_direct: the halo holds raw bits, A fragments are expanded in registers
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   int epilogue_pref = 0;                   // float/int8 epilogue: 0 auto, 1 per-tile transpose, 2 joint transpose
@@ -105,9 +102,7 @@ bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out);
 constexpr int kDirectLdsMax = 160 * 1024;   // one block per CU
 constexpr int kDirectLdsAuto = 80 * 1024;   // two blocks per CU: what the auto rule requires
 bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
-                     int* ipt, int lds_budget, bool bits = false);
-// Can the bit-halo variant run this convolution?  (whole 64-channel K-steps, padding that is a bit value)
-bool bits_supported(const HostPlan& p, const MfmaCfg& c);
+                     int* ipt, int lds_budget);
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 

@@ -123,14 +123,14 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
     if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
-                             h.use_direct, h.use_bits);
+                             h.use_direct);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const MfmaArgs G = make_mfma_args(h, nb);
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
       if (h.use_direct) {
-        launch_block_lockstep(h.ipt > 1 ? (nb + h.ipt - 1) / h.ipt : nb * h.tpi, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.direct_lds_bytes(h.halo_bytes, h.use_bits), [&] {
+        launch_block_lockstep(h.ipt > 1 ? (nb + h.ipt - 1) / h.ipt : nb * h.tpi, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.direct_lds_bytes(h.halo_bytes), [&] {
           fn(A, G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
         });
         continue;

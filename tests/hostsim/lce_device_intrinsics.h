@@ -162,6 +162,7 @@ template <int N> inline void wait_vmcnt() {     // retire the oldest pieces unti
 }
 inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
 inline void pin(f32x16&) {}
+template <int N> inline void yield_issue_slots() {}
 template <int N> inline void interleave_mfma_ldsread() {}
 template <int NMFMA, int NDS, int NVMEM> inline void interleave_step() {}
 inline void store_streaming(f32x4* p, f32x4 v) { *p = v; }

@@ -70,7 +70,7 @@ def bconv2d(spec: O.ConvSpec, dst_type: int, inp, filt, post_mul=None, post_bias
     d = make_desc(spec, dst_type, out_scale, out_zero_point)
     rc = lib().hostsim_bconv2d(C.byref(d), _p(filt), _p(mul), _p(bias), _p(thr), _p(inp), _p(out),
                                {"auto": 0, "tiled": 1, "general": 2}[kernel], tile[0], tile[1],
-                               max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3, "bits": 4}[engine])
+                               max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3}[engine])
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
     return out, name.value.decode()

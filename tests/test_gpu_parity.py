@@ -661,15 +661,3 @@ def test_two_plans_on_two_streams_from_two_threads():
         t.join()
     assert not errors, errors
 
-
-@pytest.mark.parametrize("tile", ["128x256", "128x128", "256x64", "128x64"])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 40), (256, 256), (192, 130), (512, 96)])
-@pytest.mark.parametrize("pad", ["VALID", "ONE"])
-def test_conv_bit_halo_variant(tile, cin, cout, pad):
-    """The bit-halo variant of the matrix-core engine (raw words in LDS, A fragments expanded in registers):
-    every tile, 1 to 8 K-steps per tap, strides / dilation, partial last tiles, all output types."""
-    padding, pv = PADS[pad]
-    for st, dil, act in [((1, 1), (1, 1), O.ACT_NONE), ((2, 1), (1, 2), O.ACT_RELU)]:
-        spec = O.ConvSpec(3, 19, 23, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pv, act)
-        names = _check_all_dst(spec, cin * 7 + cout, tile=tile, engine="bits")
-        assert all(n.startswith("bconv2d_mfma_bits<") and ("," + tile + ">") in n for n in names), names

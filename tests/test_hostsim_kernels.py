@@ -268,34 +268,6 @@ def test_mfma_direct_variant(tile, cin, cout, pad):
         assert all("bconv2d_mfma_direct" in n and ",%dx%d>" % tile in n for n in names), names
 
 
-@pytest.mark.parametrize("tile", [(128, 64), (128, 128), (256, 64), (128, 256)], ids=lambda t: "%dx%d" % t)
-@pytest.mark.parametrize("cin,cout,pad", [(64, 64, "ONE"), (128, 33, "VALID"), (192, 70, "ONE"), (256, 130, "ONE")])
-def test_mfma_bit_halo_variant(tile, cin, cout, pad):
-    """The bit-halo variant (raw words in LDS, A fragments expanded in registers a step ahead):
-    several tiles per image with a partial last one, tiles that start mid-row, strides, dilation,
-    1 to 4 K-steps per tap, channel counts that do not fill the block."""
-    padding, pad_values = PADS[pad]
-    for st, dil, act in [((1, 1), (1, 1), O.ACT_NONE), ((2, 1), (1, 2), O.ACT_RELU)]:
-        spec = O.ConvSpec(2, 15, 13, cin, 3, 3, cout, 1, st[0], st[1], dil[0], dil[1], padding, pad_values, act)
-        names = _run_all_dst_mfma(spec, seed=cin * 3 + cout, tile=tile, engine="bits")
-        assert all("bconv2d_mfma_bits" in n and ",%dx%d>" % tile in n for n in names), names
-
-
-def test_mfma_bit_halo_variant_shapes():
-    # pointwise (one K-step per chunk, no taps), a single K-step in all, whole small images per tile, batch chunking
-    _run_all_dst_mfma(O.ConvSpec(3, 9, 17, 128, 1, 1, 32), 51, tile=(128, 64), engine="bits", max_batch=2)
-    _run_all_dst_mfma(O.ConvSpec(2, 6, 5, 64, 1, 1, 64), 52, tile=(128, 64), engine="bits")
-    _run_all_dst_mfma(O.ConvSpec(5, 7, 7, 64, 3, 3, 40, padding=O.PADDING_SAME, pad_values=1), 53, tile=(128, 64), engine="bits")
-    _run_all_dst_mfma(O.ConvSpec(9, 5, 4, 64, 3, 3, 32, padding=O.PADDING_SAME, pad_values=1), 54, tile=(128, 64),
-                      engine="bits", max_batch=4)
-    # what it must refuse: ragged channel counts, zero padding of either semantics
-    for spec in (O.ConvSpec(1, 8, 8, 96, 3, 3, 32), O.ConvSpec(1, 8, 8, 64, 3, 3, 32, padding=O.PADDING_SAME, pad_values=0,
-                                                              semantics=O.SEM_REFERENCE)):
-        x, w, mul, bias = synth.conv_inputs(spec, 1)
-        with pytest.raises(RuntimeError, match="bit-halo variant needs"):
-            H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="bits")
-
-
 def test_mfma_direct_variant_shapes():
     # 1x1 filter, 5x5 filter with asymmetric SAME padding (even input, stride 2), batch chunking
     _run_all_dst_mfma(O.ConvSpec(3, 9, 17, 64, 1, 1, 32), 21, tile=(128, 64), engine="direct", max_batch=2)
