@@ -33,12 +33,13 @@ SEM_REFERENCE, SEM_OPTIMIZED = 0, 1
 ABI_SYMBOLS = (
     "lce_hip_abi_version", "lce_hip_last_error", "lce_hip_device_count", "lce_hip_set_device",
     "lce_hip_malloc", "lce_hip_free", "lce_hip_memcpy_h2d", "lce_hip_memcpy_d2h", "lce_hip_memset",
+    "lce_hip_host_register", "lce_hip_host_unregister",
     "lce_hip_stream_create", "lce_hip_stream_destroy", "lce_hip_stream_synchronize",
     "lce_hip_bitpacked_size", "lce_hip_bitpack", "lce_hip_unpack",
     "lce_hip_bconv2d_plan_create", "lce_hip_bconv2d_plan_destroy", "lce_hip_bconv2d_plan_output_shape",
     "lce_hip_bconv2d_plan_padding", "lce_hip_bconv2d_plan_set_weights", "lce_hip_bconv2d_plan_folded",
     "lce_hip_bconv2d_plan_set_option", "lce_hip_bconv2d_plan_kernel_name", "lce_hip_bconv2d_run",
-    "lce_hip_bconv2d_run_host", "lce_hip_bmaxpool_output_shape", "lce_hip_bmaxpool",
+    "lce_hip_bconv2d_run_dual", "lce_hip_bconv2d_plan_device", "lce_hip_bconv2d_run_host", "lce_hip_bmaxpool_output_shape", "lce_hip_bmaxpool",
     "lce_hip_prepare_binary_filter", "lce_hip_prepare_fuse_post_op", "lce_hip_prepare_can_fuse_activation",
     "lce_hip_prepare_bitpacked_output", "lce_hip_prepare_bitpack_filter",
 )
@@ -87,6 +88,10 @@ def lib() -> C.CDLL:
         l.lce_hip_bconv2d_plan_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         l.lce_hip_bconv2d_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.lce_hip_bconv2d_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.lce_hip_bconv2d_run_dual.argtypes = [C.c_void_p] * 5
+        l.lce_hip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        l.lce_hip_host_unregister.argtypes = [C.c_void_p]
+        l.lce_hip_bconv2d_plan_device.argtypes = [C.c_void_p]
         l.lce_hip_bitpack.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int32,
                                       C.c_void_p, C.c_void_p]
         l.lce_hip_unpack.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
@@ -189,6 +194,15 @@ class Bconv2dPlan:
         m = None if post_mul is None else np.ascontiguousarray(post_mul, np.float32)
         b = None if post_bias is None else np.ascontiguousarray(post_bias, np.float32)
         t = None if thresholds is None else np.ascontiguousarray(thresholds, np.int32)
+        p = self.params
+        if hasattr(p, "filter_height"):   # (a plan adopted from a handle carries no descriptor: the C side owns it)
+            # the C ABI reads exactly this many elements from the raw pointers
+            want = p.channels_out * p.filter_height * p.filter_width * bitpacked_size(p.channels_in // max(1, p.groups))
+            if f.size != want:
+                raise ValueError(f"filter has {f.size} words, the plan needs Cout*KH*KW*ceil(Cin/G/32) = {want}")
+            for name, a in (("post_activation_multiplier", m), ("post_activation_bias", b), ("thresholds", t)):
+                if a is not None and a.size != p.channels_out:
+                    raise ValueError(f"{name} has {a.size} entries, the plan needs channels_out = {p.channels_out}")
         check(lib().lce_hip_bconv2d_plan_set_weights(self._h, _host_ptr(f), _host_ptr(m),
                                                      _host_ptr(b), _host_ptr(t)))
 
@@ -211,25 +225,87 @@ class Bconv2dPlan:
         check(lib().lce_hip_bconv2d_run(self._h, C.c_void_p(input_dev), C.c_void_p(output_dev),
                                         C.c_void_p(stream)))
 
+    def device(self) -> int:
+        """The HIP device the plan's buffers live on (-1 before the first run)."""
+        return lib().lce_hip_bconv2d_plan_device(self._h)
+
+    def _check_input(self, x):
+        import torch
+        assert x.is_cuda and x.dtype == torch.int32 and x.is_contiguous()
+        p = self.params
+        if hasattr(p, "in_height"):
+            want = (p.batch, p.in_height, p.in_width, bitpacked_size(p.channels_in))
+            if tuple(x.shape) != want:
+                raise ValueError(f"input shape {tuple(x.shape)} does not match the plan's {want}")
+
+    def _out(self, x, out, dtype):
+        import torch
+        if out is None:
+            return torch.empty(self.output_shape, dtype=dtype, device=x.device)
+        assert out.is_cuda and out.device == x.device and out.dtype == dtype and out.is_contiguous()
+        if tuple(out.shape) != tuple(self.output_shape):
+            raise ValueError(f"output shape {tuple(out.shape)} does not match the plan's {tuple(self.output_shape)}")
+        return out
+
     def run(self, x, out=None, stream: int | None = None):
         """x: CUDA int32 tensor [B,H,W,ceil(Cin/32)]; returns / fills the output tensor."""
         import torch
-        assert x.is_cuda and x.dtype == torch.int32 and x.is_contiguous()
-        if out is None:
-            dt = {F32: torch.float32, I8: torch.int8, BITPACKED: torch.int32}[self.params.dst_type]
-            out = torch.empty(self.output_shape, dtype=dt, device=x.device)
-        if stream is None:
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-        self.run_ptr(x.data_ptr(), out.data_ptr(), stream)
+        self._check_input(x)
+        out = self._out(x, out, {F32: torch.float32, I8: torch.int8, BITPACKED: torch.int32}[self.params.dst_type])
+        with torch.cuda.device(x.device):   # the plan's buffers land on (and must stay on) the tensor's device
+            if stream is None:
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+            self.run_ptr(x.data_ptr(), out.data_ptr(), stream)
         return out
 
-    def run_host(self, x_np):
+    def run_dual(self, x, out=None, out_bits=None, stream: int | None = None):
+        """Float output AND its LceQuantize (sign bits, [B,OH,OW,ceil(Cout/32)] int32) in one pass."""
+        import torch
+        self._check_input(x)
+        out = self._out(x, out, torch.float32)
+        b, oh, ow, n = self.output_shape
+        if out_bits is None:
+            out_bits = torch.empty((b, oh, ow, bitpacked_size(n)), dtype=torch.int32, device=x.device)
+        assert out_bits.is_cuda and out_bits.dtype == torch.int32 and out_bits.is_contiguous()
+        if tuple(out_bits.shape) != (b, oh, ow, bitpacked_size(n)):
+            raise ValueError(f"bit output shape {tuple(out_bits.shape)} does not match {(b, oh, ow, bitpacked_size(n))}")
+        with torch.cuda.device(x.device):
+            if stream is None:
+                stream = torch.cuda.current_stream(x.device).cuda_stream
+            check(lib().lce_hip_bconv2d_run_dual(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(out_bits.data_ptr()), C.c_void_p(stream)))
+        return out, out_bits
+
+    def run_host(self, x_np, out=None):
+        """Host (NumPy) tensors through H2D | kernel | D2H; pass page-locked arrays (``host_register``) and an
+        ``out`` to reuse for fully overlapped copies."""
         import numpy as np
         x = np.ascontiguousarray(x_np, np.int32)
         dt = {F32: np.float32, I8: np.int8, BITPACKED: np.int32}[self.params.dst_type]
-        out = np.empty(self.output_shape, dt)
+        if out is None:
+            out = np.empty(self.output_shape, dt)
+        assert out.dtype == dt and out.flags.c_contiguous and tuple(out.shape) == tuple(self.output_shape)
         check(lib().lce_hip_bconv2d_run_host(self._h, _host_ptr(x), _host_ptr(out)))
         return out
+
+
+class host_register:
+    """``with host_register(a, b): ...`` page-locks the NumPy arrays for the duration of the block."""
+
+    def __init__(self, *arrays):
+        self.arrays = arrays
+
+    def __enter__(self):
+        self.done = []
+        for a in self.arrays:
+            check(lib().lce_hip_host_register(_host_ptr(a), C.c_size_t(a.nbytes)))
+            self.done.append(a)
+        return self
+
+    def __exit__(self, *exc):
+        for a in self.done:
+            lib().lce_hip_host_unregister(_host_ptr(a))
+        return False
 
 
 def bitpack(x, zero_point: int = 0, out=None, stream: int | None = None):
@@ -241,10 +317,11 @@ def bitpack(x, zero_point: int = 0, out=None, stream: int | None = None):
     rows = x.numel() // cols if cols else 0
     if out is None:
         out = torch.empty(tuple(x.shape[:-1]) + (bitpacked_size(cols),), dtype=torch.int32, device=x.device)
-    if stream is None:
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-    check(lib().lce_hip_bitpack(t, C.c_void_p(x.data_ptr()), rows, cols, int(zero_point),
-                                C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    with torch.cuda.device(x.device):
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        check(lib().lce_hip_bitpack(t, C.c_void_p(x.data_ptr()), rows, cols, int(zero_point),
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
     return out
 
 
@@ -255,10 +332,11 @@ def unpack(words, channels: int, dtype, scale: float = 1.0, zero_point: int = 0,
     t = {torch.float32: F32, torch.int8: I8, torch.bool: BOOL}[dtype]
     rows = words.numel() // words.shape[-1]
     out = torch.empty(tuple(words.shape[:-1]) + (channels,), dtype=dtype, device=words.device)
-    if stream is None:
-        stream = torch.cuda.current_stream(words.device).cuda_stream
-    check(lib().lce_hip_unpack(t, C.c_void_p(words.data_ptr()), rows, channels, float(scale),
-                               int(zero_point), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    with torch.cuda.device(words.device):
+        if stream is None:
+            stream = torch.cuda.current_stream(words.device).cuda_stream
+        check(lib().lce_hip_unpack(t, C.c_void_p(words.data_ptr()), rows, channels, float(scale),
+                                   int(zero_point), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
     return out
 
 
@@ -271,11 +349,12 @@ def bmaxpool(x, filter_height, filter_width, stride_height, stride_width, paddin
     check(lib().lce_hip_bmaxpool_output_shape(h, w, filter_height, filter_width, stride_height,
                                               stride_width, padding, C.byref(oh), C.byref(ow)))
     out = torch.empty((b, oh.value, ow.value, c), dtype=torch.int32, device=x.device)
-    if stream is None:
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-    check(lib().lce_hip_bmaxpool(C.c_void_p(x.data_ptr()), b, h, w, c, filter_height, filter_width,
-                                 stride_height, stride_width, padding, C.c_void_p(out.data_ptr()),
-                                 C.c_void_p(stream)))
+    with torch.cuda.device(x.device):
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        check(lib().lce_hip_bmaxpool(C.c_void_p(x.data_ptr()), b, h, w, c, filter_height, filter_width,
+                                     stride_height, stride_width, padding, C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(stream)))
     return out
 
 

@@ -52,7 +52,7 @@ inline general_fn find_general(int dst) {
 
 
 typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const uint8_t*, const float*,
-                        const float*, const float*, const float*, void*);
+                        const float*, const float*, const float*, void*, uint32_t*);
 
 // CORR = the optimized kernels' SAME-zero float correction in the epilogue (float output only)
 // DIRECT = LDS-resident input halo instead of the FP4 workspace (lce_kernels_mfma.h)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/lce_hip.h"
 #include "lce_kernels.h"
@@ -37,15 +38,20 @@ lce_hip_status fail(lce_hip_status code, const char* fmt, ...) {
                   "%s failed: %s", #expr, hipGetErrorString(e_));                          \
   } while (0)
 
+// Asked once per process (the answer cannot change while it runs): the run / bitpack entry points are
+// called per layer on 10-30 us kernels and must not pay a runtime query each time.
 lce_hip_status require_device() {
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) {
-    (void)hipGetLastError();
+  static const int count = [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+      (void)hipGetLastError();
+      n = 0;
+    }
+    return n;
+  }();
+  if (count <= 0)
     return fail(LCE_HIP_ERR_NO_DEVICE,
-                "no usable HIP device (hipGetDeviceCount: %s, count %d); this library has no CPU "
-                "fallback", hipGetErrorString(e), n);
-  }
+                "no usable HIP device (hipGetDeviceCount found %d); this library has no CPU fallback", count);
   return LCE_HIP_OK;
 }
 
@@ -88,14 +94,29 @@ struct lce_hip_bconv2d_plan {
   DevBuf<int32_t> d_thr, d_oobc;
   DevBuf<uint8_t> d_wq;
   DevBuf<float> d_thrq;
-  void* workspace = nullptr;       // FP4 expanded activations (matrix-core engine)
+  int device = -1;                 // the HIP device the plan's buffers live on (bound at the first upload)
+  void* workspace = nullptr;       // FP4 expanded activations (matrix-core engine, workspace variant)
   void* lds_opt_in = nullptr;      // kernel already granted > 64 KiB of dynamic LDS
   size_t workspace_bytes = 0;
-  // staging for run_host
+  // The workspace is ONE buffer per plan: a run on another stream must not start expanding into it while
+  // the previous run's GEMM still reads it.  ws_done is recorded behind every workspace GEMM; a run on a
+  // different stream waits for it first.
+  hipEvent_t ws_done = nullptr;
+  hipStream_t ws_stream = nullptr;
+  bool ws_used = false;
+  // run_host: device staging + a three-stream pipeline (H2D | compute | D2H) over batch slices
   void* stage_in = nullptr;
   void* stage_out = nullptr;
   size_t stage_in_bytes = 0, stage_out_bytes = 0;
+  hipStream_t s_h2d = nullptr, s_run = nullptr, s_d2h = nullptr;
+  std::vector<hipEvent_t> ev_in, ev_run;
   ~lce_hip_bconv2d_plan() {
+    for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_run) (void)hipEventDestroy(e);
+    if (s_h2d) (void)hipStreamDestroy(s_h2d);
+    if (s_run) (void)hipStreamDestroy(s_run);
+    if (s_d2h) (void)hipStreamDestroy(s_d2h);
+    if (ws_done) (void)hipEventDestroy(ws_done);
     if (stage_in) (void)hipFree(stage_in);
     if (stage_out) (void)hipFree(stage_out);
     if (workspace) (void)hipFree(workspace);
@@ -125,6 +146,20 @@ lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
   if (!err.empty()) return fail(LCE_HIP_ERR_UNSUPPORTED, "%s", err.c_str());
   plan->selected_for_pixels = pixels;
   plan->device_current = false;
+  return LCE_HIP_OK;
+}
+
+// A plan's weights, tables, workspace and staging live on ONE device: the one that is current when it first
+// runs.  Running it with another device current would launch on that device with foreign pointers.
+lce_hip_status check_device(lce_hip_bconv2d_plan* plan) {
+  int cur = -1;
+  LCE_HIP_TRY(hipGetDevice(&cur));
+  if (plan->device < 0) plan->device = cur;
+  if (plan->device != cur)
+    return fail(LCE_HIP_ERR_INVALID,
+                "bconv2d: this plan is bound to HIP device %d but device %d is current (a plan's buffers live on "
+                "the device it first ran on; make that device current or create one plan per device)",
+                plan->device, cur);
   return LCE_HIP_OK;
 }
 
@@ -201,6 +236,16 @@ lce_hip_status lce_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void
 }
 lce_hip_status lce_hip_memset(void* dst, int value, size_t bytes, void* stream) {
   LCE_HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_host_register(void* host_ptr, size_t bytes) {
+  if (!host_ptr || !bytes) return fail(LCE_HIP_ERR_INVALID, "lce_hip_host_register: null or empty range");
+  if (lce_hip_status s = require_device()) return s;
+  LCE_HIP_TRY(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_host_unregister(void* host_ptr) {
+  if (host_ptr) LCE_HIP_TRY(hipHostUnregister(host_ptr));
   return LCE_HIP_OK;
 }
 lce_hip_status lce_hip_stream_create(void** stream) {
@@ -434,33 +479,38 @@ const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan) {
   return plan->host.kernel_name.c_str();
 }
 
-lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, void* output_dev, void* stream) {
-  if (!plan) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: null argument");
+// Images [first, first + count) of the plan's batch; input_dev / output_dev / sign_dev point at image 0.
+// sign_dev (float output only, may be null): the LceQuantize of the output, written by the same epilogue
+// when the kernel variant can do it, otherwise by a bitpack launch behind it.
+static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, void* output_dev,
+                                 int32_t* sign_dev, int first, int count, hipStream_t st) {
   lce::HostPlan& h = plan->host;
-  if (!h.have_weights) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: plan_set_weights was not called");
-  if (h.d.batch == 0) return LCE_HIP_OK;   // empty batch: tensors may legitimately be null
-  if (!input_dev || !output_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: null argument");
-  if (lce_hip_status s = require_device()) return s;
   const int chunk = lce::max_batch_per_launch(h);
   if (lce_hip_status s = ensure_selected(plan, chunk)) return s;
+  if (lce_hip_status s = check_device(plan)) return s;
   if (lce_hip_status s = ensure_uploaded(plan)) return s;
-  hipStream_t st = (hipStream_t)stream;
 
   const size_t in_img_words = (size_t)h.d.in_height * h.d.in_width * h.cw;
   const size_t out_row = h.d.dst_type == LCE_HIP_BITPACKED ? (size_t)h.wout : (size_t)h.d.channels_out;
   const size_t out_img_bytes = (size_t)h.out_h * h.out_w * out_row * out_elem_bytes(h.d.dst_type);
+  const size_t sign_img_words = (size_t)h.out_h * h.out_w * h.wout;
 
-  for (int b0 = 0; b0 < h.d.batch; b0 += chunk) {
-    const int nb = std::min(chunk, h.d.batch - b0);
+  for (int b0 = first; b0 < first + count; b0 += chunk) {
+    const int nb = std::min(chunk, first + count - b0);
     ConvArgs A = lce::make_conv_args(h, nb);
     const uint32_t* in = (const uint32_t*)input_dev + (size_t)b0 * in_img_words;
     void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
+    uint32_t* sgn = sign_dev ? (uint32_t*)sign_dev + (size_t)b0 * sign_img_words : nullptr;
+    bool sign_fused = false;
     if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
+      // the joint-transpose float epilogue is the one that can also emit the sign words
+      sign_fused = sgn && G.f32_wide && h.zero_pad_mode != lce::kZeroPadCorrection && ((uintptr_t)out & 15) == 0;
+      uint32_t* ksgn = sign_fused ? sgn : nullptr;
       if (h.use_direct) {
         // no workspace: every block expands its own input halo into LDS
         const size_t lds = (size_t)h.mfma.direct_lds_bytes(h.halo_bytes);
@@ -470,28 +520,39 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
         }
         const dim3 grid((unsigned)(h.ipt > 1 ? (nb + h.ipt - 1) / h.ipt : (int64_t)nb * h.tpi), (unsigned)(h.npad / bn));
         hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), lds, st, A, G, (const uint8_t*)in, plan->d_wq.ptr,
-                           plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_zpc.ptr, out);
+                           plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_zpc.ptr, out, ksgn);
         LCE_HIP_TRY(hipGetLastError());
-        continue;
+      } else {
+        const size_t ws = lce::mfma_workspace_bytes(h, nb);
+        if (plan->ws_used && plan->ws_stream != st) LCE_HIP_TRY(hipStreamWaitEvent(st, plan->ws_done, 0));
+        if (plan->workspace_bytes < ws) {
+          // a larger workspace: the old one may still be read by a run in flight on another stream
+          if (plan->ws_used) LCE_HIP_TRY(hipEventSynchronize(plan->ws_done));
+          if (plan->workspace) (void)hipFree(plan->workspace);
+          plan->workspace = nullptr;
+          plan->workspace_bytes = 0;
+          LCE_HIP_TRY(hipMalloc(&plan->workspace, ws + 256));
+          plan->workspace_bytes = ws;
+        }
+        const uint64_t chunks = (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4);  // threads of expand_fp4
+        if (h.phase != 2) {
+          lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
+          LCE_HIP_TRY(hipGetLastError());
+        }
+        if (h.phase != 1) {
+          const dim3 grid((unsigned)((A.M + bm - 1) / bm), (unsigned)(h.npad / bn));
+          hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), (size_t)h.mfma.lds_bytes(), st, A, G,
+                             (const uint8_t*)plan->workspace, plan->d_wq.ptr, plan->d_mul.ptr, plan->d_bias.ptr,
+                             plan->d_thrq.ptr, plan->d_zpc.ptr, out, ksgn);
+          LCE_HIP_TRY(hipGetLastError());
+        } else {
+          sign_fused = true;   // profiling mode "expand only": nothing to quantize
+        }
+        if (!plan->ws_done) LCE_HIP_TRY(hipEventCreateWithFlags(&plan->ws_done, hipEventDisableTiming));
+        LCE_HIP_TRY(hipEventRecord(plan->ws_done, st));
+        plan->ws_stream = st;
+        plan->ws_used = true;
       }
-      const size_t ws = lce::mfma_workspace_bytes(h, nb);
-      if (plan->workspace_bytes < ws) {
-        if (plan->workspace) (void)hipFree(plan->workspace);
-        plan->workspace = nullptr;
-        plan->workspace_bytes = 0;
-        LCE_HIP_TRY(hipMalloc(&plan->workspace, ws + 256));
-        plan->workspace_bytes = ws;
-      }
-      const uint64_t chunks = (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4);  // threads of expand_fp4
-      if (h.phase != 2) {
-        lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
-        LCE_HIP_TRY(hipGetLastError());
-      }
-      if (h.phase == 1) continue;
-      const dim3 grid((unsigned)((A.M + bm - 1) / bm), (unsigned)(h.npad / bn));
-      hipLaunchKernelGGL(fn, grid, dim3(h.mfma.threads()), (size_t)h.mfma.lds_bytes(), st, A, G,
-                         (const uint8_t*)plan->workspace, plan->d_wq.ptr, plan->d_mul.ptr, plan->d_bias.ptr,
-                         plan->d_thrq.ptr, plan->d_zpc.ptr, out);
     } else if (h.use_tiled) {
       tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
@@ -501,42 +562,114 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
       hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * wpb), 0, st, A, in, plan->d_packed.ptr,
                          plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thr.ptr, plan->d_oobc.ptr,
                          plan->d_zpc.ptr, out);
+      LCE_HIP_TRY(hipGetLastError());
     } else {
       general_fn fn = find_general(h.d.dst_type);
       const unsigned gx = (unsigned)((A.M + 255) / 256);
       const unsigned gy = (unsigned)((h.d.channels_out + 31) / 32);
       hipLaunchKernelGGL(fn, dim3(gx, gy), dim3(256), 0, st, A, in, plan->d_filter.ptr,
                          plan->d_mul.ptr, plan->d_bias.ptr, plan->d_thr.ptr, plan->d_zpc.ptr, out);
+      LCE_HIP_TRY(hipGetLastError());
     }
-    LCE_HIP_TRY(hipGetLastError());
+    if (sgn && !sign_fused) {
+      // this kernel variant has no second output: LceQuantize as its own launch on the same stream
+      if (lce_hip_status s = lce_hip_bitpack(LCE_HIP_F32, out, (size_t)nb * h.out_h * h.out_w, (size_t)h.d.channels_out, 0,
+                                             (int32_t*)sgn, (void*)st))
+        return s;
+    }
   }
   return LCE_HIP_OK;
 }
 
+static lce_hip_status run_checks(lce_hip_bconv2d_plan* plan, const void* input, const void* output, const char* who) {
+  if (!plan) return fail(LCE_HIP_ERR_INVALID, "%s: null argument", who);
+  if (!plan->host.have_weights) return fail(LCE_HIP_ERR_INVALID, "%s: plan_set_weights was not called", who);
+  if (plan->host.d.batch == 0) return LCE_HIP_OK;   // empty batch: tensors may legitimately be null
+  if (!input || !output) return fail(LCE_HIP_ERR_INVALID, "%s: null argument", who);
+  return require_device();
+}
+
+lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, void* output_dev, void* stream) {
+  if (lce_hip_status s = run_checks(plan, input_dev, output_dev, "bconv2d_run")) return s;
+  if (plan->host.d.batch == 0) return LCE_HIP_OK;
+  return run_images(plan, input_dev, output_dev, nullptr, 0, plan->host.d.batch, (hipStream_t)stream);
+}
+
+lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, float* output_dev,
+                                        int32_t* output_bits_dev, void* stream) {
+  if (lce_hip_status s = run_checks(plan, input_dev, output_dev, "bconv2d_run_dual")) return s;
+  if (plan->host.d.dst_type != LCE_HIP_F32)
+    return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: the plan's output type must be float32 (a bitpacked-output plan "
+                "already writes bits; int8 has no sign to quantize)");
+  if (plan->host.d.batch == 0) return LCE_HIP_OK;
+  if (!output_bits_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: null argument");
+  return run_images(plan, input_dev, output_dev, output_bits_dev, 0, plan->host.d.batch, (hipStream_t)stream);
+}
+
+int lce_hip_bconv2d_plan_device(const lce_hip_bconv2d_plan* plan) { return plan ? plan->device : -1; }
+
+// Host tensors (the TFLite interpreter's arena).  The batch is cut into slices that flow through three
+// streams -- H2D | kernel | D2H -- so the copies of neighbouring slices overlap the compute of the one in
+// between.  The copies are truly asynchronous only from page-locked memory: a host that owns long-lived
+// buffers (an arena) registers them once with lce_hip_host_register; with pageable memory the runtime
+// stages each copy and the slices still pipeline, just less tightly.
 lce_hip_status lce_hip_bconv2d_run_host(lce_hip_bconv2d_plan* plan, const int32_t* input_host, void* output_host) {
-  if (!plan) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_host: null argument");
-  if (plan->host.d.batch == 0) return LCE_HIP_OK;   // empty batch
-  if (!input_host || !output_host) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_host: null argument");
-  if (lce_hip_status s = require_device()) return s;
+  if (lce_hip_status s = run_checks(plan, input_host, output_host, "bconv2d_run_host")) return s;
   const lce::HostPlan& h = plan->host;
-  const size_t in_bytes = (size_t)h.d.batch * h.d.in_height * h.d.in_width * h.cw * 4;
+  if (h.d.batch == 0) return LCE_HIP_OK;   // empty batch
+  if (lce_hip_status s = check_device(plan)) return s;
+  const size_t in_img = (size_t)h.d.in_height * h.d.in_width * h.cw * 4;
   const size_t out_row = h.d.dst_type == LCE_HIP_BITPACKED ? (size_t)h.wout : (size_t)h.d.channels_out;
-  const size_t out_bytes = (size_t)h.d.batch * h.out_h * h.out_w * out_row * out_elem_bytes(h.d.dst_type);
+  const size_t out_img = (size_t)h.out_h * h.out_w * out_row * out_elem_bytes(h.d.dst_type);
+  const size_t in_bytes = in_img * h.d.batch, out_bytes = out_img * h.d.batch;
   if (plan->stage_in_bytes < in_bytes) {
     if (plan->stage_in) (void)hipFree(plan->stage_in);
     plan->stage_in = nullptr;
+    plan->stage_in_bytes = 0;
     LCE_HIP_TRY(hipMalloc(&plan->stage_in, in_bytes));
     plan->stage_in_bytes = in_bytes;
   }
   if (plan->stage_out_bytes < out_bytes) {
     if (plan->stage_out) (void)hipFree(plan->stage_out);
     plan->stage_out = nullptr;
+    plan->stage_out_bytes = 0;
     LCE_HIP_TRY(hipMalloc(&plan->stage_out, out_bytes));
     plan->stage_out_bytes = out_bytes;
   }
-  LCE_HIP_TRY(hipMemcpy(plan->stage_in, input_host, in_bytes, hipMemcpyHostToDevice));
-  if (lce_hip_status s = lce_hip_bconv2d_run(plan, (const int32_t*)plan->stage_in, plan->stage_out, nullptr)) return s;
-  LCE_HIP_TRY(hipMemcpy(output_host, plan->stage_out, out_bytes, hipMemcpyDeviceToHost));
+  // slices of >= ~8 MiB of traffic each, at most 8 of them
+  const size_t per_image = in_img + out_img;
+  int slices = (int)std::min<size_t>(8, std::max<size_t>(1, (per_image * h.d.batch) / (8u << 20)));
+  slices = std::min(slices, h.d.batch);
+  if (!plan->s_h2d) {
+    LCE_HIP_TRY(hipStreamCreateWithFlags(&plan->s_h2d, hipStreamNonBlocking));
+    LCE_HIP_TRY(hipStreamCreateWithFlags(&plan->s_run, hipStreamNonBlocking));
+    LCE_HIP_TRY(hipStreamCreateWithFlags(&plan->s_d2h, hipStreamNonBlocking));
+  }
+  while ((int)plan->ev_in.size() < slices) {
+    hipEvent_t a, b;
+    LCE_HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    LCE_HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    plan->ev_in.push_back(a);
+    plan->ev_run.push_back(b);
+  }
+  const int base = h.d.batch / slices, extra = h.d.batch % slices;
+  int first = 0;
+  for (int k = 0; k < slices; ++k) {
+    const int count = base + (k < extra ? 1 : 0);
+    LCE_HIP_TRY(hipMemcpyAsync((char*)plan->stage_in + first * in_img, (const char*)input_host + first * in_img,
+                               count * in_img, hipMemcpyHostToDevice, plan->s_h2d));
+    LCE_HIP_TRY(hipEventRecord(plan->ev_in[k], plan->s_h2d));
+    LCE_HIP_TRY(hipStreamWaitEvent(plan->s_run, plan->ev_in[k], 0));
+    if (lce_hip_status s = run_images(plan, (const int32_t*)plan->stage_in, plan->stage_out, nullptr, first, count, plan->s_run))
+      return s;
+    LCE_HIP_TRY(hipEventRecord(plan->ev_run[k], plan->s_run));
+    LCE_HIP_TRY(hipStreamWaitEvent(plan->s_d2h, plan->ev_run[k], 0));
+    LCE_HIP_TRY(hipMemcpyAsync((char*)output_host + first * out_img, (const char*)plan->stage_out + first * out_img,
+                               count * out_img, hipMemcpyDeviceToHost, plan->s_d2h));
+    first += count;
+  }
+  LCE_HIP_TRY(hipStreamSynchronize(plan->s_d2h));   // the last slice's copy is the last thing queued anywhere
+  LCE_HIP_TRY(hipStreamSynchronize(plan->s_run));
   return LCE_HIP_OK;
 }
 

@@ -84,6 +84,10 @@ struct MfmaArgs {
   int32_t i8_wide;         // int8 epilogue may use WN*4 KiB of LDS scratch per wave (16-byte row stores)
   int32_t noclamp;         // the output transform's clamp is the identity on [0, 2*K_bt] (activation NONE)
   FastDiv div_tpi, div_qg, div_ohow, div_hpix;
+  // grouped convolutions: a block's channels lie in ONE group g = n0 / Npg, whose input channels are the
+  // slice [g*Cin_g, (g+1)*Cin_g) of the same pixels; its K loop covers the KCH 64-channel chunks that
+  // contain the slice, starting at chunk (g*Cwg)/2 (weights outside the slice are FP4 zeros)
+  FastDiv div_npg;
 };
 
 }  // namespace lce

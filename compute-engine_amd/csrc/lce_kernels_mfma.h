@@ -173,7 +173,7 @@ LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
              const uint8_t* __restrict__ wq, const float* __restrict__ mul,
              const float* __restrict__ bias, const float* __restrict__ thrf,
-             const float* __restrict__ zpc, void* __restrict__ out) {
+             const float* __restrict__ zpc, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
   // WGM x WGN waves per block, each owning WM x WN MFMA tiles of 32x32
   constexpr int NWAVES = WGM * WGN;
   constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
@@ -226,6 +226,8 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     }
   }
   const int n0 = block_idx_y() * BN;
+  // grouped convolution: first 64-channel chunk of this block's group (0 when groups == 1: Npg == N > n0)
+  const int chunk0 = ((int)fastdiv((uint32_t)n0, G.div_npg) * A.Cwg) >> 1;
 
   const rsrc_t rx = make_rsrc(xp, G.x_bytes);
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
@@ -274,6 +276,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   uint32_t a_off = 0, b_off = 0;    // byte offsets of the NEXT K-step to be filled
   int f_kc = 0, f_fx = 0;
   const uint32_t a_step_kc = 2u * G.NPIX * 16u;
+  a_off = (uint32_t)chunk0 * a_step_kc;
   const uint32_t a_step_fx = (uint32_t)A.DW * 16u - (uint32_t)G.KCH * a_step_kc;
   const uint32_t a_step_fy = (uint32_t)(A.DH * G.Wp - A.KW * A.DW) * 16u;
   const uint32_t b_step = (uint32_t)G.Npad * 32u;
@@ -332,7 +335,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // hit 16 different bank groups (PS/4 = 4 mod 8 dwords).  No FP4 workspace, no A traffic in
   // the K loop; only the weights stream through the ring.
   uint32_t a_base[WM];
-  uint32_t a_cur = 0;               // byte offset of the K-step whose fragments are read next
+  uint32_t a_cur = (uint32_t)chunk0 * 32u;   // byte offset of the K-step whose fragments are read next
   int c_kc = 0, c_fx = 0;
   if constexpr (DIRECT) {
     const int oy0 = (int)fastdiv((uint32_t)p0, A.div_ow);
@@ -552,53 +555,58 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     else { mj[j] = mul[n]; bj[j] = bias[n]; }
   }
 
-  if constexpr (DST == kDstBitpacked) {
+  // Bit rows of one 32-pixel row block: register r of a tile holds pixel rows q (lanes 0-31) and q + 4
+  // (lanes 32-63), q = (r & 3) + 8 * (r >> 2); the 32 channel bits of a row are one compare + ballot, and
+  // v_writelane drops each word into the lane that will store it -- afterwards lane p (< 32) owns row p.
+  // BITPACKED output: bit = acc > thr (accum > threshold <=> 2*accum > 2*threshold, output_transform.h:160-168);
+  // second output of a float layer: bit = y < 0, the LceQuantize of the value the lane just produced
+  // (core/bitpacking/bitpack.h:72-110; -0.0 and NaN give 0 there and here).
+  auto bit_rows = [&](int i, auto below_zero, uint32_t* dst_words) LCE_LAMBDA_INLINE {
+    constexpr bool SIGN = decltype(below_zero)::value;
+    uint32_t words[WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      uint32_t words[WN];
+    for (int j = 0; j < WN; ++j) words[j] = 0u;
+    auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
+      constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
+      unsigned long long bits[WN];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) words[j] = 0u;
-      // register r holds pixel rows q (lanes 0-31) and q + 4 (lanes 32-63) of the tile,
-      // q = (r & 3) + 8 * (r >> 2);  accum > threshold <=> 2*accum > 2*threshold
-      // (output_transform.h:160-168).  v_writelane drops each 32-channel word into the lane
-      // that will store it.
-      auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
-        constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
-        unsigned long long bits[WN];
+      for (int j = 0; j < WN; ++j) bits[j] = wave_ballot(SIGN ? acc[i][j][r] < 0.0f : acc[i][j][r] > tj[j]);
+      settle_ballots(bits);                    // ONE hazard pad for the WN compares, not one per v_writelane
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bits[j] = wave_ballot(acc[i][j][r] > tj[j]);
-        settle_ballots(bits);                    // ONE hazard pad for the WN compares, not one per v_writelane
+      for (int j = 0; j < WN; ++j) {
+        words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);              // lane q     <- row q
+        words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);  // lane q + 4 <- row q + 4
+      }
+    };
+    gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
+    gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
+    gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
+    gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
+    // lane p (< 32) now owns pixel row p of the tile: WN consecutive output words
+    const int m = m0 + (wm * WM + i) * 32 + lane;
+    const int w0 = (n0 + wn * WN * 32) >> 5;
+    if (lane < 32 && m < m_end) {
+      uint32_t* o = dst_words + (size_t)m * (size_t)A.Wout + (size_t)w0;
+      if (WN == 4 && w0 + 4 <= A.Wout && (A.Wout & 3) == 0) {
+        u32x4 v = {words[0], words[WN > 1 ? 1 : 0], words[WN > 2 ? 2 : 0], words[WN > 3 ? 3 : 0]};
+        *(u32x4*)o = v;
+      } else if (WN >= 2 && w0 + WN <= A.Wout && (A.Wout & 1) == 0) {
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);              // lane q     <- row q
-          words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);  // lane q + 4 <- row q + 4
+        for (int j = 0; j < WN; j += 2) {
+          u32x2 v = {words[j], words[j + 1 < WN ? j + 1 : j]};
+          *(u32x2*)(o + j) = v;
         }
-      };
-      gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
-      gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
-      gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
-      gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
-      // lane p (< 32) now owns pixel row p of the tile: WN consecutive output words
-      const int m = m0 + (wm * WM + i) * 32 + lane;
-      const int w0 = (n0 + wn * WN * 32) >> 5;
-      if (lane < 32 && m < m_end) {
-        uint32_t* o = (uint32_t*)out + (size_t)m * (size_t)A.Wout + (size_t)w0;
-        if (WN == 4 && w0 + 4 <= A.Wout && (A.Wout & 3) == 0) {
-          u32x4 v = {words[0], words[WN > 1 ? 1 : 0], words[WN > 2 ? 2 : 0], words[WN > 3 ? 3 : 0]};
-          *(u32x4*)o = v;
-        } else if (WN >= 2 && w0 + WN <= A.Wout && (A.Wout & 1) == 0) {
+      } else {
 #pragma unroll
-          for (int j = 0; j < WN; j += 2) {
-            u32x2 v = {words[j], words[j + 1 < WN ? j + 1 : j]};
-            *(u32x2*)(o + j) = v;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            if (w0 + j < A.Wout) o[j] = words[j];
-        }
+        for (int j = 0; j < WN; ++j)
+          if (w0 + j < A.Wout) o[j] = words[j];
       }
     }
+  };
+
+  if constexpr (DST == kDstBitpacked) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) bit_rows(i, StepTail{}, (uint32_t*)out);
   } else if (DST == kDstFloat && !CORR && G.f32_wide && (((size_t)out) & 15) == 0) {
     // float, wide path: the WN tiles of a 32-row block are transposed together
     // ([32 rows][WN*32] floats of scratch), so there is one LDS fence pair per row block instead of
@@ -620,20 +628,26 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     const uint32_t lane_off = n < A.N ? (uint32_t)(lane / LPR) * row_bytes + (uint32_t)n * 4u : kOobOffset;   // N % 4 == 0
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+      // the transform in place (the accumulators become the outputs) ...
       if (G.noclamp) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] = mul_then_add(acc[i][j][r], mj[j], bj[j]);
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = mul_then_add(acc[i][j][r], mj[j], bj[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] =
-                mul_then_add(med3(acc[i][j][r], cminf, cmaxf), mj[j], bj[j]);
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = mul_then_add(med3(acc[i][j][r], cminf, cmaxf), mj[j], bj[j]);
       }
+      // ... the optional second output: their sign bits, packed like LceQuantize would pack them ...
+      if (sign_words != nullptr) bit_rows(i, StepSteady{}, sign_words);
+      // ... and the transpose through LDS
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] = acc[i][j][r];
       wave_lds_fence();
 #pragma unroll
       for (int k0 = 0; k0 < NK; k0 += KB) {

@@ -210,7 +210,8 @@ static void pack_for_tile(HostPlan& p) {
 // ------------------------------------------------------------------------------------
 bool mfma_supported(const HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
-  if (d.groups != 1) return false;                       // one K range for all channels
+  // grouped: a block's channels must lie in one group -- some block width (64) has to divide Cout/G
+  if (d.groups != 1 && (d.channels_out / d.groups) % 64 != 0) return false;
   if (p.backtransform_add >= (1 << 23)) return false;    // fp32 accumulation must stay exact
   const int cpad = ceil_div(d.channels_in, 64) * 64;
   const int64_t hp = std::max<int64_t>(p.pad_h + d.in_height,
@@ -237,26 +238,42 @@ const MfmaCfg* mfma_cfg_by_tile(int bm, int bn) {
   return nullptr;
 }
 
+// 64-channel chunks per tap that the blocks of a grouped convolution run: the chunks group g's channel
+// slice [g*Cin_g, (g+1)*Cin_g) touches (Cin_g is a multiple of 32, so a slice may start mid-chunk)
+static int group_chunks(const lce_hip_bconv2d_desc& d) {
+  const int cin_g = d.channels_in / d.groups;
+  int most = 0;
+  for (int g = 0; g < d.groups; ++g)
+    most = std::max(most, ((g + 1) * cin_g + 63) / 64 - (g * cin_g) / 64);
+  return most;
+}
+
 static void pack_for_mfma(HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
   const int taps = d.filter_height * d.filter_width, n = d.channels_out;
   const int bn = p.mfma.bn();
+  const int cin_g = d.channels_in / d.groups;
   p.cpad = ceil_div(d.channels_in, 64) * 64;
   p.npad = ceil_div(n, bn) * bn;
-  const int kch = p.cpad / 64, ks_total = taps * kch;
+  p.kch = d.groups > 1 ? group_chunks(d) : p.cpad / 64;
+  const int kch = p.kch, ks_total = taps * kch;
   p.wq.assign((size_t)ks_total * p.npad * 32, 0);
-  for (int oc = 0; oc < n; ++oc)
+  for (int oc = 0; oc < n; ++oc) {
+    const int g = oc / p.npg, chunk0 = (g * cin_g) / 64;    // the kernel starts the group's K loop at this chunk
     for (int t = 0; t < taps; ++t)
-      for (int c = 0; c < d.channels_in; ++c) {
-        const uint32_t w = p.filter[((size_t)oc * taps + t) * p.cwg + c / 32];
+      for (int ci = 0; ci < cin_g; ++ci) {
+        const uint32_t w = p.filter[((size_t)oc * taps + t) * p.cwg + ci / 32];
         // the NEGATED weight: bit 1 (-1) -> +1 = 0x2, bit 0 (+1) -> -1 = 0xA.  The kernel starts its
         // accumulators at K_bt, so they hold K_bt - <a, w> = 2 * popcount-accumulator directly, the
         // value the output transform clamps (output_transform.h:62-91,105) -- no subtraction later.
-        const uint8_t nib = ((w >> (c % 32)) & 1u) ? 0x2 : 0xA;
-        const int ks = t * kch + c / 64, j = c % 64, half = j / 32, jj = j % 32;
+        // Channels of the chunk that belong to a neighbouring group keep the code 0: they contribute nothing.
+        const uint8_t nib = ((w >> (ci % 32)) & 1u) ? 0x2 : 0xA;
+        const int c = g * cin_g + ci;                         // position in the pixel's channel vector
+        const int ks = t * kch + (c / 64 - chunk0), j = c % 64, half = j / 32, jj = j % 32;
         uint8_t& byte = p.wq[(((size_t)ks * 2 + half) * p.npad + oc) * 16 + jj / 2];
         byte |= (uint8_t)(nib << (4 * (jj & 1)));
       }
+  }
   p.mul_q.assign(p.npad, 0.0f);
   p.bias_q.assign(p.npad, 0.0f);
   std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
@@ -281,6 +298,7 @@ static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
   int bn = n > 128 ? 256 : n > 64 ? 128 : 64;
   auto blocks = [&](int bm, int bn_) { return ((pixels + bm - 1) / bm) * (int64_t)ceil_div(n, bn_); };
   while (bn > 64 && blocks(128, bn) < 512) bn /= 2;
+  while (bn > 64 && p.d.groups > 1 && p.npg % bn) bn /= 2;   // a block's channels lie in one group
   const int bm = bn == 64 ? 256 : 128;
   const MfmaCfg* c = mfma_cfg_by_tile(bm, bn);
   if (bn == 64 && blocks(256, 64) < 512) c = mfma_cfg_by_tile(128, 64);
@@ -335,7 +353,8 @@ bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out) {
   // MFMA-first K-step, float / bitpacked output gains 2-3 % over 256x128 (0.2955 -> 0.288 ms).  On
   // short launches more, smaller blocks win (28x28x256 int8: 128x128 0.082 ms vs 128x256 0.089).
   const bool wide = p.d.channels_out > 128 && (int64_t)p.d.batch * ceil_div(ohow, 128) >= 4096;
-  const int bn = wide ? 256 : p.d.channels_out > 64 ? 128 : 64;
+  int bn = wide ? 256 : p.d.channels_out > 64 ? 128 : 64;
+  while (bn > 64 && p.d.groups > 1 && p.npg % bn) bn /= 2;    // a block's channels lie in one group
   struct Cand { const MfmaCfg* c; double padded; int64_t blocks; };
   Cand cand[2];
   int n = 0;
@@ -368,7 +387,7 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   MfmaArgs G{};
   G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
   G.Hp = p.hp; G.Wp = p.wp; G.PH = p.pad_h; G.PW = p.pad_w;
-  G.NPIX = (uint32_t)((int64_t)batch_chunk * p.hp * p.wp); G.CPW = p.cpad / 32; G.KCH = p.cpad / 64;
+  G.NPIX = (uint32_t)((int64_t)batch_chunk * p.hp * p.wp); G.CPW = p.cpad / 32; G.KCH = p.d.groups > 1 ? group_chunks(p.d) : p.cpad / 64;
   G.Npad = p.npad;
   G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
   G.x_bytes = (uint32_t)mfma_workspace_bytes(p, batch_chunk);
@@ -376,6 +395,7 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   G.div_npix = make_fastdiv(G.NPIX);
   G.div_wp = make_fastdiv((uint32_t)G.Wp);
   G.div_hp = make_fastdiv((uint32_t)G.Hp);
+  G.div_npg = make_fastdiv((uint32_t)p.npg);
   G.a_bt = (float)p.backtransform_add;
   G.cmin = (float)p.clamp_min;
   G.cmax = (float)p.clamp_max;
@@ -413,7 +433,7 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
   p.use_mfma = false;
   p.use_direct = false;
   if (p.engine_pref >= 2 && !mfma_supported(p))
-    return "bconv2d: the matrix-core engine cannot run this convolution (grouped, or too deep)";
+    return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   if (p.engine_pref >= 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
                              mfma_supported(p) && pixels * d.channels_out >= (1 << 16))) {
     p.use_mfma = true;
@@ -423,6 +443,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     if (p.engine_pref >= 2 && p.tile_pref.tm != 0) {
       const MfmaCfg* forced = mfma_cfg_by_tile(p.tile_pref.tm, p.tile_pref.tn);
       if (!forced) return "bconv2d: no matrix-core kernel instance for the requested block tile";
+      if (d.groups > 1 && p.npg % forced->bn())
+        return "bconv2d: the requested block tile would straddle channel groups";
       want = *forced;
       direct = p.engine_pref == 3;
     } else if (p.engine_pref != 2) {
@@ -434,7 +456,7 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       } else if (p.engine_pref == 3) {
         // forced: take any tile whose halo fits, whatever the padding waste
         for (int bm : {128, 256}) {
-          const MfmaCfg* c = mfma_cfg_by_tile(bm, d.channels_out > 64 ? 128 : 64);
+          const MfmaCfg* c = mfma_cfg_by_tile(bm, d.channels_out > 64 && (d.groups == 1 || p.npg % 128 == 0) ? 128 : 64);
           int a, b, c2, e, f;
           if (c && direct_geometry(p, *c, &a, &b, &c2, &e, &f, kDirectLdsMax)) { want = *c; direct = true; break; }
         }

@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -25,10 +26,14 @@ struct MfmaCfg {
   int threads() const { return 64 * wgm * wgn; }
   static constexpr int kStages = 4;        // LDS ring depth of bconv2d_mfma (A + B per stage)
   static constexpr int kDirectStages = 3;  // ... of its direct variant (B only; the halo is extra)
-  int lds_bytes() const { return kStages * (bm() + bn()) * 32; }
+  // The joint-transpose epilogues (float / int8 rows of WN*32 channels, and the float kernels' optional
+  // sign-bit output) need waves x WN x 4 KiB of scratch.  Every block asks for at least that much: with
+  // this kernel's register use no tile loses a resident block to it (e.g. 128x256: 64 KiB, two blocks per
+  // CU either way), and every layer gets the lean epilogue.
+  int epilogue_scratch_bytes() const { return (threads() / 64) * wn * 4096; }
+  int lds_bytes() const { return std::max(kStages * (bm() + bn()) * 32, epilogue_scratch_bytes()); }
   int direct_lds_bytes(int halo_bytes) const {
-    const int need = halo_bytes + kDirectStages * bn() * 32, scratch = (threads() / 64) * 4096;
-    return need > scratch ? need : scratch;
+    return std::max(halo_bytes + kDirectStages * bn() * 32, epilogue_scratch_bytes());
   }
 };
 // The instantiated shapes, by block tile (pixels x channels).
@@ -68,6 +73,8 @@ struct HostPlan {
   bool use_mfma = false;
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
   int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count
+  int kch = 0;                             // K-steps (64-channel chunks) per filter tap that a block runs: cpad/64,
+                                           // or the chunks one group's channel slice touches
   std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
   std::vector<float> mul_q, bias_q, thr_q; // Npad entries
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LCE_HIP_ABI_VERSION 1
+#define LCE_HIP_ABI_VERSION 2
 
 typedef enum lce_hip_status {
   LCE_HIP_OK = 0,
@@ -80,6 +80,11 @@ lce_hip_status lce_hip_free(void* dev_ptr);
 lce_hip_status lce_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 lce_hip_status lce_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 lce_hip_status lce_hip_memset(void* dst_dev, int value, size_t bytes, void* stream);
+/* Page-locks [host_ptr, host_ptr + bytes) (hipHostRegister) so that copies from / to it are truly
+ * asynchronous and lce_hip_bconv2d_run_host can overlap them with compute.  For buffers the caller keeps
+ * alive and reuses (the interpreter's tensor arena); the range must be unregistered before it is freed. */
+lce_hip_status lce_hip_host_register(void* host_ptr, size_t bytes);
+lce_hip_status lce_hip_host_unregister(void* host_ptr);
 lce_hip_status lce_hip_stream_create(void** stream);
 lce_hip_status lce_hip_stream_destroy(void* stream);
 lce_hip_status lce_hip_stream_synchronize(void* stream);
@@ -177,10 +182,36 @@ const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan);
 /* Replaces bconv2d::Eval (bconv2d.cc:550-564) -> BConv2DReference /
  * BConv2DOptimizedBGEMM / BConv2DOptimizedIndirectBGEMM (core/bconv2d/ headers) with
  * device-resident tensors: input int32 [B,H,W,ceil(Cin/32)], output per dst_type.
- * Asynchronous on `stream`. */
+ * Asynchronous on `stream`.
+ *
+ * Devices and streams.  A plan's weights, tables, workspace and staging buffers live on ONE HIP device:
+ * the one that is current at the plan's first run (lce_hip_bconv2d_plan_device).  Running it while another
+ * device is current fails with LCE_HIP_ERR_INVALID -- create one plan per device (the batch-shard mode of
+ * SURVEY.md 8(e) runs one process per GPU).  A plan may be run on any stream of that device, one call at a
+ * time per plan: calls from several host threads into the SAME plan must be serialised by the caller (the
+ * reference's OpData is per node and TFLite invokes a node from one thread, tflite/kernels/bconv2d.cc:44-74);
+ * calls on different streams are ordered by the library where they share the plan's workspace.  Different
+ * plans are independent. */
 lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* input_dev,
                                    void* output_dev, void* stream);
-/* Same with host tensors (interpreter arena): H2D, run, D2H, synchronous. */
+/* The HIP device the plan is bound to, -1 before its first run. */
+int lce_hip_bconv2d_plan_device(const lce_hip_bconv2d_plan* plan);
+
+/* LceBconv2d (float output) and the LceQuantize that follows it in a converted graph
+ * (tflite/kernels/quantization.cc:76-114 on the convolution's output), in one pass: `output_dev` gets the
+ * float tensor [B,OH,OW,Cout] exactly as lce_hip_bconv2d_run writes it, `output_bits_dev` its sign bits
+ * [B,OH,OW,ceil(Cout/32)] exactly as lce_hip_bitpack(F32, output_dev, ...) would -- from the same epilogue
+ * (the value a lane just produced is balloted) where the kernel variant allows, by a second launch on the
+ * same stream otherwise.  Saves re-reading the float tensor between the binary convolutions of a
+ * device-resident chain.  The plan's dst_type must be LCE_HIP_F32. */
+lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_t* input_dev,
+                                        float* output_dev, int32_t* output_bits_dev, void* stream);
+
+/* Same as lce_hip_bconv2d_run with host tensors (the interpreter arena), synchronous.  The batch is cut
+ * into slices that flow through three streams (H2D | kernel | D2H) so that the copies of neighbouring
+ * slices overlap the compute.  The overlap is complete when the two buffers are page-locked
+ * (lce_hip_host_register -- an arena is reused for every Invoke, so the glue registers it once); pageable
+ * buffers work too, with the runtime staging every copy. */
 lce_hip_status lce_hip_bconv2d_run_host(lce_hip_bconv2d_plan* plan, const int32_t* input_host,
                                         void* output_host);
 

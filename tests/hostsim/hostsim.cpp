@@ -79,12 +79,14 @@ void launch_block_lockstep(int grid_x, int grid_y, int block, size_t lds_bytes, 
 }
 
 std::string g_err;
+void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call (float output, matrix-core engine)
 
 }  // namespace
 
 extern "C" {
 
 const char* hostsim_last_error() { return g_err.c_str(); }
+void hostsim_set_sign_output(void* words) { g_sign_out = words; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
 // engine_pref: 0 auto, 1 valu, 2 mfma
@@ -131,7 +133,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
       if (h.use_direct) {
         launch_block_lockstep(h.ipt > 1 ? (nb + h.ipt - 1) / h.ipt : nb * h.tpi, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.direct_lds_bytes(h.halo_bytes), [&] {
-          fn(A, G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
+          fn(A, G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out, g_sign_out ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr);
         });
         continue;
       }
@@ -139,7 +141,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       std::vector<lce_dev::u32x4> work(ws / 16 + 16);
       launch_sequential(3, 1, 256, [&] { expand_fp4(in, work.data(), G, (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4)); });
       launch_block_lockstep((A.M + bm - 1) / bm, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.lds_bytes(), [&] {
-        fn(A, G, (const uint8_t*)work.data(), wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out);
+        fn(A, G, (const uint8_t*)work.data(), wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out, g_sign_out ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr);
       });
     } else if (h.use_tiled) {
       tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);

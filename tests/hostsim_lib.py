@@ -57,7 +57,9 @@ def _p(a):
 
 def bconv2d(spec: O.ConvSpec, dst_type: int, inp, filt, post_mul=None, post_bias=None,
             thresholds=None, out_scale=1.0, out_zero_point=0, kernel="auto", tile=(0, 0),
-            max_batch=0, engine="valu"):
+            max_batch=0, engine="valu", sign_words=None):
+    """sign_words: an int32 array [B,OH,OW,ceil(Cout/32)] that receives the float output's sign bits (the
+    matrix-core kernels' second output; stays untouched when the chosen kernel variant cannot write it)."""
     inp = np.ascontiguousarray(inp, np.int32)
     filt = np.ascontiguousarray(filt, np.int32)
     mul = None if post_mul is None else np.ascontiguousarray(post_mul, np.float32)
@@ -68,9 +70,11 @@ def bconv2d(spec: O.ConvSpec, dst_type: int, inp, filt, post_mul=None, post_bias
         else np.full(spec.output_shape(dst_type), -7, dtype=dt)
     name = C.create_string_buffer(128)
     d = make_desc(spec, dst_type, out_scale, out_zero_point)
+    lib().hostsim_set_sign_output(_p(sign_words))
     rc = lib().hostsim_bconv2d(C.byref(d), _p(filt), _p(mul), _p(bias), _p(thr), _p(inp), _p(out),
                                {"auto": 0, "tiled": 1, "general": 2}[kernel], tile[0], tile[1],
                                max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3}[engine])
+    lib().hostsim_set_sign_output(None)
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
     return out, name.value.decode()

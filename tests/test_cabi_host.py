@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = amd.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lce_hip_abi_version() == 1
+    assert lib.lce_hip_abi_version() == 2
 
 
 def _params(spec: O.ConvSpec, dst, **kw):
@@ -187,7 +187,8 @@ def test_planner_fallbacks():
                     channels_out=128)
         base.update(kw)
         return amd.Bconv2dPlan(amd.ConvParams(**base)).kernel_name()
-    assert name(groups=2).startswith("bconv2d_tiled<")                 # grouped: xor-popcount engine
+    assert name(groups=2) == "bconv2d_mfma_direct<f32,256x64>"         # grouped, 64 channels per group: one group per block
+    assert name(groups=4).startswith("bconv2d_tiled<")                 # 32 channels per group: xor-popcount engine
     assert name(batch=1, in_height=4, in_width=4, channels_out=8).startswith("bconv2d_tiled<")   # too small for the matrix cores
     assert name(channels_in=2048, batch=8).startswith("bconv2d_mfma<")  # LDS halo too large: workspace GEMM
     # 13x13 outputs: a 128-pixel tile would be 34 % padding -> workspace GEMM (tiles span images)

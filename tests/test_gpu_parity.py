@@ -148,18 +148,29 @@ def test_bitpack_empty_and_errors():
 
 # ------------------------------------------------------------------------------------ LceBconv2d
 
+@pytest.mark.parametrize("engine", ["auto", "direct", "mfma", "valu", "valu-general"])
 @pytest.mark.parametrize("name,spec,d", list(G.conv_cases()), ids=lambda v: v if isinstance(v, str) else "")
-def test_conv_golden(name, spec, d):
+def test_conv_golden(name, spec, d, engine):
+    """The committed golden vectors (tests/golden/bconv2d_golden.npz) through every engine that ships: the
+    planner's own choice (what bench.py times), both matrix-core variants, the xor-popcount engine and its
+    any-shape kernel.  A forced engine may legally refuse a case (grouped channels that are not a multiple
+    of 64, a halo beyond LDS); nothing may compute it differently."""
     scale, zp = float(d["int8_scale_zp"][0]), int(d["int8_scale_zp"][1])
     x, w, mul, bias = d["input"], d["filter"], d["post_mul"], d["post_bias"]
-    for kernel in ("auto", "general"):
-        got, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel)
+    kw = dict(engine="valu", kernel="general") if engine == "valu-general" else dict(engine=engine)
+    ran = 0
+    try:
+        got, _ = _gpu_conv(spec, amd.F32, x, w, mul, bias, **kw)
         assert np.array_equal(got.view(np.int32), d["out_f32"].view(np.int32))
+        ran += 1
         if "out_i8" in d:
-            got, _ = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel)
+            got, _ = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, **kw)
             assert np.array_equal(got, d["out_i8"])
-            got, _ = _gpu_conv(spec, amd.BITPACKED, x, w, thr=d["thresholds"], kernel=kernel)
+            got, _ = _gpu_conv(spec, amd.BITPACKED, x, w, thr=d["thresholds"], **kw)
             assert np.array_equal(got, d["out_bitpacked"])
+    except amd.LceHipError as e:
+        assert engine in ("direct", "mfma") and ("matrix-core engine cannot run" in str(e) or "halo in LDS" in str(e)), e
+        assert ran == 0
 
 
 GRID = CASES[:72] + CASES[72::5]
@@ -259,6 +270,99 @@ def test_float_and_int8_epilogue_variants(shape, engine, epilogue):
     want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=4)
     got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, engine=engine, opts=(("epilogue", epilogue),))
     assert np.array_equal(got, want), name
+
+
+@pytest.mark.parametrize("engine", ["auto", "mfma", "direct"])
+@pytest.mark.parametrize("cin,cout,groups", [(128, 128, 2), (192, 256, 2), (128, 256, 4), (320, 128, 2), (64, 128, 2),
+                                             (512, 512, 4)])
+def test_conv_grouped_on_the_matrix_cores(cin, cout, groups, engine):
+    """core/bconv2d/reference.h:62,95-110: group g of the output channels sees the input channel slice
+    [g*Cin/G, (g+1)*Cin/G).  With Cout/G a multiple of 64 the matrix-core engine runs it (a block's channels
+    lie in one group; slices that start mid-way through a 64-channel K-step share it with zero weights)."""
+    for pad, st, act in (("ONE", (1, 1), O.ACT_NONE), ("VALID", (2, 1), O.ACT_RELU), ("SAME", (1, 1), O.ACT_NONE)):
+        padding, pv = PADS[pad]
+        spec = O.ConvSpec(3, 19, 23, cin, 3, 3, cout, groups, st[0], st[1], 1, 1, padding, pv, act, O.SEM_REFERENCE)
+        names = _check_all_dst(spec, cin + cout + groups, engine=engine)
+        assert all(n.startswith("bconv2d_mfma") for n in names), names
+
+
+@pytest.mark.parametrize("engine,kernel", [("auto", "auto"), ("direct", "auto"), ("mfma", "auto"), ("valu", "auto"), ("valu", "general")])
+@pytest.mark.parametrize("shape", [(3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 136), (2, 28, 28, 128, 33)])
+def test_run_dual_is_run_followed_by_lcequantize(shape, engine, kernel):
+    """lce_hip_bconv2d_run_dual: float output bit-equal to lce_hip_bconv2d_run, bit output bit-equal to
+    lce_hip_bitpack of it (fused into the epilogue where the kernel variant can, a second launch where not)."""
+    b, h, w_, cin, cout = shape
+    for sem, pv, act in ((O.SEM_REFERENCE, 1, O.ACT_RELU), (O.SEM_OPTIMIZED, 0, O.ACT_NONE)):
+        spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=pv, activation=act, semantics=sem)
+        x, w, mul, bias = synth.conv_inputs(spec, sum(shape), negative_mul_fraction=0.3)
+        plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+        plan.set_weights(w, mul, bias)
+        plan.set_option("engine", engine)
+        plan.set_option("kernel", kernel)
+        xd = torch.from_numpy(x).to(DEV)
+        y = plan.run(xd)
+        bits_poison = torch.full((b, spec.out_h, spec.out_w, (cout + 31) // 32), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+        y2, bits = plan.run_dual(xd, out_bits=bits_poison)
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int32), y2.view(torch.int32)), plan.kernel_name()
+        assert torch.equal(bits, amd.bitpack(y)), plan.kernel_name()
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=4)
+        assert np.array_equal(bits.cpu().numpy(), O.bitpack(want)), plan.kernel_name()
+        frac = np.unpackbits(bits.cpu().numpy().view(np.uint8)).mean() * 32 * ((cout + 31) // 32) / cout
+        assert 0.02 < frac < 0.98, frac                 # both signs occur (30 % of the multipliers are negative)
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1)
+    with pytest.raises(amd.LceHipError, match="float32"):
+        p8 = amd.Bconv2dPlan(_params(spec, amd.I8, out_scale=0.5))
+        p8.set_weights(w, mul, bias)
+        amd.check(amd.lib().lce_hip_bconv2d_run_dual(p8._h, xd.data_ptr(), y.data_ptr(), bits.data_ptr(), None))
+
+
+def test_run_host_pipelines_large_batches_and_binds_the_plan_to_its_device():
+    """lce_hip_bconv2d_run_host cuts a big batch into slices (H2D | kernel | D2H on three streams): same bits
+    as the device-resident run, from pageable and from page-locked (lce_hip_host_register) buffers."""
+    spec = O.ConvSpec(96, 56, 56, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 401)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    assert plan.device() == -1
+    want = plan.run(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    assert plan.device() == 0
+    for _ in range(2):
+        assert np.array_equal(plan.run_host(x).view(np.int32), want.view(np.int32))           # pageable buffers
+    x2 = np.ascontiguousarray(x[::-1])
+    out = np.empty_like(want)
+    with amd.host_register(x2, out):                                                          # page-locked buffers
+        for _ in range(2):
+            out[:] = 0
+            assert plan.run_host(x2, out) is out
+            assert np.array_equal(out.view(np.int32), want[::-1].view(np.int32))
+    subset = [0, 50, 95]
+    ref = O.bconv2d(O.ConvSpec(3, 56, 56, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), O.DST_F32, x[subset], w, mul, bias, threads=4)
+    assert np.array_equal(want[subset].view(np.int32), ref.view(np.int32))
+
+
+def test_one_plan_on_two_streams_workspace_variant():
+    """The workspace variant shares ONE FP4 workspace per plan: a run on a second stream must not expand
+    into it while the first stream's GEMM still reads it (the library orders them with an event)."""
+    spec = O.ConvSpec(16, 28, 28, 256, 3, 3, 256, padding=O.PADDING_SAME, pad_values=1)
+    xs = [synth.conv_inputs(spec, 500 + k)[0] for k in range(2)]
+    _, w, mul, bias = synth.conv_inputs(spec, 500)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    plan.set_option("engine", "mfma")
+    xd = [torch.from_numpy(x).to(DEV) for x in xs]
+    want = [plan.run(x).clone() for x in xd]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(20):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(plan.run(xd[k]))
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for o in outs[k]:
+            assert torch.equal(o, want[k]), plan.kernel_name()
 
 
 def test_conv_accumulator_overflow_shape():

@@ -344,6 +344,38 @@ def test_mfma_random_specs(seed):
         done += 1
 
 
+@pytest.mark.parametrize("engine", ["mfma", "direct"])
+@pytest.mark.parametrize("cin,cout,groups,tile", [(128, 128, 2, (128, 64)), (192, 256, 2, (128, 128)), (128, 256, 4, (128, 64)),
+                                                  (320, 128, 2, (256, 64)), (64, 128, 2, (128, 64))])
+def test_mfma_engine_grouped(cin, cout, groups, tile, engine):
+    """Grouped convolutions on the matrix cores: a block's channels lie in one group, its K loop covers the
+    64-channel chunks that group's input slice touches -- slices that start mid-chunk (Cin/G = 32, 96, 160)
+    share a chunk with their neighbour, whose channels carry zero weights."""
+    for pad, st in (("ONE", (1, 1)), ("VALID", (2, 1)), ("SAME", (1, 1))):
+        padding, pad_values = PADS[pad]
+        spec = O.ConvSpec(2, 9, 11, cin, 3, 3, cout, groups, st[0], st[1], 1, 1, padding, pad_values,
+                          O.ACT_RELU if pad == "VALID" else O.ACT_NONE, O.SEM_REFERENCE)
+        names = _run_all_dst_mfma(spec, seed=cin + cout + groups, tile=tile, engine=engine)
+        assert all("bconv2d_mfma" in n and ",%dx%d>" % tile in n for n in names), names
+
+
+@pytest.mark.parametrize("engine,tile", [("direct", (128, 128)), ("direct", (128, 256)), ("mfma", (256, 128)), ("direct", (256, 64))])
+def test_mfma_second_output_is_the_lcequantize_of_the_float_output(engine, tile):
+    """lce_hip_bconv2d_run_dual: the float epilogue also writes sign(y) bits, word for word what LceQuantize
+    makes of the float tensor -- negative multipliers, a RELU clamp (y >= 0 wherever the multiplier is
+    positive), partial last tiles and a channel count that leaves padding bits in the last word."""
+    for cout, act in ((128, O.ACT_NONE), (136, O.ACT_RELU)):
+        spec = O.ConvSpec(2, 11, 13, 64, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=act)
+        x, w, mul, bias = synth.conv_inputs(spec, 77 + cout, negative_mul_fraction=0.3)
+        bias = (bias - 40.0 * np.abs(mul)).astype(np.float32)          # both signs occur
+        words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, tile=tile, engine=engine, sign_words=words)
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+        assert np.array_equal(words, O.bitpack(want)), name
+        assert 0.02 < ((words.view(np.uint32)[..., 0] & 1) == 1).mean() < 0.98
+
+
 def test_mfma_engine_refuses_grouped():
     spec = O.ConvSpec(1, 6, 6, 128, 3, 3, 64, groups=2)
     x, w, mul, bias = synth.conv_inputs(spec, 1)
