@@ -6,19 +6,25 @@
 One "step" = one pass of the hot path over one batch of synthetic input: the LceBconv2d
 layer of BASELINE.json configs[1] -- 3x3, 256->256 channels, 56x56, SAME padding with
 pad_values=1, batch 256 PER GPU, float32 output through the fused output transform --
-with the bitpacked input, packed weights and output resident in HBM.  For N > 1 (launched
-by torch.distributed.run, one rank per GPU) the batch dimension is sharded: every rank
-runs its own 256 images, there is no data-path collective, RCCL is used
-only for the barrier and the max-over-ranks of the elapsed time.  `value` is whole-job
-binary MACs per second.
+with the bitpacked input, packed weights and output resident in HBM.
+
+N > 1: one rank per GPU over RCCL.  Under `torch.distributed.run` the ranks are already there
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); started as a plain `python bench.py
+--gpus N` this process launches them itself (torch.distributed.run, 127.0.0.1) and passes their output
+through.  The batch dimension is sharded: every rank runs its own 256 images, there is no data-path
+collective; RCCL carries the barrier, the max-over-ranks of the elapsed time and the
+gather of the per-rank times.  `value` is whole-job binary MACs per second.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (bconv2d_mfma, or bconv2d_tiled with engine=valu): algorithmic
-                bytes per launch / mean launch duration (events on the launch stream, kernel
-                timed alone) vs the 8 TB/s HBM peak -- the binding roofline of this layer;
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events on the
+                launch stream around the timed region; one launch per step) vs the 8 TB/s HBM peak;
   compute       the same kernel against the other roofline (FP4 MFMA peak, or the measured
                 v_xor+v_bcnt pair ceiling for the xor-popcount engine);
-  cpu_baseline  the CPU oracle (a port of the reference's portable C++ path) on the host
+  extra         the other BASELINE configs: L0 with int8 / bitpacked output, the four QuickNet layer
+                shapes, QuickNet (16 layers), QuickNetLarge (32 layers, config 4's per-GPU shard) and the
+                Bi-RealNet-style int8 stack (12 layers, config 5) as REAL device-resident chains, the
+                streaming ops;
+  cpu_baseline  the CPU oracle (a port of the reference's two portable C++ formulations) on the host
                 cores, on a bounded sample of the same workload (rank 0, N == 1 only).
 """
 from __future__ import annotations
@@ -27,6 +33,7 @@ import argparse
 import importlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -43,12 +50,6 @@ MFMA_FP4_PEAK_TFLOPS = 10000.0                         # MI355X_MICROARCH.md: FP
 VALU_BMAC_PEAK = 8.1e14                                # measured v_xor+v_bcnt ceiling (profiles/r01/valu_peak_microbench.jsonl)
 
 L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_out=256)
-QUICKNET = [(56, 64), (28, 128), (14, 256), (7, 512)]  # (H=W, C): 4 layers each in QuickNet
-
-
-def algorithmic_bytes(layer, dst) -> int:
-    """input words + weights + params + output, each counted once."""
-    return layer.algorithmic_bytes(dst)
 
 
 def _event_time(torch, dev, fn, steps):
@@ -77,8 +78,11 @@ def time_layer(amd, torch, layer, dst, steps, warmup, seed, dev, scale=1.0, zp=0
     return _event_time(torch, dev, lambda: plan.run(x, out), steps), plan.kernel_name(), plan, x, out
 
 
-def cpu_baseline(target_seconds=12.0):
-    """Time the CPU oracle (port of the reference's portable path) on the L0 layer."""
+def cpu_baseline(target_seconds=8.0):
+    """Time the CPU oracle -- BOTH portable formulations of the reference (the direct
+    loop of core/bconv2d/reference.h and the indirect BGEMM of core/indirect_bgemm/kernel_4x2_portable.h) --
+    on the L0 layer: one image on one thread each (as the reference runs them), then the faster one with
+    OpenMP over all host cores on a bounded number of images."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))   # the oracle's ctypes wrapper lives with the tests
     import oracle_lib as O
     import synth
@@ -86,20 +90,60 @@ def cpu_baseline(target_seconds=12.0):
     lib_note = "oracle/liblce_oracle.so (-O3 -march=x86-64-v3 -ffp-contract=off, OpenMP)"
     one = O.ConvSpec(batch=1, padding=O.PADDING_SAME, pad_values=1, **L0)
     x1, w, mul, bias = synth.conv_inputs(one, 1)
-    t = time.perf_counter()
-    O.bconv2d(one, O.DST_F32, x1, w, mul, bias, threads=1)
-    t1 = time.perf_counter() - t
-    per_image_parallel = t1 / max(1, cores) * 1.3
+    single = {}
+    for name, fn in (("BConv2DReference-shaped (direct loop)", O.bconv2d), ("Kernel4x2Portable-shaped (indirect BGEMM)", O.bconv2d_indirect)):
+        fn(one, O.DST_F32, x1, w, mul, bias, threads=1)
+        t = time.perf_counter()
+        fn(one, O.DST_F32, x1, w, mul, bias, threads=1)
+        single[name] = time.perf_counter() - t
+    best_name = min(single, key=single.get)
+    best = O.bconv2d if best_name.startswith("BConv2DReference") else O.bconv2d_indirect
+    per_image_parallel = single[best_name] / max(1, cores) * 1.3
     n = int(max(cores, min(256, target_seconds / max(per_image_parallel, 1e-6))))
     spec = O.ConvSpec(batch=n, padding=O.PADDING_SAME, pad_values=1, **L0)
     x = synth.random_words(synth.rng(2), spec.input_shape(), spec.channels_in)
     t = time.perf_counter()
-    O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=cores)
+    best(spec, O.DST_F32, x, w, mul, bias, threads=cores)
     dt = time.perf_counter() - t
     return {"value": spec.binary_macs / dt, "unit": "binary-MAC/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of 256 images of the same layer, float output, {dt:.1f} s wall; "
-                      f"1 image on 1 thread: {t1 * 1e3:.1f} ms; {lib_note}",
-            "single_thread_value": one.binary_macs / t1}
+            "sample": f"{n} of 256 images of the same layer, float output, {dt:.1f} s wall, {best_name}; {lib_note}",
+            "single_thread_one_image": {k: {"ms": v * 1e3, "bmac_per_s": one.binary_macs / v} for k, v in single.items()}}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_selftest(args):
+    """No GPU work: checks the launcher + process-group plumbing of this file with gloo on the CPU
+    (tests/test_batch_shard_gloo.py drives it at world size 2)."""
+    import torch
+    import torch.distributed as dist
+    shard = importlib.import_module("compute-engine_amd.batch_shard")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    assert (dist.get_world_size() if world > 1 else 1) == args.gpus, "world size != --gpus"
+    start, count = shard.shard_range(args.batch * world, world, rank)
+    elapsed = shard.max_over_ranks(0.001 * (rank + 1), dist if world > 1 else None)
+    per_rank = shard.gather_over_ranks(0.001 * (rank + 1), dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"launch_selftest": True, "n_gpus": world, "backend": "gloo", "max_ms": elapsed * 1e3,
+                          "per_rank_ms": [v * 1e3 for v in per_rank], "shard_of_rank0": [start, count]}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -110,7 +154,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--launch-selftest", action="store_true", help="CPU-only check of the multi-rank launch path (gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    if args.launch_selftest:
+        return launch_selftest(args)
 
     import torch
     amd = importlib.import_module("compute-engine_amd")
@@ -119,13 +169,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, the node has {torch.cuda.device_count()}")
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -150,16 +205,17 @@ def main():
         plan.run(x, out)
         evs[i + 1].record()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     barrier()
     region_event_sec = evs[0].elapsed_time(evs[-1]) / 1e3 / args.steps
     per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     pct = lambda q: per_step_ms[min(len(per_step_ms) - 1, int(q * len(per_step_ms)))]
-    elapsed = shard.max_over_ranks(elapsed, dist, dev)
+    elapsed = shard.max_over_ranks(elapsed_local, dist, dev)
+    per_rank = shard.gather_over_ranks(elapsed_local, dist, dev)
 
     total_bmacs = spec.binary_macs * args.steps * world
     value = total_bmacs / elapsed
-    abytes = algorithmic_bytes(spec, SL.DST_F32)
+    abytes = spec.algorithmic_bytes(SL.DST_F32)
     mfma = kname.startswith("bconv2d_mfma")
     direct = kname.startswith("bconv2d_mfma_direct")   # single kernel: the block expands its own input halo
 
@@ -179,6 +235,8 @@ def main():
         # spread of the K timed steps (the chip's power management moves the clock during a run)
         "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
         "per_gpu_value": value / world,
+        "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+        "per_rank_ms_per_step": [v / args.steps * 1e3 for v in per_rank],
         "kernel": kname + ("+expand_fp4" if mfma and not direct else ""),
     }
     if rank == 0:
@@ -193,21 +251,23 @@ def main():
             # one kernel per step: its average duration IS the event time of the timed region / K
             k_sec, e_sec = region_event_sec, 0.0
         ach = abytes / k_sec / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this kernel, not measured in this run)"
             except Exception:
                 traffic = None
         result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_launch": abytes, "kernel": kname,
                               "kernel_ms": k_sec * 1e3, "expand_fp4_ms": e_sec * 1e3,
                               "kernel_ms_source": ("phase=gemm re-run, HIP events" if mfma and not direct else
                                                    "HIP events around the timed region / steps (one launch per step)"),
-                              "note": "HBM is the binding roofline of this layer at spec peaks "
-                                      "(0.106 ms vs 0.095 ms of FP4 MFMA); see `compute` for the other one"}
+                              "note": "HBM is the binding roofline of this layer at spec peaks (0.106 ms vs 0.095 ms of FP4 "
+                                      "MFMA); the output stream alone needs 0.137 ms at the 6.0 TB/s this chip writes "
+                                      "(tools/probes/store_overlap.hip); see `compute` for the other roofline"}
         if mfma:
             tf = 2.0 * spec.binary_macs / k_sec / 1e12
             result["compute"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -218,105 +278,104 @@ def main():
                                  "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
                                  "model": "v_xor_b32 + v_bcnt_u32_b32 per 32 bMAC, measured pair ceiling"}
         if not args.no_extra and world == 1:
-            extra = {}
-            st, wu = max(5, args.steps // 5), 3
-            sc, zp = 0.125, 3
-            for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
-                s_, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
-                extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
-                             "GBps_algorithmic": algorithmic_bytes(spec, od) / s_ / 1e9}
-            # the other matrix-core variant (FP4 workspace + GEMM whose tiles span images)
-            s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="mfma")
-            extra["l0_f32_workspace_gemm"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn + "+expand_fp4"}
-            # the xor-popcount engine on the same layer (the north star's literal formulation)
-            s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="valu")
-            extra["l0_f32_valu_engine"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
-                                           "valu_pair_frac": spec.binary_macs / s_ / VALU_BMAC_PEAK}
-            tot = 0.0
-            for hw, c in QUICKNET:
-                sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
-                              channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
-                s_, kn, *_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
-                tot += 4 * s_
-                extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {
-                    "ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
-                    "GBps_algorithmic": algorithmic_bytes(sp, SL.DST_F32) / s_ / 1e9,
-                    "hbm_frac": algorithmic_bytes(sp, SL.DST_F32) / s_ / 1e9 / HBM_PEAK_GBS}
-            extra["quicknet_16_layers_ms"] = tot * 1e3
-            # BASELINE config 4: QuickNetLarge = blocks (6, 8, 12, 6) of the same four layer shapes
-            extra["quicknet_large_32_layers_ms"] = sum(
-                n * extra[f"quicknet_{hw}x{hw}x{c}_f32"]["ms"] for n, (hw, c) in zip((6, 8, 12, 6), QUICKNET))
-            # the same 16 layers as ONE device-resident chain, each fed by LceQuantize of the previous
-            # float output (what a converted QuickNet does between its binary convolutions), replayed
-            # from a captured HIP graph: launch gaps and the LceQuantize passes included
-            try:
-                chain = []
-                for hw, c in QUICKNET:
-                    sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
-                                  channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
-                    _, _, pl, xq, yo = time_layer(amd, torch, sp, amd.F32, 1, 1, hw, dev)
-                    chain.append((pl, xq, yo))
-
-                def run_chain():
-                    for pl, xq, yo in chain:
-                        for _ in range(4):
-                            pl.run(xq, yo)
-                            amd.bitpack(yo, out=xq)
-                run_chain()
-                torch.cuda.synchronize(dev)
-                eager = _event_time(torch, dev, run_chain, st)
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    run_chain()
-                torch.cuda.current_stream(dev).wait_stream(side)
-                torch.cuda.synchronize(dev)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    run_chain()
-                graph.replay()
-                torch.cuda.synchronize(dev)
-                extra["quicknet_16_layers_with_lcequantize_chain_ms"] = {
-                    "eager": eager * 1e3, "hip_graph_replay": _event_time(torch, dev, graph.replay, st) * 1e3}
-                del chain, graph
-            except Exception as e:   # a report line must not take the bench down
-                extra["quicknet_16_layers_with_lcequantize_chain_ms"] = {"error": repr(e)[:200]}
-            # BASELINE config 5 flavour: 1x1 int8-output layers with a RELU clamp (the HBM-bound cases)
-            for hw, c in QUICKNET:
-                sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
-                              channels_out=c, activation=SL.ACT_RELU)
-                s_, kn, *_ = time_layer(amd, torch, sp, amd.I8, st, wu, hw + 1, dev, sc, zp)
-                ab = algorithmic_bytes(sp, SL.DST_I8)
-                extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {
-                    "ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
-                    "GBps_algorithmic": ab / s_ / 1e9, "hbm_frac": ab / s_ / 1e9 / HBM_PEAK_GBS}
-            # LceQuantize stream: float32 56x56x256 feature map, batch 256
-            fx = torch.randn((args.batch, 56, 56, 256), device=dev)
-            ow = amd.bitpack(fx)
-            torch.cuda.synchronize(dev)
-            s_ = _event_time(torch, dev, lambda: amd.bitpack(fx, out=ow), st)
-            qb = fx.numel() * 4 + ow.numel() * 4
-            extra["lcequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": qb / s_ / 1e9,
-                                                      "hbm_frac": qb / s_ / 1e9 / HBM_PEAK_GBS}
-            # LceDequantize (bits -> float) and LceBMaxPool2d (2x2 stride 2) on the same feature map
-            fo = amd.unpack(ow, 256, torch.float32)
-            torch.cuda.synchronize(dev)
-            s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32), st)
-            extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": qb / s_ / 1e9,
-                                                        "hbm_frac": qb / s_ / 1e9 / HBM_PEAK_GBS}
-            po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
-            torch.cuda.synchronize(dev)
-            s_ = _event_time(torch, dev, lambda: amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID), st)
-            pb = ow.numel() * 4 + po.numel() * 4
-            extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, "GBps_algorithmic": pb / s_ / 1e9,
-                                                        "hbm_frac": pb / s_ / 1e9 / HBM_PEAK_GBS}
-            del fx, ow, fo, po
-            result["extra"] = extra
+            result["extra"] = extra_measurements(amd, torch, spec, args, dev)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extra_measurements(amd, torch, spec, args, dev):
+    """Everything else BASELINE.json names, on the same GPU (N == 1 only): never part of `value`."""
+    import layer_chain
+    extra = {}
+    st, wu = max(5, args.steps // 5), 3
+    sc, zp = 0.125, 3
+    hbm = lambda b, s: {"GBps_algorithmic": b / s / 1e9, "hbm_frac": b / s / 1e9 / HBM_PEAK_GBS}
+    for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
+        s_, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
+        extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_)}
+    # the other matrix-core variant (FP4 workspace + GEMM whose tiles span images) and the xor-popcount
+    # engine (the north star's literal formulation) on the same layer
+    s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="mfma")
+    extra["l0_f32_workspace_gemm"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn + "+expand_fp4"}
+    s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="valu")
+    extra["l0_f32_valu_engine"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
+                                   "valu_pair_frac": spec.binary_macs / s_ / VALU_BMAC_PEAK}
+    # BASELINE config 3: the four QuickNet layer shapes, one at a time ...
+    for hw, c in SL.QUICKNET_STAGES:
+        sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                      channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
+        s_, kn, *_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
+        extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
+                                                **hbm(sp.algorithmic_bytes(SL.DST_F32), s_)}
+        # ... and the 1x1 int8 + RELU layers of config 5's flavour (the HBM-bound cases)
+        sp1 = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
+                       channels_out=c, activation=SL.ACT_RELU)
+        s_, kn, *_ = time_layer(amd, torch, sp1, amd.I8, st, wu, hw + 1, dev, sc, zp)
+        extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sp1.binary_macs / s_, "kernel": kn,
+                                                       **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_)}
+
+    # configs 3, 4 (one GPU's shard) and 5 as REAL stacks: every layer has its own plan, weights and
+    # buffers, run back to back on one stream -- (a) the convolutions alone, each on its own input;
+    # (b) the device-resident chain, each output quantized into the next layer's input by the same
+    # epilogue (lce_hip_bconv2d_run_dual); (c) the same chain with a separate LceQuantize pass per layer
+    def stack(name, layers, dst):
+        try:
+            ch = layer_chain.LayerChain(amd, torch, layers, dev, dst=dst, seed=4000)
+            ch.run_chain()
+            ch.run_convs()
+            torch.cuda.synchronize(dev)
+            convs = _event_time(torch, dev, ch.run_convs, st)
+            fused = _event_time(torch, dev, lambda: ch.run_chain(fused=True), st)
+            entry = {"layers": len(layers), "batch": args.batch, "convolutions_only_ms": convs * 1e3,
+                     "bmac_per_s": ch.binary_macs / convs, **hbm(ch.algorithmic_bytes(), convs),
+                     "device_resident_chain_ms": fused * 1e3}
+            if dst == "f32":
+                entry["chain_with_separate_lcequantize_ms"] = _event_time(torch, dev, lambda: ch.run_chain(fused=False), st) * 1e3
+            # launch gaps: the chain replayed from a captured HIP graph
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                ch.run_chain()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ch.run_chain()
+            graph.replay()
+            torch.cuda.synchronize(dev)
+            entry["device_resident_chain_hip_graph_ms"] = _event_time(torch, dev, graph.replay, st) * 1e3
+            entry["kernels"] = sorted(set(ch.kernel_names()))
+            extra[name] = entry
+            del ch, graph
+        except Exception as e:   # a report line must not take the bench down
+            extra[name] = {"error": repr(e)[:300]}
+
+    stack("quicknet_16_layers", SL.quicknet_layers(args.batch), "f32")
+    stack("quicknet_large_32_layers_per_gpu_shard", SL.quicknet_layers(args.batch, (6, 8, 12, 6)), "f32")
+    stack("birealnet_style_12_layers_int8_relu", SL.birealnet_layers(args.batch), "i8")
+
+    # LceQuantize stream: float32 56x56x256 feature map, batch 256
+    fx = torch.randn((args.batch, 56, 56, 256), device=dev)
+    ow = amd.bitpack(fx)
+    torch.cuda.synchronize(dev)
+    s_ = _event_time(torch, dev, lambda: amd.bitpack(fx, out=ow), st)
+    qb = fx.numel() * 4 + ow.numel() * 4
+    extra["lcequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
+    # LceDequantize (bits -> float) and LceBMaxPool2d (2x2 stride 2) on the same feature map
+    fo = amd.unpack(ow, 256, torch.float32)
+    torch.cuda.synchronize(dev)
+    s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32), st)
+    extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
+    po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
+    torch.cuda.synchronize(dev)
+    s_ = _event_time(torch, dev, lambda: amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID), st)
+    pb = ow.numel() * 4 + po.numel() * 4
+    extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(pb, s_)}
+    del fx, ow, fo, po
+    return extra
 
 
 if __name__ == "__main__":

@@ -33,6 +33,17 @@ def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(seconds: float, dist=None, device=None) -> list:
+    """Every rank's elapsed time, in rank order (bench.py reports them next to the MAX)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [seconds]
+    import torch
+    mine = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]
+
+
 def all_gather_batch(local, global_batch: int, dist):
     """Reassemble the full-batch tensor on every rank from contiguous shards (shards may
     differ by one image, so they are padded to the largest shard for the collective)."""

@@ -432,6 +432,124 @@ void lce_oracle_zero_pad_apply(const lce_oracle_conv* c, const float* cache, flo
 /* LceBMaxPool2d, core/bmaxpool.h:24-88 ("next" row n1 of SURVEY section 8f). */
 /* ------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------
+ * The reference's OTHER portable kernel for the same convolution: the indirect BGEMM
+ * (core/indirect_bgemm/kernel.h:16-186 + kernel_4x2_portable.h:22-158).  Restated as the
+ * reference structures it -- weights repacked once into blocks of 4 output channels
+ * ([group][block of 4][tap][word][4], kernel.h:54-94), an indirection table with one entry
+ * per (pair of output pixels, tap, pixel) that points at the pixel's input words or at a
+ * shared all-zero row for taps outside the image (= +1 padding, kernel.h:101-174), and a
+ * 4-channel x 2-pixel micro-kernel with eight int32 accumulators that walks taps, then
+ * words (kernel_4x2_portable.h:84-111) -- so that bench.py can time BOTH portable CPU
+ * formulations.  Float / int8 output; VALID or one-padding
+ * (SAME-zero is this kernel + lce_oracle_zero_pad_apply in the reference too,
+ * optimized_indirect_bgemm.h:35-61).  Results are bit-identical to lce_oracle_bconv2d_*.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t* packed;       /* [G][ceil(Npg/4)][taps][Cwg][4], missing channels of a last block stay 0 */
+  int64_t* indirect;     /* [ceil(M/2)][taps][2]: word offset of the pixel's row in `input`, or -1 */
+  int64_t pixels;
+} indirect_plan;
+
+static void indirect_pack_weights(const lce_oracle_conv* c, const int32_t* filter, int32_t* packed) {
+  const int taps = c->filter_h * c->filter_w, g_count = c->groups;
+  const int cwg = lce_oracle_bitpacked_size(c->channels_in / g_count), npg = c->channels_out / g_count;
+  const int blocks = (npg + 3) / 4;
+  memset(packed, 0, sizeof(int32_t) * (size_t)g_count * blocks * taps * cwg * 4);
+  for (int g = 0; g < g_count; ++g)
+    for (int blk = 0; blk < blocks; ++blk)
+      for (int t = 0; t < taps; ++t)
+        for (int w = 0; w < cwg; ++w)
+          for (int k = 0; k < 4 && blk * 4 + k < npg; ++k) {
+            const int oc = g * npg + blk * 4 + k;
+            packed[((((size_t)g * blocks + blk) * taps + t) * cwg + w) * 4 + k] =
+                filter[((size_t)oc * taps + t) * cwg + w];
+          }
+}
+
+static void indirect_fill_table(const lce_oracle_conv* c, int64_t* table) {
+  const int taps = c->filter_h * c->filter_w, cw = lce_oracle_bitpacked_size(c->channels_in);
+  const int64_t m_total = (int64_t)c->batch * c->out_h * c->out_w, pairs = (m_total + 1) / 2;
+  for (int64_t pr = 0; pr < pairs; ++pr)
+    for (int k = 0; k < 2; ++k) {
+      int64_t m = 2 * pr + k;
+      if (m >= m_total) m = m_total - 1;                       /* the odd tail re-reads the last pixel (kernel.h:133-134) */
+      const int64_t b = m / ((int64_t)c->out_h * c->out_w);
+      const int oy = (int)((m / c->out_w) % c->out_h), ox = (int)(m % c->out_w);
+      for (int fy = 0; fy < c->filter_h; ++fy)
+        for (int fx = 0; fx < c->filter_w; ++fx) {
+          const int iy = oy * c->stride_h + fy * c->dilation_h - c->pad_h;
+          const int ix = ox * c->stride_w + fx * c->dilation_w - c->pad_w;
+          const int inside = iy >= 0 && iy < c->in_h && ix >= 0 && ix < c->in_w;
+          table[(pr * taps + fy * c->filter_w + fx) * 2 + k] =
+              inside ? ((b * c->in_h + iy) * c->in_w + ix) * cw : -1;
+        }
+    }
+}
+
+static void indirect_run(const lce_oracle_conv* c, const int32_t* input, const int32_t* packed,
+                         const int64_t* table, int dst_type, const float* mul, const float* bias,
+                         int32_t cmin, int32_t cmax, void* out, int num_threads) {
+  const int taps = c->filter_h * c->filter_w, g_count = c->groups;
+  const int cw = lce_oracle_bitpacked_size(c->channels_in);
+  const int cwg = lce_oracle_bitpacked_size(c->channels_in / g_count), npg = c->channels_out / g_count;
+  const int blocks = (npg + 3) / 4, n = c->channels_out;
+  const int64_t m_total = (int64_t)c->batch * c->out_h * c->out_w, pairs = (m_total + 1) / 2;
+  int32_t* zero_row = (int32_t*)calloc((size_t)cw, sizeof(int32_t));
+  (void)num_threads;
+#pragma omp parallel for schedule(static) num_threads(num_threads > 1 ? num_threads : 1)
+  for (int64_t pr = 0; pr < pairs; ++pr) {
+    const int64_t m0 = 2 * pr, m1 = m0 + 1 < m_total ? m0 + 1 : m0;   /* a lone last pixel is computed twice */
+    const int64_t* tab = table + pr * taps * 2;
+    for (int g = 0; g < g_count; ++g)
+      for (int blk = 0; blk < blocks; ++blk) {
+        int32_t acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        const int32_t* wp = packed + (((size_t)g * blocks + blk) * taps) * cwg * 4;
+        for (int t = 0; t < taps; ++t) {
+          const int32_t* a0 = (tab[t * 2] < 0 ? zero_row : input + tab[t * 2]) + (size_t)g * cwg;
+          const int32_t* a1 = (tab[t * 2 + 1] < 0 ? zero_row : input + tab[t * 2 + 1]) + (size_t)g * cwg;
+          for (int w = 0; w < cwg; ++w, wp += 4)
+            for (int k = 0; k < 4; ++k) {
+              acc[k][0] += xor_popcount(wp[k], a0[w]);
+              acc[k][1] += xor_popcount(wp[k], a1[w]);
+            }
+        }
+        for (int k = 0; k < 4 && blk * 4 + k < npg; ++k) {
+          const int oc = g * npg + blk * 4 + k;
+          if (dst_type == LCE_ORACLE_DST_F32) {
+            ((float*)out)[m1 * n + oc] = ot_float(acc[k][1], cmin, cmax, mul[oc], bias[oc]);
+            ((float*)out)[m0 * n + oc] = ot_float(acc[k][0], cmin, cmax, mul[oc], bias[oc]);
+          } else {
+            ((int8_t*)out)[m1 * n + oc] = ot_int8(acc[k][1], cmin, cmax, mul[oc], bias[oc]);
+            ((int8_t*)out)[m0 * n + oc] = ot_int8(acc[k][0], cmin, cmax, mul[oc], bias[oc]);
+          }
+        }
+      }
+  }
+  free(zero_row);
+}
+
+int lce_oracle_bconv2d_indirect(const lce_oracle_conv* c, const int32_t* input, const int32_t* filter,
+                                int dst_type, const float* mul, const float* bias, int32_t clamp_min,
+                                int32_t clamp_max, void* out, int num_threads) {
+  if (dst_type != LCE_ORACLE_DST_F32 && dst_type != LCE_ORACLE_DST_I8) return 1;
+  if (c->padding == LCE_ORACLE_PADDING_SAME && c->pad_values == 0) return 2;   /* caller adds the correction */
+  const int taps = c->filter_h * c->filter_w;
+  const int cwg = lce_oracle_bitpacked_size(c->channels_in / c->groups), npg = c->channels_out / c->groups;
+  const int64_t m_total = (int64_t)c->batch * c->out_h * c->out_w, pairs = (m_total + 1) / 2;
+  if (m_total == 0) return 0;
+  int32_t* packed = (int32_t*)malloc(sizeof(int32_t) * (size_t)c->groups * ((npg + 3) / 4) * taps * cwg * 4);
+  int64_t* table = (int64_t*)malloc(sizeof(int64_t) * (size_t)pairs * taps * 2);
+  if (!packed || !table) { free(packed); free(table); return 3; }
+  indirect_pack_weights(c, filter, packed);     /* once per layer in the reference (first Eval) */
+  indirect_fill_table(c, table);
+  indirect_run(c, input, packed, table, dst_type, mul, bias, clamp_min, clamp_max, out, num_threads);
+  free(packed);
+  free(table);
+  return 0;
+}
+
+
 void lce_oracle_bmaxpool(int32_t batch, int32_t in_h, int32_t in_w, int32_t words,
                          int32_t filter_h, int32_t filter_w, int32_t stride_h,
                          int32_t stride_w, int32_t padding, const int32_t* in,

@@ -108,6 +108,12 @@ void lce_oracle_bconv2d_i8(const lce_oracle_conv* c, const int32_t* input,
 void lce_oracle_bconv2d_bitpacked(const lce_oracle_conv* c, const int32_t* input,
                                   const int32_t* filter, const int32_t* thresholds,
                                   int32_t* out, int num_threads);
+/* The same convolution by the reference's indirect-BGEMM formulation (core/indirect_bgemm/kernel.h:16-186,
+ * kernel_4x2_portable.h:22-158): packed weight blocks of 4 channels, an indirection table, a 4x2 micro-kernel.
+ * dst_type F32 or I8, VALID or one-padding; returns 0 on success.  Bit-identical to the functions above. */
+int lce_oracle_bconv2d_indirect(const lce_oracle_conv* c, const int32_t* input, const int32_t* filter,
+                                int dst_type, const float* mul, const float* bias, int32_t clamp_min,
+                                int32_t clamp_max, void* out, int num_threads);
 /* raw accumulators (sum of xor-popcounts, incl. zero-padding terms) for debugging */
 void lce_oracle_bconv2d_accum(const lce_oracle_conv* c, const int32_t* input,
                               const int32_t* filter, int32_t* out, int num_threads);

@@ -251,6 +251,23 @@ def bconv2d(spec: ConvSpec, dst_type: int, inp: np.ndarray, filt: np.ndarray,
     return out
 
 
+def bconv2d_indirect(spec: ConvSpec, dst_type: int, inp: np.ndarray, filt: np.ndarray, post_mul, post_bias,
+                     out_scale: float = 1.0, out_zero_point: int = 0, threads: int = 1) -> np.ndarray:
+    """The same op through the restatement of the reference's indirect BGEMM (packed 4-channel weight
+    blocks, indirection table, 4x2 micro-kernel; core/indirect_bgemm/kernel.h, kernel_4x2_portable.h).
+    Float / int8 output, VALID or one-padding."""
+    inp = np.ascontiguousarray(inp, dtype=np.int32)
+    filt = np.ascontiguousarray(filt, dtype=np.int32)
+    assert inp.shape == spec.input_shape() and filt.shape == spec.filter_shape()
+    mul, bias, cmin, cmax = fold_output_transform(spec, dst_type, post_mul, post_bias, out_scale, out_zero_point)
+    out = np.empty(spec.output_shape(dst_type), np.float32 if dst_type == DST_F32 else np.int8)
+    rc = lib().lce_oracle_bconv2d_indirect(C.byref(spec.c_struct()), _p(inp), _p(filt), C.c_int(dst_type), _p(mul),
+                                           _p(bias), C.c_int32(cmin), C.c_int32(cmax), _p(out), C.c_int(threads))
+    if rc != 0:
+        raise ValueError(f"lce_oracle_bconv2d_indirect refused the case (rc {rc})")
+    return out
+
+
 def bmaxpool(x: np.ndarray, filter_h, filter_w, stride_h, stride_w, padding) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.int32)
     b, h, w, c = x.shape

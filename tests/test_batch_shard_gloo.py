@@ -69,3 +69,31 @@ def test_sharded_run_equals_full_batch(world, global_batch):
     assert sorted(r for r, _, _ in results) == list(range(world))
     assert all(ok for _, ok, _ in results)
     assert all(abs(t - 0.001 * world) < 1e-9 for _, _, t in results)      # MAX over ranks
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it starts N ranks itself (torch.distributed.run on
+    127.0.0.1) -- the path the driver's scaling runs take.  --launch-selftest swaps the GPU work for the
+    process-group plumbing over gloo, so the launch, the world-size check, the max-over-ranks and the
+    per-rank gather are exercised on the CPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                          "--launch-selftest"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 prints ONE line
+    r = lines[0]
+    assert r["n_gpus"] == world and r["launch_selftest"] and len(r["per_rank_ms"]) == world
+    assert abs(r["max_ms"] - world) < 1e-6 and r["per_rank_ms"] == pytest.approx([k + 1.0 for k in range(world)])
+    assert r["shard_of_rank0"] == [0, 256]      # weak scaling: 256 images per rank
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "world size != --gpus" in (out.stderr + out.stdout)

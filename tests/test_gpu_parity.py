@@ -765,3 +765,97 @@ def test_two_plans_on_two_streams_from_two_threads():
         t.join()
     assert not errors, errors
 
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs 4 and 5 at full size
+
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
+
+
+def _chain(layers, dst, seed, engine="auto"):
+    import layer_chain
+    return layer_chain.LayerChain(amd, torch, layers, DEV, dst=dst, seed=seed, engine=engine)
+
+
+def _spec_of(L, batch):
+    return O.ConvSpec(batch, L.in_h, L.in_w, L.channels_in, L.filter_h, L.filter_w, L.channels_out, 1, L.stride, L.stride,
+                      1, 1, L.padding, L.pad_values, L.activation)
+
+
+def _check_chain(chain, subset, odst):
+    """(a) the oracle, run as the same chain on a seeded subset of the images, reproduces every layer's bytes;
+    (b) batch independence: the subset run alone through a second chain gives the same bytes;
+    (c) every layer, fed the very input the chain fed it, is bit-equal under the independently written
+        any-shape xor-popcount kernel (all images)."""
+    import synthetic_layers as SL
+    torch.cuda.synchronize()
+    names = chain.kernel_names()
+    prev = None
+    for k, L in enumerate(chain.layers):
+        w, mul, bias = chain.weights[k]
+        scale, zp = chain.quant[k]
+        x = prev if chain.fed[k] else chain.x[k][subset].cpu().numpy()
+        want = O.bconv2d(_spec_of(L, len(subset)), odst, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=8)
+        got = chain.y[k][subset].cpu().numpy()
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (k, names[k])
+        prev = O.bitpack(want, zp) if odst == O.DST_I8 else O.bitpack(want)
+        assert np.array_equal(chain.bits[k][subset].cpu().numpy(), prev), (k, names[k])
+    small = _chain([type(L)(**{**L.__dict__, "batch": len(subset)}) for L in chain.layers], chain.dst, 0)
+    small.weights, small.quant = chain.weights, chain.quant
+    for k, p in enumerate(small.plans):
+        p.set_weights(*chain.weights[k])
+        sc, zp = chain.quant[k]
+        if chain.dst == "i8":   # same output quantization as the big chain's layer k
+            small.plans[k] = amd.Bconv2dPlan(small.layers[k].params(amd, amd.I8, sc, zp))
+            small.plans[k].set_weights(*chain.weights[k])
+        small.x[k] = chain.x[k][subset].contiguous()
+    small.run_chain()
+    torch.cuda.synchronize()
+    for k in range(len(chain.layers)):
+        assert torch.equal(small.y[k], chain.y[k][subset]), (k, names[k])
+    for k, L in enumerate(chain.layers):
+        sc, zp = chain.quant[k]
+        g = amd.Bconv2dPlan(L.params(amd, amd.I8 if chain.dst == "i8" else amd.F32, sc, zp))
+        g.set_weights(*chain.weights[k])
+        g.set_option("engine", "valu")
+        g.set_option("kernel", "general")
+        ref = g.run(chain.bits[k - 1] if chain.fed[k] else chain.x[k])
+        assert g.kernel_name().startswith("bconv2d_general"), g.kernel_name()
+        assert torch.equal(ref, chain.y[k]), (k, names[k])
+    return names
+
+
+def test_birealnet_stack_batch256():
+    """BASELINE config 5 at its size: twelve layers -- per section 1x1 s1 -> 3x3 s1 -> 3x3 s2 over
+    56x56x64 ... 7x7x512 -- int8 output transform with a fused RELU, batch 256, ONE device-resident chain
+    (each int8 output is quantized at its zero point into the next layer's input), planner's own engines.
+    Mirrors tflite/tests/bconv2d_test.cc:790-856 (strides, 1x1 and 3x3 filters, int8 outputs)."""
+    import synthetic_layers as SL
+    chain = _chain(SL.birealnet_layers(256), "i8", 900)
+    assert all(chain.fed[1:])
+    chain.run_chain()
+    names = _check_chain(chain, [0, 131, 255], O.DST_I8)
+    assert all(n.startswith("bconv2d_mfma") for n in names), names
+
+
+def test_quicknet_large_per_gpu_shard_batch256():
+    """BASELINE config 4, one GPU's shard: QuickNetLarge's 32 binary convolutions (blocks 6, 8, 12, 6) on 256
+    images as one device-resident chain.  The fused second output (sign bits from the convolution's own
+    epilogue) must give the very same chain as a separate LceQuantize pass after every layer."""
+    import synthetic_layers as SL
+    chain = _chain(SL.quicknet_layers(256, (6, 8, 12, 6)), "f32", 950)
+    assert len(chain.layers) == 32 and sum(chain.fed) == 28
+    chain.run_chain(fused=False)
+    torch.cuda.synchronize()
+    unfused = [(y.clone(), b.clone()) for y, b in zip(chain.y, chain.bits)]
+    for y, b in zip(chain.y, chain.bits):
+        y.zero_()
+        b.zero_()
+    chain.run_chain(fused=True)
+    torch.cuda.synchronize()
+    for k, (y, b) in enumerate(unfused):
+        assert torch.equal(y, chain.y[k]) and torch.equal(b, chain.bits[k]), k
+    names = _check_chain(chain, [0, 255], O.DST_F32)
+    assert all(n.startswith("bconv2d_mfma_direct") for n in names), names

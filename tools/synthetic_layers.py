@@ -101,3 +101,34 @@ def weights(layer: Layer, seed: int):
 
 def activations(layer: Layer, seed: int) -> np.ndarray:
     return random_words(rng(seed + 7), layer.input_shape(), layer.channels_in)
+
+
+# ---- the BASELINE.json model stacks, as lists of layers ----------------
+QUICKNET_STAGES = ((56, 64), (28, 128), (14, 256), (7, 512))      # (H = W, channels) of the four binary sections
+
+
+def quicknet_layers(batch: int, blocks=(4, 4, 4, 4)) -> list:
+    """QuickNet's binary convolutions (3x3, stride 1, SAME with pad_values = 1, float output feeding a
+    residual add): `blocks` layers per section -- (4, 4, 4, 4) = QuickNet, (6, 8, 12, 6) = QuickNetLarge."""
+    out = []
+    for n, (hw, c) in zip(blocks, QUICKNET_STAGES):
+        out += [Layer(batch, hw, hw, c, 3, 3, c, padding=PADDING_SAME, pad_values=1) for _ in range(n)]
+    return out
+
+
+def birealnet_layers(batch: int) -> list:
+    """a Bi-RealNet-style chain with int8 outputs and a fused RELU -- per section
+    1x1 stride 1 -> 3x3 stride 1 -> 3x3 stride 2 (which also doubles the channels for the next section)."""
+    out = []
+    for k, (hw, c) in enumerate(QUICKNET_STAGES):
+        nxt = QUICKNET_STAGES[k + 1][1] if k + 1 < len(QUICKNET_STAGES) else c
+        out.append(Layer(batch, hw, hw, c, 1, 1, c, activation=ACT_RELU))
+        out.append(Layer(batch, hw, hw, c, 3, 3, c, padding=PADDING_SAME, pad_values=1, activation=ACT_RELU))
+        out.append(Layer(batch, hw, hw, c, 3, 3, nxt, stride=2, padding=PADDING_SAME, pad_values=1, activation=ACT_RELU))
+    return out
+
+
+def int8_quant(seed: int):
+    """(output scale, output zero point) of an int8-output layer: scale in [1/16, 1/4], zero point in [-20, 20]."""
+    g = rng(seed + 31)
+    return float(g.choice([1 / 16, 1 / 8, 3 / 16, 1 / 4])), int(g.integers(-20, 21))
