@@ -367,13 +367,27 @@ def extra_measurements(amd, torch, spec, args, dev):
     # LceDequantize (bits -> float) and LceBMaxPool2d (2x2 stride 2) on the same feature map
     fo = amd.unpack(ow, 256, torch.float32)
     torch.cuda.synchronize(dev)
-    s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32), st)
+    s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32, out=fo), st)
     extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
     po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
     torch.cuda.synchronize(dev)
-    s_ = _event_time(torch, dev, lambda: amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID), st)
+    # (a 5 us kernel: timed from a captured HIP graph of 20 launches, or the host's launch rate is what is measured)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID, out=po)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(20):
+            amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID, out=po)
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    s_ = _event_time(torch, dev, graph.replay, st) / 20
     pb = ow.numel() * 4 + po.numel() * 4
-    extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(pb, s_)}
+    extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(pb, s_),
+                                                "note": "26 MB input, just written: largely served by the 256 MB Infinity Cache"}
     del fx, ow, fo, po
     return extra
 

@@ -325,13 +325,15 @@ def bitpack(x, zero_point: int = 0, out=None, stream: int | None = None):
     return out
 
 
-def unpack(words, channels: int, dtype, scale: float = 1.0, zero_point: int = 0, stream: int | None = None):
+def unpack(words, channels: int, dtype, scale: float = 1.0, zero_point: int = 0, stream: int | None = None, out=None):
     """LceDequantize on a CUDA int32 tensor."""
     import torch
     assert words.is_cuda and words.dtype == torch.int32 and words.is_contiguous()
     t = {torch.float32: F32, torch.int8: I8, torch.bool: BOOL}[dtype]
     rows = words.numel() // words.shape[-1]
-    out = torch.empty(tuple(words.shape[:-1]) + (channels,), dtype=dtype, device=words.device)
+    if out is None:
+        out = torch.empty(tuple(words.shape[:-1]) + (channels,), dtype=dtype, device=words.device)
+    assert out.is_cuda and out.dtype == dtype and out.is_contiguous() and tuple(out.shape) == tuple(words.shape[:-1]) + (channels,)
     with torch.cuda.device(words.device):
         if stream is None:
             stream = torch.cuda.current_stream(words.device).cuda_stream
@@ -340,7 +342,7 @@ def unpack(words, channels: int, dtype, scale: float = 1.0, zero_point: int = 0,
     return out
 
 
-def bmaxpool(x, filter_height, filter_width, stride_height, stride_width, padding, stream: int | None = None):
+def bmaxpool(x, filter_height, filter_width, stride_height, stride_width, padding, stream: int | None = None, out=None):
     """LceBMaxPool2d on a CUDA int32 tensor [B,H,W,words]."""
     import torch
     assert x.is_cuda and x.dtype == torch.int32 and x.is_contiguous() and x.dim() == 4
@@ -348,7 +350,9 @@ def bmaxpool(x, filter_height, filter_width, stride_height, stride_width, paddin
     oh, ow = C.c_int32(), C.c_int32()
     check(lib().lce_hip_bmaxpool_output_shape(h, w, filter_height, filter_width, stride_height,
                                               stride_width, padding, C.byref(oh), C.byref(ow)))
-    out = torch.empty((b, oh.value, ow.value, c), dtype=torch.int32, device=x.device)
+    if out is None:
+        out = torch.empty((b, oh.value, ow.value, c), dtype=torch.int32, device=x.device)
+    assert out.is_cuda and out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (b, oh.value, ow.value, c)
     with torch.cuda.device(x.device):
         if stream is None:
             stream = torch.cuda.current_stream(x.device).cuda_stream

@@ -704,10 +704,15 @@ lce_hip_status lce_hip_bmaxpool(const int32_t* input_dev, int32_t batch, int32_t
   if (lce_hip_status s = require_device()) return s;
   const int ph = std::max(0, (oh - 1) * sh + fh - in_h) / 2;
   const int pw = std::max(0, (ow - 1) * sw + fw - in_w) / 2;
-  const uint64_t total = (uint64_t)batch * oh * ow * words;
+  // 16 bytes per thread when the words of a pixel come in fours and the tensors are 16-byte aligned
+  const bool vec = words % 4 == 0 && ((uintptr_t)input_dev & 15) == 0 && ((uintptr_t)output_dev & 15) == 0;
+  const int groups = vec ? words / 4 : words;
+  const uint64_t total = (uint64_t)batch * oh * ow * groups;
   const unsigned grid = grid_for_stream((total + 63) / 64, 4);
-  lce::bmaxpool_words<<<grid, 256, 0, (hipStream_t)stream>>>((const uint32_t*)input_dev, (uint32_t*)output_dev, batch, in_h, in_w,
-                                                              words, oh, ow, fh, fw, sh, sw, ph, pw, total, lce::make_fastdiv((uint32_t)words), lce::make_fastdiv((uint32_t)ow), lce::make_fastdiv((uint32_t)oh));
+  auto kernel = vec ? lce::bmaxpool_words<4> : lce::bmaxpool_words<1>;
+  kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint32_t*)input_dev, (uint32_t*)output_dev, batch, in_h, in_w,
+                                                  groups, oh, ow, fh, fw, sh, sw, ph, pw, total, lce::make_fastdiv((uint32_t)groups),
+                                                  lce::make_fastdiv((uint32_t)ow), lce::make_fastdiv((uint32_t)oh));
   LCE_HIP_TRY(hipGetLastError());
   return LCE_HIP_OK;
 }

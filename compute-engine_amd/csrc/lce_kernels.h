@@ -474,14 +474,19 @@ unpack_flat(const uint32_t* __restrict__ in, u32x4* __restrict__ out, uint64_t c
 
 // ---------------------------------------------------------------------------------
 // LceBMaxPool2d: bitwise AND over the (clipped) window (core/bmaxpool.h:24-88).
-// One thread per output word.
+// One thread per VEC consecutive output words (VEC = 4: 16-byte loads and stores, 8 lanes cover a
+// 128-byte line of a 1024-channel pixel... or four 256-channel pixels' worth; VEC = 1: any word count).
+// Windows that do not overlap (filter <= stride) read every input word exactly once: streaming loads.
 // ---------------------------------------------------------------------------------
+template <int VEC>
 LCE_KERNEL void __launch_bounds__(256)
 bmaxpool_words(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int B, int H, int W,
                int C, int OH, int OW, int FH, int FW, int SH, int SW, int PH, int PW,
                uint64_t total, FastDiv div_c, FastDiv div_ow, FastDiv div_oh) {
+  // C, total, div_c count VEC-word groups; the tensors are addressed in words
   const uint64_t stride = (uint64_t)grid_dim_x() * (uint64_t)block_dim_x();
   const bool small = total < (1ull << 31);   // the multiply-shift division is exact below 2^31
+  const bool once = FH <= SH && FW <= SW;
   for (uint64_t e = (uint64_t)block_idx_x() * (uint64_t)block_dim_x() + (uint64_t)thread_idx_x(); e < total; e += stride) {
     int c, ox, oy, b;
     if (small) {
@@ -501,10 +506,21 @@ bmaxpool_words(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int 
     const int x0 = ox * SW - PW, y0 = oy * SH - PH;
     const int xs = x0 < 0 ? 0 : x0, ys = y0 < 0 ? 0 : y0;
     const int xe = x0 + FW < W ? x0 + FW : W, ye = y0 + FH < H ? y0 + FH : H;
-    uint32_t m = 0xffffffffu;
-    for (int y = ys; y < ye; ++y)
-      for (int x = xs; x < xe; ++x) m &= in[(((size_t)b * H + y) * W + x) * (size_t)C + c];
-    out[e] = m;
+    if constexpr (VEC == 4) {
+      u32x4 m = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      for (int y = ys; y < ye; ++y)
+        for (int x = xs; x < xe; ++x) {
+          const u32x4* src = (const u32x4*)in + (((size_t)b * H + y) * W + x) * (size_t)C + c;
+          const u32x4 v = once ? load_streaming(src) : *src;
+          m[0] &= v[0]; m[1] &= v[1]; m[2] &= v[2]; m[3] &= v[3];
+        }
+      store_streaming((u32x4*)out + e, m);
+    } else {
+      uint32_t m = 0xffffffffu;
+      for (int y = ys; y < ye; ++y)
+        for (int x = xs; x < xe; ++x) m &= in[(((size_t)b * H + y) * W + x) * (size_t)C + c];
+      out[e] = m;
+    }
   }
   (void)B;
 }

@@ -243,9 +243,16 @@ int hostsim_bmaxpool(const uint32_t* in, int b, int h, int w, int c, int fh, int
   const int oh = padding == LCE_HIP_PADDING_SAME ? (h + sh - 1) / sh : (h + sh - fh) / sh;
   const int ow = padding == LCE_HIP_PADDING_SAME ? (w + sw - 1) / sw : (w + sw - fw) / sw;
   const int ph = std::max(0, (oh - 1) * sh + fh - h) / 2, pw = std::max(0, (ow - 1) * sw + fw - w) / 2;
-  const uint64_t total = (uint64_t)b * oh * ow * c;
-  launch_sequential(2, 1, 256, [&] { bmaxpool_words(in, out, b, h, w, c, oh, ow, fh, fw, sh, sw, ph, pw, total, make_fastdiv((uint32_t)c), make_fastdiv((uint32_t)ow),
-                   make_fastdiv((uint32_t)oh)); });
+  // as lce_hip_bmaxpool: four words per thread when a pixel's words come in fours (np arrays are 16-byte aligned)
+  const bool vec = c % 4 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
+  const int groups = vec ? c / 4 : c;
+  const uint64_t total = (uint64_t)b * oh * ow * groups;
+  launch_sequential(2, 1, 256, [&] {
+    if (vec) bmaxpool_words<4>(in, out, b, h, w, groups, oh, ow, fh, fw, sh, sw, ph, pw, total, make_fastdiv((uint32_t)groups),
+                               make_fastdiv((uint32_t)ow), make_fastdiv((uint32_t)oh));
+    else bmaxpool_words<1>(in, out, b, h, w, groups, oh, ow, fh, fw, sh, sw, ph, pw, total, make_fastdiv((uint32_t)groups),
+                           make_fastdiv((uint32_t)ow), make_fastdiv((uint32_t)oh));
+  });
   return 0;
 }
 

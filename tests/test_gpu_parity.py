@@ -522,8 +522,15 @@ def test_birealnet_style_int8_stack():
 @pytest.mark.parametrize("f,s,pad", [((2, 2), (2, 2), O.PADDING_SAME), ((3, 3), (2, 2), O.PADDING_SAME),
                                      ((3, 2), (1, 2), O.PADDING_VALID), ((2, 3), (3, 1), O.PADDING_SAME)])
 def test_bmaxpool(f, s, pad):
-    x = synth.random_words(synth.rng(99), (4, 19, 17, 3))
-    got = amd.bmaxpool(torch.from_numpy(x).to(DEV), f[0], f[1], s[0], s[1], pad).cpu().numpy()
+    for words in (3, 8, 4):   # one word per thread, and the 16-byte path (words % 4 == 0)
+        x = synth.random_words(synth.rng(99 + words), (4, 19, 17, words))
+        got = amd.bmaxpool(torch.from_numpy(x).to(DEV), f[0], f[1], s[0], s[1], pad).cpu().numpy()
+        assert np.array_equal(got, O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
+    # an unaligned view (the tensor starts 4 bytes into an allocation) takes the one-word path
+    x = synth.random_words(synth.rng(98), (2, 6, 6, 4))
+    flat = torch.empty(x.size + 1, dtype=torch.int32, device=DEV)
+    flat[1:] = torch.from_numpy(x).to(DEV).flatten()
+    got = amd.bmaxpool(flat[1:].view(2, 6, 6, 4), f[0], f[1], s[0], s[1], pad).cpu().numpy()
     assert np.array_equal(got, O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
 
 

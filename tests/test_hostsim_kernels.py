@@ -171,8 +171,9 @@ def test_quantize_dequantize_round_trip(cols):
                                      ((3, 2), (1, 2), O.PADDING_VALID), ((2, 3), (3, 1), O.PADDING_SAME)])
 def test_bmaxpool(f, s, pad):
     g = synth.rng(99)
-    x = synth.random_words(g, (2, 9, 7, 3))
-    assert np.array_equal(H.bmaxpool(x, f[0], f[1], s[0], s[1], pad), O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
+    for words in (3, 8):      # one word per thread, and the 16-byte path (words % 4 == 0)
+        x = synth.random_words(g, (2, 9, 7, words))
+        assert np.array_equal(H.bmaxpool(x, f[0], f[1], s[0], s[1], pad), O.bmaxpool(x, f[0], f[1], s[0], s[1], pad))
 
 
 def test_round_sat_i8_every_float():
