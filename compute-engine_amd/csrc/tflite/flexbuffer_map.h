@@ -34,26 +34,37 @@ class Map {
   }
 
  private:
+  // All positions are OFFSETS into [0, len_): every value read from the file is checked against what is
+  // left of the buffer before it is used, with subtractions that cannot wrap -- no pointer is ever formed
+  // outside the buffer (the options blob of a .tflite file is attacker-controlled input).
   const uint8_t* buf_ = nullptr;
   size_t len_ = 0;
   bool valid_ = false;
-  const uint8_t* values_ = nullptr;
-  const uint8_t* keys_ = nullptr;
+  size_t values_ = 0, keys_ = 0;   // offsets of the value vector / key vector
   size_t size_ = 0, bw_ = 1, keys_bw_ = 1;
 
-  bool in(const uint8_t* p, size_t n) const { return p >= buf_ && p + n <= buf_ + len_; }
-  static uint64_t read_u(const uint8_t* p, size_t w) {
+  bool span(size_t pos, size_t n) const { return pos <= len_ && n <= len_ - pos; }
+  static bool width_ok(size_t w) { return w == 1 || w == 2 || w == 4 || w == 8; }
+  uint64_t read_u(size_t pos, size_t w) const {
     uint64_t v = 0;
-    memcpy(&v, p, w);  // little-endian hosts only, like the reference (FLATBUFFERS_LITTLEENDIAN)
+    memcpy(&v, buf_ + pos, w);  // little-endian hosts only, like the reference (FLATBUFFERS_LITTLEENDIAN)
     return v;
   }
-  static int64_t read_i(const uint8_t* p, size_t w) {
+  int64_t read_i(size_t pos, size_t w) const {
     switch (w) {
-      case 1: { int8_t v; memcpy(&v, p, 1); return v; }
-      case 2: { int16_t v; memcpy(&v, p, 2); return v; }
-      case 4: { int32_t v; memcpy(&v, p, 4); return v; }
-      default: { int64_t v; memcpy(&v, p, 8); return v; }
+      case 1: { int8_t v; memcpy(&v, buf_ + pos, 1); return v; }
+      case 2: { int16_t v; memcpy(&v, buf_ + pos, 2); return v; }
+      case 4: { int32_t v; memcpy(&v, buf_ + pos, 4); return v; }
+      default: { int64_t v; memcpy(&v, buf_ + pos, 8); return v; }
     }
+  }
+  // `pos` holds a backwards offset of width w: the position it points at, or false
+  bool deref(size_t pos, size_t w, size_t* target) const {
+    if (!span(pos, w)) return false;
+    const uint64_t d = read_u(pos, w);
+    if (d > (uint64_t)pos) return false;
+    *target = pos - (size_t)d;
+    return true;
   }
 
   void parse(const uint8_t* buf, size_t len) {
@@ -62,50 +73,45 @@ class Map {
     if (!buf || len < 3) return;
     const size_t root_w = buf[len - 1];
     const uint8_t packed = buf[len - 2];
-    if ((packed >> 2) != kMap || (root_w != 1 && root_w != 2 && root_w != 4 && root_w != 8)) return;
+    if ((packed >> 2) != kMap || !width_ok(root_w)) return;
     bw_ = (size_t)1 << (packed & 3);
     if (len < 2 + root_w) return;
-    const uint8_t* root = buf + len - 2 - root_w;
-    const uint64_t off = read_u(root, root_w);
-    if (off > (uint64_t)(root - buf)) return;
-    values_ = root - off;
-    if (!in(values_ - 3 * bw_, 3 * bw_)) return;
-    size_ = (size_t)read_u(values_ - bw_, bw_);
+    if (!deref(len - 2 - root_w, root_w, &values_)) return;
+    // the three words in front of the values: offset to the keys, key width, element count
+    if (values_ < 3 * bw_) return;
+    const uint64_t count = read_u(values_ - bw_, bw_);
     keys_bw_ = (size_t)read_u(values_ - 2 * bw_, bw_);
-    const uint8_t* koff = values_ - 3 * bw_;
-    const uint64_t kd = read_u(koff, bw_);
-    if (kd > (uint64_t)(koff - buf)) return;
-    keys_ = koff - kd;
-    if (keys_bw_ != 1 && keys_bw_ != 2 && keys_bw_ != 4 && keys_bw_ != 8) return;
-    if (!in(values_, size_ * bw_ + size_) || !in(keys_, size_ * keys_bw_)) return;
+    if (!width_ok(keys_bw_) || !deref(values_ - 3 * bw_, bw_, &keys_)) return;
+    // count * (bw + 1) bytes of values + type bytes, count * keys_bw of key offsets: divide, never multiply first
+    if (count > (uint64_t)(len_ - values_) / (bw_ + 1) || count > (uint64_t)(len_ - keys_) / keys_bw_) return;
+    size_ = (size_t)count;
     valid_ = true;
   }
 
   bool find(const char* key, int64_t* out) const {
     if (!valid_) return false;
     for (size_t i = 0; i < size_; ++i) {
-      const uint8_t* kp = keys_ + i * keys_bw_;
-      const uint64_t d = read_u(kp, keys_bw_);
-      if (d > (uint64_t)(kp - buf_)) continue;
-      const char* ks = (const char*)(kp - d);
-      const size_t maxn = (size_t)(buf_ + len_ - (const uint8_t*)ks);
-      if (strnlen(ks, maxn) == maxn || strcmp(ks, key) != 0) continue;
-      const uint8_t vt = values_[size_ * bw_ + i];
+      size_t ks;
+      if (!deref(keys_ + i * keys_bw_, keys_bw_, &ks)) continue;
+      const size_t maxn = len_ - ks;
+      const char* kstr = (const char*)(buf_ + ks);
+      if (strnlen(kstr, maxn) == maxn || strcmp(kstr, key) != 0) continue;
+      const uint8_t vt = buf_[values_ + size_ * bw_ + i];
       const uint8_t type = vt >> 2;
       const size_t vw = (size_t)1 << (vt & 3);
-      const uint8_t* vp = values_ + i * bw_;
+      const size_t vp = values_ + i * bw_;
       switch (type) {
         case kInt: *out = read_i(vp, bw_); return true;      // inline scalars use the parent width
         case kUInt: case kBool: *out = (int64_t)read_u(vp, bw_); return true;
         case kIndirectInt: case kIndirectUInt: {
-          const uint64_t dd = read_u(vp, bw_);
-          if (dd > (uint64_t)(vp - buf_)) return false;
-          *out = type == kIndirectInt ? read_i(vp - dd, vw) : (int64_t)read_u(vp - dd, vw);
+          size_t tp;
+          if (!deref(vp, bw_, &tp) || !span(tp, vw)) return false;
+          *out = type == kIndirectInt ? read_i(tp, vw) : (int64_t)read_u(tp, vw);
           return true;
         }
         case kFloat: {
-          if (bw_ == 4) { float f; memcpy(&f, vp, 4); *out = (int64_t)f; return true; }
-          if (bw_ == 8) { double f; memcpy(&f, vp, 8); *out = (int64_t)f; return true; }
+          if (bw_ == 4) { float f; memcpy(&f, buf_ + vp, 4); *out = (int64_t)f; return true; }
+          if (bw_ == 8) { double f; memcpy(&f, buf_ + vp, 8); *out = (int64_t)f; return true; }
           return false;
         }
         default: return false;  // FBT_NULL and everything else read as "null"

@@ -130,6 +130,7 @@ lce_hip_status lce_tflite_model_bconv2d_plan(const lce_tflite_model* model, int3
   d.channels_out = filter.shape[0];
   d.filter_height = filter.shape[1];
   d.filter_width = filter.shape[2];
+  if (d.channels_in <= 0) return Fail(LCE_HIP_ERR_INVALID, "LceBconv2d: channels_in must be positive");
   // groups from the filter's packed depth (bconv2d.cc:169-186)
   const int32_t cw = (d.channels_in + 31) / 32;
   if (in.shape[3] != cw) return Fail(LCE_HIP_ERR_INVALID, "LceBconv2d: input depth does not match channels_in");

@@ -168,6 +168,7 @@ TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bconv2d.cc:
                  "Supported output types are int8, int32, and float32.");
 
   const int32_t channels_out = SizeOfDimension(filter, 0);
+  LCE_ENSURE(context, op->channels_in > 0);   // (the divisions below must not see a zero group count)
   // groups are inferred from the filter's packed depth (:169-186)
   if (SizeOfDimension(filter, 3) == BitpackedSize(op->channels_in)) {
     op->groups = 1;
@@ -177,6 +178,7 @@ TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bconv2d.cc:
     LCE_ENSURE(context, SizeOfDimension(filter, 3) > 0);
     LCE_ENSURE_EQ(context, BitpackedSize(op->channels_in) % SizeOfDimension(filter, 3), 0);
     const int32_t groups = BitpackedSize(op->channels_in) / SizeOfDimension(filter, 3);
+    LCE_ENSURE(context, groups >= 1);
     const int32_t group_size = op->channels_in / groups;
     LCE_ENSURE_EQ(context, group_size % 32, 0);
     LCE_ENSURE_EQ(context, channels_out % groups, 0);

@@ -20,11 +20,23 @@ TfLiteRegistration* Register_BCONV_2D_OPT_BGEMM();           // declared by the 
 TfLiteRegistration* Register_BCONV_2D_OPT_INDIRECT_BGEMM();
 TfLiteRegistration* Register_BMAXPOOL_2D();
 
-// lce_ops_register.h:25-53.  `Resolver` is ::tflite::MutableOpResolver in a TFLite build;
-// any type with AddCustom(const char*, const TfLiteRegistration*) works.
+// lce_ops_register.h:25-53.  Inside a TFLite tree (-DLCE_USE_SYSTEM_TFLITE) this is the reference's exact
+// signature -- a plain function taking ::tflite::MutableOpResolver*, so explicit uses of its address or type
+// keep compiling; standalone (no TensorFlow headers in this image) the resolver type is a template
+// parameter: any type with AddCustom(const char*, const TfLiteRegistration*) works.
+#ifdef LCE_USE_SYSTEM_TFLITE
+}  // namespace tflite
+}  // namespace compute_engine
+#include "tensorflow/lite/mutable_op_resolver.h"
+namespace compute_engine {
+namespace tflite {
+inline void RegisterLCECustomOps(::tflite::MutableOpResolver* resolver, const bool use_reference_bconv = false,
+                                 const bool use_indirect_bgemm = false) {
+#else
 template <typename Resolver>
 inline void RegisterLCECustomOps(Resolver* resolver, const bool use_reference_bconv = false,
                                  const bool use_indirect_bgemm = false) {
+#endif
   if (use_reference_bconv && use_indirect_bgemm) {
     std::fprintf(stderr,
                  "WARNING: 'use_reference_bconv' and `use_indirect_bgemm` are both set to true. "

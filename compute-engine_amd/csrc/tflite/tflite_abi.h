@@ -143,7 +143,7 @@ typedef struct TfLiteRegistration {
   int version;
   void* registration_external;
   void* async_kernel;
-  int32_t inplace_operator;
+  uint64_t inplace_operator;
 } TfLiteRegistration;
 
 // tensorflow/lite/core/c/builtin_op_data.h
@@ -160,3 +160,64 @@ typedef enum {
 }
 #endif
 #endif  // LCE_USE_SYSTEM_TFLITE
+
+// ---------------------------------------------------------------------------------------------
+// Layout table (LP64) of the TFLite v2.16.1 structures the LCE ops read or write
+// (tensorflow/lite/core/c/common.h at the commit pinned by the reference's WORKSPACE:12-24).  The op glue
+// is handed pointers to these by the interpreter, so field ORDER is the ABI: the asserts hold for the
+// mirror above and -- with -DLCE_USE_SYSTEM_TFLITE -- are checked against TensorFlow's own header, so a
+// TensorFlow bump that moves a field fails the build instead of corrupting tensors at run time.
+// ---------------------------------------------------------------------------------------------
+#ifdef __cplusplus
+#define LCE_ABI_AT(T, field, off) static_assert(offsetof(T, field) == (off), "TFLite ABI drift: " #T "::" #field)
+static_assert(sizeof(void*) == 8 && sizeof(size_t) == 8, "LP64 only");
+LCE_ABI_AT(TfLiteTensor, type, 0);
+LCE_ABI_AT(TfLiteTensor, data, 8);
+LCE_ABI_AT(TfLiteTensor, dims, 16);
+LCE_ABI_AT(TfLiteTensor, params, 24);
+LCE_ABI_AT(TfLiteTensor, allocation_type, 32);
+LCE_ABI_AT(TfLiteTensor, bytes, 40);
+LCE_ABI_AT(TfLiteTensor, allocation, 48);
+LCE_ABI_AT(TfLiteTensor, name, 56);
+LCE_ABI_AT(TfLiteTensor, delegate, 64);
+LCE_ABI_AT(TfLiteTensor, buffer_handle, 72);
+LCE_ABI_AT(TfLiteTensor, data_is_stale, 76);
+LCE_ABI_AT(TfLiteTensor, is_variable, 77);
+LCE_ABI_AT(TfLiteTensor, quantization, 80);
+LCE_ABI_AT(TfLiteTensor, sparsity, 96);
+LCE_ABI_AT(TfLiteTensor, dims_signature, 104);
+static_assert(sizeof(TfLiteTensor) == 112, "TFLite ABI drift: sizeof(TfLiteTensor) (context->tensors is indexed by it)");
+static_assert(sizeof(TfLiteQuantizationParams) == 8 && sizeof(TfLiteQuantization) == 16 && sizeof(TfLitePtrUnion) == 8,
+              "TFLite ABI drift: tensor member sizes");
+LCE_ABI_AT(TfLiteAffineQuantization, scale, 0);
+LCE_ABI_AT(TfLiteAffineQuantization, zero_point, 8);
+LCE_ABI_AT(TfLiteAffineQuantization, quantized_dimension, 16);
+LCE_ABI_AT(TfLiteIntArray, data, 4);
+LCE_ABI_AT(TfLiteNode, inputs, 0);
+LCE_ABI_AT(TfLiteNode, outputs, 8);
+LCE_ABI_AT(TfLiteNode, intermediates, 16);
+LCE_ABI_AT(TfLiteNode, temporaries, 24);
+LCE_ABI_AT(TfLiteNode, user_data, 32);
+LCE_ABI_AT(TfLiteNode, builtin_data, 40);
+LCE_ABI_AT(TfLiteNode, custom_initial_data, 48);
+LCE_ABI_AT(TfLiteNode, custom_initial_data_size, 56);
+LCE_ABI_AT(TfLiteContext, tensors_size, 0);
+LCE_ABI_AT(TfLiteContext, tensors, 16);
+LCE_ABI_AT(TfLiteContext, ResizeTensor, 32);
+LCE_ABI_AT(TfLiteContext, ReportError, 40);
+LCE_ABI_AT(TfLiteContext, AddTensors, 48);
+LCE_ABI_AT(TfLiteContext, recommended_num_threads, 72);
+LCE_ABI_AT(TfLiteRegistration, init, 0);
+LCE_ABI_AT(TfLiteRegistration, free, 8);
+LCE_ABI_AT(TfLiteRegistration, prepare, 16);
+LCE_ABI_AT(TfLiteRegistration, invoke, 24);
+LCE_ABI_AT(TfLiteRegistration, profiling_string, 32);
+LCE_ABI_AT(TfLiteRegistration, builtin_code, 40);
+LCE_ABI_AT(TfLiteRegistration, custom_name, 48);
+LCE_ABI_AT(TfLiteRegistration, version, 56);
+static_assert(kTfLiteFloat32 == 1 && kTfLiteInt32 == 2 && kTfLiteBool == 6 && kTfLiteInt8 == 9, "TFLite ABI drift: TfLiteType");
+static_assert(kTfLiteMmapRo == 1 && kTfLiteArenaRw == 2 && kTfLiteDynamic == 4, "TFLite ABI drift: TfLiteAllocationType");
+static_assert(kTfLitePaddingSame == 1 && kTfLitePaddingValid == 2 && kTfLiteActRelu == 1 && kTfLiteActReluN1To1 == 2 &&
+                  kTfLiteActRelu6 == 3, "TFLite ABI drift: builtin_op_data enums");
+#undef LCE_ABI_AT
+#endif

@@ -41,6 +41,28 @@ def test_flexbuffer_wide_values_and_garbage():
             T.flex_lookup(junk, "channels_in")
 
 
+def test_flexbuffer_reader_survives_every_single_byte_corruption():
+    """The options blob comes out of a file: every byte of a valid map replaced by 0x00 / 0x7f / 0xff (sizes
+    and offsets that would wrap a pointer, widths of 8, counts of 2^32) must be refused or read as some
+    value -- never crash.  Copies are placed at the END of an exactly-sized heap buffer so that a read past
+    either end of the blob is a read out of the allocation (caught by the allocator's guard in debug runs;
+    here the test asserts the call returns)."""
+    for base in (flexbuf.bconv2d_options(64, 1, 1, 1, 1, 0, 1, 1), flexbuf.build_int_map({"channels_in": 70000, "x": -5})):
+        for pos in range(len(base)):
+            for v in (0x00, 0x7F, 0xFF, 0x08, 0x24):
+                blob = bytearray(base)
+                blob[pos] = v
+                try:
+                    T.flex_lookup(bytes(blob), "channels_in")
+                except ValueError:
+                    pass
+        for cut in range(len(base)):
+            try:
+                T.flex_lookup(bytes(base[:cut]), "channels_in")
+            except ValueError:
+                pass
+
+
 def _spec(case, sem):
     inp, flt, g, st, dil, pad, act = case
     padding, pv = PADS[pad]
