@@ -43,3 +43,21 @@ def test_reference_semantics_flag():
     data, _ = small_model(22)
     mr.Interpreter(data, batch_size=4, use_reference_bconv=True).predict(
         synth.rng(6).uniform(-1, 1, (4, 12, 12, 64)).astype(np.float32))
+
+
+def test_predict_accepts_the_reference_iterator_forms_and_pipelines_many_batches():
+    """interpreter_base.py:10-27: predict takes an array, a list of arrays, or an ITERATOR that yields one
+    sample at a time (an array without the sample axis, or a list of such for several inputs).  Seven batches
+    flow through the H2D | ops | D2H pipeline (two staging slots reused three times each) and come back in
+    order."""
+    data, p = small_model(23)
+    x = synth.rng(8).uniform(-1.5, 1.5, (100, 12, 12, 64)).astype(np.float32)
+    want_i8, want_deq = oracle_forward(x, p)
+    it = mr.Interpreter(data, batch_size=16)
+    for form in (iter(x), iter([s] for s in x), (s for s in x)):
+        got_i8, got_deq = it.predict(form)
+        assert np.array_equal(got_i8, want_i8) and np.array_equal(got_deq, want_deq)
+    with pytest.raises(ValueError):
+        it.predict("not samples")
+    with pytest.raises(ValueError):
+        it.predict(iter(()))
