@@ -165,8 +165,11 @@ LCE_DEVICE uint8_t* lds_base() {
 // at its own buffer offset; the wave's 64 x 16 bytes land CONTIGUOUSLY at lds_dst + 16*lane
 // (lds_dst is wave-uniform).  No VGPR round trip, no ds_write.  Completion is tracked by
 // vmcnt: wait_vmcnt<N>() below, then a barrier, before another wave reads the bytes.
-LCE_DEVICE void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, byte_off, 0, 0, 0);
+// lane_off: per-lane byte offset (VGPR); uniform_off: wave-uniform byte offset (SGPR, no VALU add); IMM: an
+// instruction-immediate byte offset (< 4096) that moves BOTH the source and the LDS destination.
+template <int IMM>
+LCE_DEVICE void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t lane_off, uint32_t uniform_off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, lane_off, uniform_off, IMM, 0);
 }
 // Barrier that does NOT drain the VM counter: LDS-DMA copies issued for later pipeline
 // stages stay in flight across it.  Pair with wait_vmcnt<N>() for the stage being consumed.

@@ -256,7 +256,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   }
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
-    const int q = (wave + i * NWAVES) % B_PIECES;
+    const int q = (NPB == 2 && B_PIECES == 2 * NWAVES) ? 2 * wave + i : (wave + i * NWAVES) % B_PIECES;
     const int half = q / (BN / 64), blk = q % (BN / 64);
     b_dst[i] = A_BYTES + half * (BN * 16) + blk * 1024;
     b_src[i] = (uint32_t)(half * G.Npad + n0 + blk * 64 + lane) * 16u;
@@ -280,17 +280,30 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   const uint32_t a_step_fx = (uint32_t)A.DW * 16u - (uint32_t)G.KCH * a_step_kc;
   const uint32_t a_step_fy = (uint32_t)(A.DH * G.Wp - A.KW * A.DW) * 16u;
   const uint32_t b_step = (uint32_t)G.Npad * 32u;
+  // B pieces of a wave: when every wave has exactly two (BN = 256 with four waves), they are NEIGHBOURS
+  // (pieces 2w and 2w+1: 1 KiB apart in the weights and in the stage), so the second copy is the first
+  // one's instruction with an immediate offset -- same address VGPR, same M0.  The K-step's offset rides
+  // in the instruction's scalar offset: no VALU.
+  constexpr bool PAIRED_B = NPB == 2 && B_PIECES == 2 * NWAVES;
   auto fill = [&](int stage) {
     uint8_t* base = lds + stage * STAGE;
-    // Every wave issues exactly NP pieces per fill (the counted vmcnt waits rely on it); when a
-    // block has fewer pieces than waves, a surplus slot re-copies an earlier piece (same bytes to
-    // the same address) -- skipping it would need a branch, and a branch would split the K-step's
-    // scheduling region.
 #ifndef LCE_ABL_NODMA   // timing ablation (results are wrong): the K loop without its LDS-DMA instructions
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) buf_load_to_lds16(rx, base + a_dst[i], a_src[i] + a_off);
+    for (int i = 0; i < NPA; ++i) buf_load_to_lds16<0>(rx, base + a_dst[i], a_src[i], a_off);
+    if constexpr (PAIRED_B) {
+      buf_load_to_lds16<0>(rw, base + b_dst[0], b_src[0], b_off);
+      buf_load_to_lds16<1024>(rw, base + b_dst[0], b_src[0], b_off);
+    } else {
+      // A 1-KiB copy occupies the CU's load path for ~25-30 cycles and blocks the wave that issued it meanwhile
+      // (tools/probes/dma_cost.hip): in the direct variant a block with fewer pieces than waves (256x128: four
+      // pieces, eight waves) does not issue the surplus -- there a wave copies either its one piece or nothing,
+      // so the counted waits stay exact (a wave that copied nothing has nothing to wait for).  In the workspace
+      // variant the surplus slots re-copy an earlier piece: a wave that dropped only its B slot would still
+      // wait as if it had issued NP.
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) buf_load_to_lds16(rw, base + b_dst[i], b_src[i] + b_off);
+      for (int i = 0; i < NPB; ++i)
+        if (!(DIRECT && NPB == 1) || wave < B_PIECES) buf_load_to_lds16<0>(rw, base + b_dst[i], b_src[i], b_off);
+    }
 #endif
     // cursor to the next K-step, branch-free (selects, not jumps: a branch here would split the
     // K-step's basic block and with it the scheduling region the MFMA interleave needs)

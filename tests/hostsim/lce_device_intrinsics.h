@@ -145,10 +145,13 @@ inline uint8_t* lds_base() { return g_ctx.lds; }
 // real bytes land only when the issuing wave executes the s_waitcnt vmcnt(N) that retires
 // the piece.  A missing or miscounted wait, or a refill of a stage still being read, turns
 // into a wrong result instead of a lucky pass.
-inline void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t byte_off) {
-  const u32x4 v = buf_load_impl<u32x4>(r, byte_off);
+template <int IMM>
+inline void buf_load_to_lds16(rsrc_t r, uint8_t* lds_dst, uint32_t lane_off, uint32_t uniform_off) {
+  // the range check covers lane_off + IMM (the scalar offset is outside it on the hardware; the kernels never
+  // rely on the check for these copies)
+  const u32x4 v = buf_load_impl<u32x4>(r, lane_off + uniform_off + IMM);
   ThreadCtx::PendingDma p;
-  p.dst = lds_dst + 16 * (g_ctx.tid_x & 63);
+  p.dst = lds_dst + IMM + 16 * (g_ctx.tid_x & 63);
   memcpy(p.data, &v, 16);
   memset(p.dst, 0xEE, 16);
   g_ctx.dma.push_back(p);
