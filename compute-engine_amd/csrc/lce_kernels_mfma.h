@@ -193,6 +193,15 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #ifdef LCE_PHASES
   const uint32_t ph_lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
 #endif
+#ifdef LCE_STAGGER   // experiment: spread the first residents' start over one block period (units of 512 cycles)
+  {
+    const uint32_t lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
+    if (lin < 512u) {
+      const uint32_t d = uniform(((lin * 2654435761u) >> 16) % (uint32_t)(LCE_STAGGER));
+      for (uint32_t i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#endif
   LCE_PH(0);
   LCE_PH(7);
   uint8_t* const lds0 = lds_base();

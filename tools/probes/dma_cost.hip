@@ -70,6 +70,14 @@ __global__ __launch_bounds__(256, 1) void dma_cost(const uint8_t* wts, float* ou
           else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(0), 16, voff, soff, 3072, 0);
         }
       }
+      // FORM 8: staggered by wave -- wave w issues its copies after MFMAs 2w and 2w+1, so the four waves' copies
+      // never meet in the address path; FORM 9: only wave 0 copies (NDMA per step), nobody to collide with
+      if (FORM == 8 && NDMA == 2 && (i >> 1) == wave) {
+        if ((i & 1) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(0), 16, voff, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(0), 16, voff, soff, 1024, 0);
+      }
+      if (FORM == 8 && NDMA == 1 && i == 2 * wave) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(0), 16, voff, soff, 0, 0);
+      if (FORM == 9 && wave == 0 && i < NDMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(i), 16, voff, soff + i * 1024, 0, 0);
       if (FORM == 3 && wave == 0 && i < NDMA) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(4 * i), 16, voff, soff + i * 4096, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(4 * i), 16, voff, soff + i * 4096, 1024, 0);
@@ -149,6 +157,70 @@ __global__ __launch_bounds__(256, 1) void reg_staged(const uint8_t* wts, float* 
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_cyc[blockIdx.x] = t1 - t0;
 }
 
+// A fifth wave as the block's loader, running a 3-deep ring ahead of the four MFMA waves: per step it issues all
+// NCOPY copies, waits until only the last two steps' copies are in flight, and meets the others at the barrier.
+template <int NCOPY>
+__global__ __launch_bounds__(320, 1) void loader_wave(const uint8_t* wts, float* out, int steps) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wts), 0, 512 * 1024, 0x00020000);
+  v8i a = {0x22222222, 0x2A2A2A2A, (int)0xA2A2A2A2, 0x22222222, 0, 0, 0, 0};
+  v8i b = {0x2222AAAA, 0x2A2A2A2A, 0x22222222, (int)0xAAAA2222, 0, 0, 0, 0};
+  a[0] ^= (lane * 0x01010101) & 0x88888888;
+  v16f c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[i][j] = 0.f;
+  const unsigned voff = lane * 16;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  if (wave == 4) {
+    for (int ks = 0; ks < steps; ++ks) {
+      const unsigned soff = (unsigned)((ks & 31) * 8192);
+#pragma unroll
+      for (int k = 0; k < NCOPY; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(lds + (ks % 3) * 8192 + k * 1024), 16, voff, soff + k * 1024, 0, 0);
+      __builtin_amdgcn_s_waitcnt((((NCOPY * 2) >> 4) & 3) << 14 | (0xF << 8) | (0x7 << 4) | ((NCOPY * 2) & 0xF));
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    for (int ks = 0; ks < steps; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        c[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c[i], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += c[i][j];
+  if (sum == 12345.678f) out[threadIdx.x] = sum + lds[lane];
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int NCOPY>
+static void run_loader(const char* name, const uint8_t* w, float* out) {
+  const int steps = 2000;
+  void (*fn)(const uint8_t*, float*, int) = loader_wave<NCOPY>;
+  (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  void* c;
+  (void)hipGetSymbolAddress(&c, HIP_SYMBOL(g_cyc));
+  for (int rep = 0; rep < 2; ++rep) {
+    loader_wave<NCOPY><<<256, 320, 150 * 1024>>>(w, out, steps);
+    (void)hipDeviceSynchronize();
+  }
+  std::vector<unsigned long long> cyc(256);
+  (void)hipMemcpy(cyc.data(), c, 256 * 8, hipMemcpyDeviceToHost);
+  double s = 0;
+  for (auto v : cyc) s += (double)v;
+  printf("{\"probe\": \"%s\", \"copies_per_block_step\": %d, \"cycles_per_step\": %.1f}\n", name, NCOPY, s / 256 / steps);
+  fflush(stdout);
+}
+
 template <int NDMA>
 static void run_reg(const char* name, const uint8_t* w, float* out) {
   const int steps = 1998;
@@ -211,6 +283,15 @@ int main() {
   run<2, 3, 2>("wave 0 issues all 8 copies (and its MFMAs), barrier per step", w, out);
   run<2, 4, 2>("wave 0 is a pure loader (8 copies, no MFMAs), waves 1-3 compute, barrier per step", w, out);
   run<1, 4, 2>("pure loader wave, 4 copies per step", w, out);
+  run<2, 8, 2>("staggered: wave w issues its 2 copies after MFMAs 2w, 2w+1, barrier per step", w, out);
+  run<1, 8, 2>("staggered: wave w issues its 1 copy after MFMA 2w, barrier per step", w, out);
+  run<2, 8, 1>("staggered: 2 copies per wave, counted wait, no barrier", w, out);
+  run<1, 9, 2>("only wave 0 copies, 1 per step (no one to collide with), barrier per step", w, out);
+  run<2, 9, 2>("only wave 0 copies, 2 per step, barrier per step", w, out);
+  run<4, 9, 2>("only wave 0 copies, 4 per step, barrier per step", w, out);
+  run_loader<4>("fifth wave = loader, 3-deep ring, barrier per step", w, out);
+  run_loader<8>("fifth wave = loader, 3-deep ring, barrier per step", w, out);
+  run_loader<12>("fifth wave = loader, 3-deep ring, barrier per step", w, out);
   run_reg<1>("register-staged: buffer_load_dwordx4 -> VGPR, ds_write_b128 two steps later", w, out);
   run_reg<2>("register-staged: buffer_load_dwordx4 -> VGPR, ds_write_b128 two steps later", w, out);
   run_reg<4>("register-staged: buffer_load_dwordx4 -> VGPR, ds_write_b128 two steps later", w, out);

@@ -167,6 +167,17 @@ int main() {
     snprintf(nm, sizeof nm, "tile4_lds%dk", lds / 1024);
     TIME(nm, 0.0, (fill_tile<2><<<tiles, 256, lds>>>(out, tiles)));
   }
+  // how fast can ONE CU store when the rest of the chip leaves HBM alone?  G persistent blocks (150 KiB of LDS:
+  // one per CU), 24 tiles each, tile16 pattern
+  for (int g : {8, 32, 64, 128, 256}) {
+    const int t = g * 24;
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) fill_tile<0><<<g, 256, 150 * 1024>>>(out, t);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    const double sec = time_ms(e0, e1) / reps * 1e-3;
+    printf("{\"probe\": \"tile16_on_%d_CUs\", \"ms\": %.4f, \"GBps_per_CU\": %.1f, \"store_TBps\": %.3f}\n", g, sec * 1e3,
+           24.0 * kTileFloats * 4 / sec / 1e9, (double)t * kTileFloats * 4 / sec / 1e12);
+  }
   // one wave per SIMD (1 block per CU, 150 KiB of LDS) vs two: can a lone wave keep the matrix pipe busy?
   {
     hipFuncSetAttribute((const void*)mfma_store<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
