@@ -193,15 +193,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #ifdef LCE_PHASES
   const uint32_t ph_lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
 #endif
-#ifdef LCE_STAGGER   // experiment: spread the first residents' start over one block period (units of 512 cycles)
-  {
-    const uint32_t lin = (uint32_t)block_idx_y() * (uint32_t)grid_dim_x() + (uint32_t)block_idx_x();
-    if (lin < 512u) {
-      const uint32_t d = uniform(((lin * 2654435761u) >> 16) % (uint32_t)(LCE_STAGGER));
-      for (uint32_t i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-#endif
   LCE_PH(0);
   LCE_PH(7);
   uint8_t* const lds0 = lds_base();
@@ -678,11 +669,16 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         for (int k = 0; k < KB; ++k) y[k] = *(const f32x4*)(scratch + (lane / LPR + (k0 + k) * RPI) * RW + g * 4);
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
+#ifdef LCE_ABL_NOSTORE   // timing ablation (results are wrong): the float epilogue without its global stores
+          if (y[k][0] == 1234.5678f)
+#endif
           buf_store_streaming(ro, lane_off + (uint32_t)((wm * WM + i) * 32 + (k0 + k) * RPI) * row_bytes, y[k]);
           // pace the burst: 128 KiB per block pushed out back to back fills the CU's memory pipeline and
           // the co-resident block's weight DMAs queue behind it (its K loop 18.7k -> 16.4k cycles with the
           // pause, L0 float -2.5 %, tools/phases.py); the sleeping wave also leaves its issue slots to it
+#ifndef LCE_ABL_NOSLEEP
           yield_issue_slots<2>();
+#endif
         }
       }
       wave_lds_fence();
