@@ -19,6 +19,7 @@ namespace lce_dev {
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;  // CDNA wavefront width
 
@@ -97,6 +98,30 @@ LCE_DEVICE float mul_then_add(float a, float b, float c) {
   const float p = a * b;
   return p + c;
 }
+
+// Two of them at once: v_pk_mul_f32 + v_pk_add_f32 (each element rounded twice, exactly as above).
+#ifdef LCE_NO_PK_F32   // experiment: the same pairs with scalar instructions
+LCE_DEVICE f32x2 mul_then_add2(f32x2 a, float b, float c) {
+  f32x2 r = {mul_then_add(a[0], b, c), mul_then_add(a[1], b, c)};
+  asm volatile("" : "+v"(r));
+  return r;
+}
+LCE_DEVICE f32x2 add2(f32x2 a, f32x2 b) {
+  float x = a[0] + b[0], y = a[1] + b[1];
+  asm volatile("" : "+v"(x), "+v"(y));
+  return f32x2{x, y};
+}
+#else
+LCE_DEVICE f32x2 mul_then_add2(f32x2 a, float b, float c) {
+#pragma clang fp contract(off)
+  const f32x2 bb = {b, b}, cc = {c, c};
+  const f32x2 p = a * bb;
+  return p + cc;
+}
+LCE_DEVICE f32x2 add2(f32x2 a, f32x2 b) { return a + b; }   // v_pk_add_f32
+#endif
+// A use of `v` that generates nothing: keeps its registers allocated (and unmodified) up to this point.
+LCE_DEVICE void keep_alive(const u32x4& v) { asm volatile("" ::"v"(v)); }
 
 // acc_i += popcount(a_i ^ w) for TM independent activations against ONE weight word.
 // Hand-written so that (1) the weight word stays in an SGPR (VOP2 src0), (2) the
@@ -234,8 +259,11 @@ LCE_DEVICE void store_streaming(u32x4* p, u32x4 v) { __builtin_nontemporal_store
 LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, 0, LCE_STORE_AUX);
 }
+#ifndef LCE_STORE8_AUX
+#define LCE_STORE8_AUX 0
+#endif
 LCE_DEVICE void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, 0, LCE_STORE8_AUX);
 }
 // ... and the matching load for inputs that are read exactly once
 LCE_DEVICE f32x4 load_streaming(const f32x4* p) { return __builtin_nontemporal_load(p); }

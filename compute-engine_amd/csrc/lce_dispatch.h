@@ -4,6 +4,7 @@
 #include "../../include/lce_hip.h"
 #include "lce_kernels.h"
 #include "lce_kernels_mfma.h"
+#include "lce_kernels_pointwise.h"
 
 namespace lce {
 
@@ -82,6 +83,34 @@ mfma_fn find_mfma_v(int dst, int bm, int bn, bool zero_pad_correction) {
 inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false) {
   return direct ? find_mfma_v<true>(dst, bm, bn, zero_pad_correction)
                 : find_mfma_v<false>(dst, bm, bn, zero_pad_correction);
+}
+
+typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, const float*, const float*, const float*, void*);
+
+template <int DST, int NC>
+pointwise_fn pointwise_by_nj(int nj) {
+  switch (nj) {
+    case 4: return bconv2d_pointwise<DST, NC, 4>;
+    case 2: return bconv2d_pointwise<DST, NC, 2>;
+    case 1: return bconv2d_pointwise<DST, NC, 1>;
+    default: return nullptr;
+  }
+}
+template <int DST>
+pointwise_fn pointwise_by_nc(int nc, int nj) {
+  switch (nc) {
+    case 4: return pointwise_by_nj<DST, 4>(nj);
+    case 2: return pointwise_by_nj<DST, 2>(nj);
+    case 1: return pointwise_by_nj<DST, 1>(nj);
+    default: return nullptr;
+  }
+}
+inline pointwise_fn find_pointwise(int dst, int nc, int nj) {
+  switch (dst) {
+    case LCE_HIP_F32: return pointwise_by_nc<kDstFloat>(nc, nj);
+    case LCE_HIP_I8: return pointwise_by_nc<kDstInt8>(nc, nj);
+    default: return pointwise_by_nc<kDstBitpacked>(nc, nj);
+  }
 }
 
 }  // namespace lce

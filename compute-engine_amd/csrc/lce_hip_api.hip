@@ -426,12 +426,17 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key, const char* value) {
   if (!plan || !key || !value) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: null argument");
   lce::HostPlan& h = plan->host;
+  if (!strcmp(key, "pointwise_tiles")) {   // tuning aid for the 1x1 streaming kernel: tiles per wave
+    h.pw_tiles_pref = atoi(value);
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "engine")) {
     if (!strcmp(value, "auto")) h.engine_pref = 0;
     else if (!strcmp(value, "valu")) h.engine_pref = 1;
     else if (!strcmp(value, "mfma")) h.engine_pref = 2;
     else if (!strcmp(value, "direct")) h.engine_pref = 3;
-    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct");
+    else if (!strcmp(value, "pointwise")) h.engine_pref = 4;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|pointwise");
   } else if (!strcmp(key, "phase")) {
     // profiling aid for the matrix-core engine: time its two kernels separately
     if (!strcmp(value, "all")) h.phase = 0;
@@ -502,7 +507,20 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     void* out = (char*)output_dev + (size_t)b0 * out_img_bytes;
     uint32_t* sgn = sign_dev ? (uint32_t*)sign_dev + (size_t)b0 * sign_img_words : nullptr;
     bool sign_fused = false;
-    if (h.use_mfma) {
+    if (h.use_mfma && h.use_pointwise && ((uintptr_t)out & 15) == 0) {
+      // 1x1 streaming kernel: waves walk 32-pixel tiles of the launch's pixel matrix
+      lce::pointwise_fn fn = lce::find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj);
+      if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
+      const lce::PwArgs P = lce::make_pw_args(h, nb);
+      // k tiles per wave: enough blocks (>= 12 per CU when the launch has them) for the dispatcher to even
+      // out the CUs, few enough that a wave's register-resident filter bank is loaded once per several tiles
+      const int pw_k = h.pw_tiles_pref > 0 ? h.pw_tiles_pref : std::max(1, std::min(8, P.tiles / (4 * 256 * 12)));
+      const unsigned gx = (unsigned)(((int64_t)P.tiles + 4 * pw_k - 1) / (4 * pw_k));
+      const dim3 grid(gx, (unsigned)(h.d.channels_out / (32 * h.pw_nj)));
+      hipLaunchKernelGGL(fn, grid, dim3(256), (size_t)(4 * h.pw_nj * 4096), st, P, in, plan->d_wq.ptr, plan->d_mul.ptr,
+                         plan->d_bias.ptr, plan->d_thrq.ptr, out);
+      LCE_HIP_TRY(hipGetLastError());
+    } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());

@@ -90,4 +90,21 @@ struct MfmaArgs {
   FastDiv div_npg;
 };
 
+
+// Launch constants of the pointwise kernel.
+struct PwArgs {
+  int32_t M;            // pixels (rows) of this launch
+  int32_t N;            // output channels
+  int32_t Npad;         // padded channel count of the FP4 weight image and the parameter tables
+  int32_t Cw;           // input words per pixel
+  int32_t Cin;          // input channels
+  int32_t Wout;         // bitpacked output words per pixel
+  int32_t tiles;        // ceil(M / 32)
+  int32_t noclamp;      // the clamp is the identity on [0, 2*K_bt]
+  uint32_t in_bytes;    // M * Cw * 4
+  uint32_t out_bytes;   // bytes of the output rows of this launch
+  float a_bt;           // K_bt = Cin as float
+  float cmin, cmax;     // clamps as floats (exact integers)
+};
+
 }  // namespace lce

@@ -54,6 +54,16 @@ LCE_DEVICE int round_sat_i8(float y) {
   return (int)(c + __builtin_copysignf(0x1.fffffep-2f, c));   // float -> int conversion truncates
 }
 
+// The same rounding for two values that are already inside [-128, 127] (the clamp happened earlier): the add is
+// one v_pk_add_f32.
+LCE_DEVICE void round_i8_clamped2(float c0, float c1, int& q0, int& q1) {
+  const f32x2 c = {c0, c1};
+  const f32x2 h = {__builtin_copysignf(0x1.fffffep-2f, c0), __builtin_copysignf(0x1.fffffep-2f, c1)};
+  const f32x2 s = add2(c, h);
+  q0 = (int)s[0];
+  q1 = (int)s[1];
+}
+
 // :17-27,31-44,133-143 -- std::round (half away from zero), saturate to int8.
 LCE_DEVICE int ot_int8(int acc, int cmin, int cmax, float mul, float bias) {
   return round_sat_i8(ot_float(acc, cmin, cmax, mul, bias));

@@ -223,6 +223,56 @@ bool mfma_supported(const HostPlan& p) {
   return true;
 }
 
+// The streaming 1x1 kernel (lce_kernels_pointwise.h): filter extent 1, stride 1 (then no padding exists and
+// dilation is moot), one group, whole 32-channel output tiles, and a filter bank that fits registers
+// (1, 2 or 4 K-steps of 64 input channels).
+bool pointwise_supported(const HostPlan& p, int* nc, int* nj) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  if (!mfma_supported(p)) return false;
+  if (d.filter_height != 1 || d.filter_width != 1 || d.stride_height != 1 || d.stride_width != 1) return false;
+  if (d.groups != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
+  if (p.out_h != d.in_height || p.out_w != d.in_width) return false;
+  if (d.channels_out % 32 != 0) return false;
+  const int c = ceil_div(d.channels_in, 64);
+  if (c != 1 && c != 2 && c != 4) return false;
+  const int t = d.channels_out / 32;
+  *nc = c;
+  *nj = t % 4 == 0 ? 4 : t % 2 == 0 ? 2 : 1;
+  return true;
+}
+
+// Auto rule (profiles/r02/pointwise_vs_block_gemm.txt): on every 1x1 layer measured -- 64->64, 64->128, 128->128, 256->256
+// channels on 56x56 / 28x28 / 14x14 maps at batch 256, all three output types -- the streaming kernel is faster than
+// or equal to the block GEMM (int8 -10...-36 %, bitpacked -18...-50 %, float -2...-12 %); launches of less than 32 tiles
+// stay with the previous choice.
+// One exception: float output of a 64 -> 128-channel layer (K1 x N4: 240 VGPRs for the 16 row stores of a tile,
+// two waves per SIMD) is 15 % slower than the block GEMM.
+static bool pointwise_preferred(const HostPlan& p, int64_t pixels) {
+  if (p.d.dst_type == LCE_HIP_F32 && p.pw_nc == 1 && p.pw_nj == 4) return false;
+  return pixels >= 1024;
+}
+
+PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  PwArgs P{};
+  const int64_t m = (int64_t)batch_chunk * d.in_height * d.in_width;
+  P.M = (int32_t)m;
+  P.N = d.channels_out;
+  P.Npad = p.npad;
+  P.Cw = p.cw;
+  P.Cin = d.channels_in;
+  P.Wout = p.wout;
+  P.tiles = (int32_t)((m + 31) / 32);
+  P.noclamp = (p.clamp_min <= 0 && (int64_t)p.clamp_max >= 2 * (int64_t)p.backtransform_add) ? 1 : 0;
+  P.in_bytes = (uint32_t)(m * p.cw * 4);
+  const int64_t row = d.dst_type == LCE_HIP_BITPACKED ? (int64_t)p.wout * 4 : (int64_t)d.channels_out * (d.dst_type == LCE_HIP_I8 ? 1 : 4);
+  P.out_bytes = (uint32_t)(m * row);
+  P.a_bt = (float)p.backtransform_add;
+  P.cmin = (float)p.clamp_min;
+  P.cmax = (float)p.clamp_max;
+  return P;
+}
+
 static const MfmaCfg kMfmaCfgs[] = {
     {4, 2, 2, 4},  // 256 x 256, 8 waves
     {4, 2, 2, 2},  // 256 x 128, 8 waves
@@ -278,6 +328,22 @@ static void pack_for_mfma(HostPlan& p) {
   p.bias_q.assign(p.npad, 0.0f);
   std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
   std::copy(p.bias.begin(), p.bias.end(), p.bias_q.begin());
+  if (d.dst_type == LCE_HIP_I8) {
+    // int8 plans: thr_q = [lo | hi], the per-channel range of the TRANSFORMED value y = float(x) * mul + bias over the
+    // clamped accumulator x in [clamp_min, clamp_max], intersected with int8's range.  y is monotone in x (each
+    // rounding is), so med3(y(x), lo, hi) == saturate(y(med3(x, clamp_min, clamp_max))) for every x: the pointwise
+    // kernel spends one clamp instead of two (lce_kernels_pointwise.h)
+    p.thr_q.assign((size_t)2 * p.npad, 0.0f);
+    for (int i = 0; i < n; ++i) {
+      auto y = [&](int32_t x) { volatile float pr = (float)x * p.mul[i]; volatile float r = pr + p.bias[i]; return (float)r; };
+      const float a0 = y(p.clamp_min), a1 = y(p.clamp_max);
+      float lo = std::min(a0, a1), hi = std::max(a0, a1);
+      if (!(lo == lo) || !(hi == hi)) { lo = -128.0f; hi = 127.0f; }   // NaN parameters: unspecified in the reference
+      p.thr_q[i] = std::max(-128.0f, std::min(127.0f, lo));
+      p.thr_q[p.npad + i] = std::max(-128.0f, std::min(127.0f, hi));
+    }
+    return;
+  }
   // bit = (accum > thr)  <=>  2*accum > 2*thr, and the kernel's accumulator IS 2*accum (an integer
   // in [0, 2*K_bt]); clamp so the float is exact, keep the always / never cases
   const int64_t a = p.backtransform_add;
@@ -432,6 +498,9 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
   // ---- engine: matrix cores vs xor-popcount VALU ----
   p.use_mfma = false;
   p.use_direct = false;
+  p.use_pointwise = false;
+  if (p.engine_pref == 4 && !pointwise_supported(p, &p.pw_nc, &p.pw_nj))
+    return "bconv2d: the pointwise kernel runs 1x1 stride-1 ungrouped convolutions with <= 256 input channels (64, 128 or 256 after padding) and a multiple of 32 output channels";
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   if (p.engine_pref >= 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
@@ -482,6 +551,15 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     snprintf(nm, sizeof nm, "bconv2d_mfma%s<%s,%dx%d>", p.use_direct ? "_direct" : "",
              d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", want.bm(), want.bn());
     p.kernel_name = nm;
+    // 1x1 stride-1 layers: the streaming kernel on top of the same weight image (the block GEMM stays the
+    // fallback for output pointers that are not 16-byte aligned)
+    if ((p.engine_pref == 4 || (p.engine_pref == 0 && p.tile_pref.tm == 0)) && pointwise_supported(p, &p.pw_nc, &p.pw_nj) &&
+        (p.engine_pref == 4 || pointwise_preferred(p, pixels))) {
+      p.use_pointwise = true;
+      snprintf(nm, sizeof nm, "bconv2d_pointwise<%s,K%dx64,N%dx32>",
+               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", p.pw_nc, p.pw_nj);
+      p.kernel_name = nm;
+    }
     return "";
   }
 

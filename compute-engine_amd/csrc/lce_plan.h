@@ -65,12 +65,16 @@ struct HostPlan {
   std::string kernel_name;
 
   // matrix-core engine (lce_kernels_mfma.h)
-  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo)
+  int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo),
+                                           // 4 pointwise (1x1 streaming kernel, lce_kernels_pointwise.h)
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   int epilogue_pref = 0;                   // float/int8 epilogue: 0 auto, 1 per-tile transpose, 2 joint transpose
   bool use_mfma = false;
+  bool use_pointwise = false;              // with use_mfma: the 1x1 streaming kernel runs instead of the block GEMM
+  int pw_nc = 0, pw_nj = 0;                // its K-steps and 32-channel tiles per block
+  int pw_tiles_pref = 0;                   // tuning aid: 32-pixel tiles per wave (0 = auto)
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
   int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count
   int kch = 0;                             // K-steps (64-channel chunks) per filter tap that a block runs: cpad/64,
@@ -111,6 +115,9 @@ constexpr int kDirectLdsAuto = 80 * 1024;   // two blocks per CU: what the auto 
 bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
                      int* ipt, int lds_budget);
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
+// 1x1 streaming kernel: can it run this convolution (fills nc / nj), and its launch constants.
+bool pointwise_supported(const HostPlan& p, int* nc, int* nj);
+PwArgs make_pw_args(const HostPlan& p, int batch_chunk);
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 
 ConvArgs make_conv_args(const HostPlan& p, int batch_chunk);

@@ -123,7 +123,17 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     const ConvArgs A = make_conv_args(h, nb);
     const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
-    if (h.use_mfma) {
+    if (h.use_mfma && h.use_pointwise) {
+      pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj);
+      if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
+      const PwArgs P = make_pw_args(h, nb);
+      std::vector<uint8_t> wq = h.wq;
+      wq.resize(wq.size() + 64, 0);
+      // a small grid: waves loop over several tiles
+      launch_block_lockstep(std::min((P.tiles + 3) / 4, 2), h.d.channels_out / (32 * h.pw_nj), 256, (size_t)(4 * h.pw_nj * 4096), [&] {
+        fn(P, in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), out);
+      });
+    } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }

@@ -26,6 +26,7 @@ namespace lce_dev {
 
 struct u32x2 { uint32_t v[2]; uint32_t& operator[](int i) { return v[i]; } uint32_t operator[](int i) const { return v[i]; } };
 struct u32x4 { uint32_t v[4]; uint32_t& operator[](int i) { return v[i]; } uint32_t operator[](int i) const { return v[i]; } };
+struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
 struct f32x4 { float v[4]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
 
 constexpr int kWave = 64;
@@ -75,6 +76,11 @@ inline u32x4 buf_load(rsrc_t r, uint32_t off, u32x4*) { return buf_load_impl<u32
 inline uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline int popc(uint32_t x) { return __builtin_popcount(x); }
 inline float mul_then_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
+
+inline f32x2 mul_then_add2(f32x2 a, float b, float c) { f32x2 r; r[0] = mul_then_add(a[0], b, c); r[1] = mul_then_add(a[1], b, c); return r; }
+inline f32x2 add2(f32x2 a, f32x2 b) { f32x2 r; { volatile float s = a[0] + b[0]; r[0] = s; } { volatile float s = a[1] + b[1]; r[1] = s; } return r; }
+
+inline void keep_alive(const u32x4&) {}
 
 inline unsigned long long wave_ballot(bool p) {
   if (!g_ctx.bar) return p ? ~0ull : 0ull;  // sequential mode: only used via wave_any

@@ -286,6 +286,17 @@ def test_conv_grouped_on_the_matrix_cores(cin, cout, groups, engine):
         assert all(n.startswith("bconv2d_mfma") for n in names), names
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32), (128, 512)])
+def test_pointwise_streaming_kernel(cin, cout):
+    """lce_kernels_pointwise.h (1x1 stride 1: filter bank in registers, waves walk 32-pixel tiles) against the
+    oracle: all three output types, 1 / 2 / 4 K-steps with partial words, several channel blocks, pixel counts
+    that are not a multiple of 32, more tiles than resident waves."""
+    for b, h, w_, act in ((3, 5, 7, O.ACT_NONE), (7, 29, 31, O.ACT_RELU), (64, 28, 28, O.ACT_RELU6)):
+        spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, padding=O.PADDING_SAME, pad_values=1, activation=act)
+        names = _check_all_dst(spec, cin + 3 * cout + b, engine="pointwise")
+        assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+
+
 @pytest.mark.parametrize("engine,kernel", [("auto", "auto"), ("direct", "auto"), ("mfma", "auto"), ("valu", "auto"), ("valu", "general")])
 @pytest.mark.parametrize("shape", [(3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 136), (2, 28, 28, 128, 33)])
 def test_run_dual_is_run_followed_by_lcequantize(shape, engine, kernel):
@@ -844,7 +855,8 @@ def test_birealnet_stack_batch256():
     assert all(chain.fed[1:])
     chain.run_chain()
     names = _check_chain(chain, [0, 131, 255], O.DST_I8)
-    assert all(n.startswith("bconv2d_mfma") for n in names), names
+    assert all(n.startswith(("bconv2d_mfma", "bconv2d_pointwise")) for n in names), names
+    assert sum(n.startswith("bconv2d_pointwise") for n in names) >= 2, names     # the 1x1 layers stream
 
 
 def test_quicknet_large_per_gpu_shard_batch256():

@@ -253,6 +253,31 @@ def test_mfma_engine_batch_chunking_and_pointwise():
     _run_all_dst_mfma(spec, 12, max_batch=1)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32)])
+@pytest.mark.parametrize("act", [O.ACT_NONE, O.ACT_RELU], ids=["none", "relu"])
+def test_pointwise_streaming_kernel(cin, cout, act):
+    """The 1x1 streaming kernel (lce_kernels_pointwise.h; filter bank in registers, waves walking 32-pixel tiles
+    of the batch's pixel matrix) against the oracle: 1 / 2 / 4 K-steps incl. partial last words and an empty
+    upper K-half, 1 / 2 / 4 channel tiles per block with several blocks along the channels, a pixel count that is
+    not a multiple of 32, more tiles than waves (the tile loop and its prefetch), batch chunking."""
+    for b, h, w_, mb in ((3, 5, 7, 0), (2, 9, 11, 0), (5, 4, 4, 2)):
+        for padding in (O.PADDING_VALID, O.PADDING_SAME):
+            spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, padding=padding, pad_values=1, activation=act)
+            names = _run_all_dst_mfma(spec, seed=cin + 3 * cout + b, max_batch=mb, engine="pointwise")
+            assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+
+
+def test_pointwise_kernel_refuses_what_it_cannot_run():
+    x, w, mul, bias = synth.conv_inputs(O.ConvSpec(1, 4, 4, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), 1)
+    for spec in (O.ConvSpec(1, 4, 4, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1),       # 3x3
+                 O.ConvSpec(1, 4, 4, 64, 1, 1, 64, stride_h=2, stride_w=2),                     # strided
+                 O.ConvSpec(1, 4, 4, 64, 1, 1, 48),                                             # channels not a multiple of 32
+                 O.ConvSpec(1, 4, 4, 320, 1, 1, 64)):                                           # filter bank too deep
+        x, w, mul, bias = synth.conv_inputs(spec, 1)
+        with pytest.raises(RuntimeError, match="pointwise kernel runs 1x1"):
+            H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="pointwise")
+
+
 @pytest.mark.parametrize("tile", [(128, 64), (128, 128), (256, 64), (128, 256)], ids=lambda t: "%dx%d" % t)
 @pytest.mark.parametrize("cin,cout,pad", [(64, 64, "ONE"), (96, 33, "SAME"), (20, 7, "VALID"), (160, 70, "ONE")])
 def test_mfma_direct_variant(tile, cin, cout, pad):
