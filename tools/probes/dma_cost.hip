@@ -16,6 +16,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 __device__ unsigned long long g_cyc[1024];
+__device__ unsigned g_sink[256 * 1024 * 1024 / 4];   // 1 MiB per block for the store forms
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 template <int NDMA, int FORM, int WAIT>
 __global__ __launch_bounds__(256, 1) void dma_cost(const uint8_t* wts, float* out, int steps) {
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(256, 1) void dma_cost(const uint8_t* wts, float* ou
   // FORM 2: stride 16 + ADD_TID_ENABLE (word3 bit 23): the hardware adds TID * stride to the address
   const rsrc_t r = FORM == 2 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wts), 16, 512 * 1024, 0x00020000 | (1 << 23))
                              : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wts), 0, 512 * 1024, 0x00020000);
+  const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g_sink + (size_t)blockIdx.x * (1024 * 1024 / 4), 0, 1024 * 1024, 0x00020000);
   v8i a = {0x22222222, 0x2A2A2A2A, (int)0xA2A2A2A2, 0x22222222, 0, 0, 0, 0};
   v8i b = {0x2222AAAA, 0x2A2A2A2A, 0x22222222, (int)0xAAAA2222, 0, 0, 0, 0};
   a[0] ^= (lane * 0x01010101) & 0x88888888;
@@ -78,6 +81,11 @@ __global__ __launch_bounds__(256, 1) void dma_cost(const uint8_t* wts, float* ou
       }
       if (FORM == 8 && NDMA == 1 && i == 2 * wave) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(0), 16, voff, soff, 0, 0);
       if (FORM == 9 && wave == 0 && i < NDMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(i), 16, voff, soff + i * 1024, 0, 0);
+      // FORM 10 / 11: one 16-byte-per-lane non-temporal STORE per step woven in after the third MFMA (the drain of a
+      // previous tile through the K loop), without / with the step's two copies
+      if ((FORM == 10 || FORM == 11) && i == 2)
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{(unsigned)ks, 2u, 3u, (unsigned)lane}, rs, (unsigned)(((ks * 4 + wave) & 1023) * 1024 + lane * 16), 0, 2);
+      if (FORM == 11 && i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(i), 16, voff, soff + i * 1024, 0, 0);
       if (FORM == 3 && wave == 0 && i < NDMA) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(4 * i), 16, voff, soff + i * 4096, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_at(4 * i), 16, voff, soff + i * 4096, 1024, 0);
@@ -289,6 +297,9 @@ int main() {
   run<1, 9, 2>("only wave 0 copies, 1 per step (no one to collide with), barrier per step", w, out);
   run<2, 9, 2>("only wave 0 copies, 2 per step, barrier per step", w, out);
   run<4, 9, 2>("only wave 0 copies, 4 per step, barrier per step", w, out);
+  run<0, 10, 2>("8 MFMAs + one 16-byte nt store per step, barrier per step", w, out);
+  run<2, 11, 2>("8 MFMAs + 2 copies + one 16-byte nt store per step, barrier per step", w, out);
+  run<2, 0, 2>("8 MFMAs + 2 copies (reference for the line above)", w, out);
   run_loader<4>("fifth wave = loader, 3-deep ring, barrier per step", w, out);
   run_loader<8>("fifth wave = loader, 3-deep ring, barrier per step", w, out);
   run_loader<12>("fifth wave = loader, 3-deep ring, barrier per step", w, out);
