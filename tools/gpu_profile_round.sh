@@ -24,7 +24,7 @@ PY
 # 1 -------------------------------------------------------------------------------------------------
 if [[ $PARTS == *1* ]]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o t -- \
-    python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench/stdout.log 2> $OUT/bench/stderr.log
+    python $R/bench.py --no-cpu-baseline > $OUT/bench/stdout.log 2> $OUT/bench/stderr.log
 echo "bench rc=$?"
 tail -1 $OUT/bench/stdout.log > $OUT/bench_under_rocprof.json
 summ $OUT/bench/t_kernel_stats.csv | tee $OUT/bench_kernel_stats.txt
