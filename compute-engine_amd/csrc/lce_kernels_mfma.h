@@ -163,6 +163,9 @@ __device__ unsigned long long lce_phase_tl[16384 * 16];
 #else
 #define LCE_PH(slot) do {} while (0)
 #endif
+#ifndef LCE_STORE_PACE
+#define LCE_STORE_PACE 2   // s_sleep argument behind every float row store of the joint-transpose epilogue
+#endif
 template <int V> struct IntC { static constexpr int value = V; };
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
@@ -677,7 +680,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           // the co-resident block's weight DMAs queue behind it (its K loop 18.7k -> 16.4k cycles with the
           // pause, L0 float -2.5 %, tools/phases.py); the sleeping wave also leaves its issue slots to it
 #ifndef LCE_ABL_NOSLEEP
-          yield_issue_slots<2>();
+          yield_issue_slots<LCE_STORE_PACE>();
 #endif
         }
       }
