@@ -168,12 +168,16 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
 /* Tuning/testing knobs (defaults are all "auto"):
  *   "engine" = "auto" | "valu" (v_xor + v_bcnt popcount kernels) | "mfma" (FP4 matrix cores, FP4
  *              workspace + GEMM whose tiles span images) | "direct" (FP4 matrix cores, each block
- *              expands its own input halo into LDS; what "auto" picks whenever it fits);
+ *              expands its own input halo into LDS; what "auto" picks whenever it fits) | "pointwise" (1x1
+ *              stride-1 ungrouped layers, <= 256 input channels, a multiple of 32 output channels: filter bank
+ *              in registers, waves stream 32-pixel tiles; what "auto" picks for such layers);
  *   "kernel" = "auto" | "tiled" | "general"                        (valu engine);
  *   "tile"   = "auto" | valu lane tile "4x16"|"2x32"|"2x16"|"1x32"|"1x16"
  *                     | matrix-core block tile "256x256"|"256x128"|"512x64"|"128x256"|"128x128"|"256x64"|"128x64"
  *                       (pixels x channels; with engine = mfma or direct);
- *   "phase"  = "all" | "expand" | "gemm"   (engine = mfma, profiling aid: run one of its two kernels). */
+ *   "phase"  = "all" | "expand" | "gemm"   (engine = mfma, profiling aid: run one of its two kernels);
+ *   "epilogue" = "auto" | "tile" | "wide"   (matrix-core float / int8 epilogue: per-tile or joint transpose);
+ *   "pointwise_tiles" = "0" (auto) | "1".."8"   (pointwise kernel: 32-pixel tiles per wave). */
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key,
                                                const char* value);
 /* Name of the kernel variant the next run will launch (static string owned by the plan). */
