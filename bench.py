@@ -363,8 +363,7 @@ def extra_measurements(amd, torch, spec, args, dev):
             entry = {"layers": len(layers), "batch": args.batch, "convolutions_only_ms": convs * 1e3,
                      "bmac_per_s": ch.binary_macs / convs, **hbm(ch.algorithmic_bytes(), convs),
                      "device_resident_chain_ms": fused * 1e3}
-            if dst == "f32":
-                entry["chain_with_separate_lcequantize_ms"] = _event_time(torch, dev, lambda: ch.run_chain(fused=False), st) * 1e3
+            entry["chain_with_separate_lcequantize_ms"] = _event_time(torch, dev, lambda: ch.run_chain(fused=False), st) * 1e3
             # launch gaps: the chain replayed from a captured HIP graph
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))

@@ -259,10 +259,13 @@ class Bconv2dPlan:
         return out
 
     def run_dual(self, x, out=None, out_bits=None, stream: int | None = None):
-        """Float output AND its LceQuantize (sign bits, [B,OH,OW,ceil(Cout/32)] int32) in one pass."""
+        """Float or int8 output AND its LceQuantize ([B,OH,OW,ceil(Cout/32)] int32: sign bits, or for an int8 plan
+        bit = q < out_zero_point) in one pass."""
         import torch
         self._check_input(x)
-        out = self._out(x, out, torch.float32)
+        if self.params.dst_type == BITPACKED:
+            raise ValueError("run_dual: the plan already writes bits")
+        out = self._out(x, out, torch.float32 if self.params.dst_type == F32 else torch.int8)
         b, oh, ow, n = self.output_shape
         if out_bits is None:
             out_bits = torch.empty((b, oh, ow, bitpacked_size(n)), dtype=torch.int32, device=x.device)

@@ -85,7 +85,7 @@ inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = fal
                 : find_mfma_v<false>(dst, bm, bn, zero_pad_correction);
 }
 
-typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, const float*, const float*, const float*, void*);
+typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, const float*, const float*, const float*, void*, uint32_t*);
 
 template <int DST, int NC>
 pointwise_fn pointwise_by_nj(int nj) {

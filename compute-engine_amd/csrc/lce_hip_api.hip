@@ -518,8 +518,9 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       const unsigned gx = (unsigned)(((int64_t)P.tiles + 4 * pw_k - 1) / (4 * pw_k));
       const dim3 grid(gx, (unsigned)(h.d.channels_out / (32 * h.pw_nj)));
       hipLaunchKernelGGL(fn, grid, dim3(256), (size_t)(4 * h.pw_nj * 4096), st, P, in, plan->d_wq.ptr, plan->d_mul.ptr,
-                         plan->d_bias.ptr, plan->d_thrq.ptr, out);
+                         plan->d_bias.ptr, plan->d_thrq.ptr, out, sgn);
       LCE_HIP_TRY(hipGetLastError());
+      sign_fused = true;   // (also when there is none to write)
     } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct);
@@ -527,7 +528,8 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
       const int bm = h.mfma.bm(), bn = h.mfma.bn();
       // the joint-transpose float epilogue is the one that can also emit the sign words
-      sign_fused = sgn && G.f32_wide && h.zero_pad_mode != lce::kZeroPadCorrection && ((uintptr_t)out & 15) == 0;
+      sign_fused = sgn && (h.d.dst_type == LCE_HIP_I8 ? G.i8_wide != 0 : G.f32_wide != 0) &&
+                   h.zero_pad_mode != lce::kZeroPadCorrection && ((uintptr_t)out & 15) == 0;
       uint32_t* ksgn = sign_fused ? sgn : nullptr;
       if (h.use_direct) {
         // no workspace: every block expands its own input halo into LDS
@@ -591,8 +593,9 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     }
     if (sgn && !sign_fused) {
       // this kernel variant has no second output: LceQuantize as its own launch on the same stream
-      if (lce_hip_status s = lce_hip_bitpack(LCE_HIP_F32, out, (size_t)nb * h.out_h * h.out_w, (size_t)h.d.channels_out, 0,
-                                             (int32_t*)sgn, (void*)st))
+      const bool i8 = h.d.dst_type == LCE_HIP_I8;
+      if (lce_hip_status s = lce_hip_bitpack(i8 ? LCE_HIP_I8 : LCE_HIP_F32, out, (size_t)nb * h.out_h * h.out_w,
+                                             (size_t)h.d.channels_out, i8 ? h.d.out_zero_point : 0, (int32_t*)sgn, (void*)st))
         return s;
     }
   }
@@ -613,12 +616,12 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
   return run_images(plan, input_dev, output_dev, nullptr, 0, plan->host.d.batch, (hipStream_t)stream);
 }
 
-lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, float* output_dev,
+lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_t* input_dev, void* output_dev,
                                         int32_t* output_bits_dev, void* stream) {
   if (lce_hip_status s = run_checks(plan, input_dev, output_dev, "bconv2d_run_dual")) return s;
-  if (plan->host.d.dst_type != LCE_HIP_F32)
-    return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: the plan's output type must be float32 (a bitpacked-output plan "
-                "already writes bits; int8 has no sign to quantize)");
+  if (plan->host.d.dst_type == LCE_HIP_BITPACKED)
+    return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: the plan's output type must be float32 or int8 (a bitpacked-output "
+                "plan already writes bits)");
   if (plan->host.d.batch == 0) return LCE_HIP_OK;
   if (!output_bits_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: null argument");
   return run_images(plan, input_dev, output_dev, output_bits_dev, 0, plan->host.d.batch, (hipStream_t)stream);

@@ -83,6 +83,8 @@ struct MfmaArgs {
   int32_t f32_wide;        // float epilogue may transpose the WN tiles of a row block together
   int32_t i8_wide;         // int8 epilogue may use WN*4 KiB of LDS scratch per wave (16-byte row stores)
   int32_t noclamp;         // the output transform's clamp is the identity on [0, 2*K_bt] (activation NONE)
+  float bit_thr;           // second output (LceQuantize of the value just produced): bit = value < bit_thr
+                           // (float output: 0; int8 output: the planner's threshold for "rounds below the zero point")
   FastDiv div_tpi, div_qg, div_ohow, div_hpix;
   // grouped convolutions: a block's channels lie in ONE group g = n0 / Npg, whose input channels are the
   // slice [g*Cin_g, (g+1)*Cin_g) of the same pixels; its K loop covers the KCH 64-channel chunks that
@@ -105,6 +107,7 @@ struct PwArgs {
   uint32_t out_bytes;   // bytes of the output rows of this launch
   float a_bt;           // K_bt = Cin as float
   float cmin, cmax;     // clamps as floats (exact integers)
+  float bit_thr;        // second output: bit = value < bit_thr (as MfmaArgs::bit_thr)
 };
 
 }  // namespace lce

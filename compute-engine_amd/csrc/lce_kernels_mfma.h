@@ -575,8 +575,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // (lanes 32-63), q = (r & 3) + 8 * (r >> 2); the 32 channel bits of a row are one compare + ballot, and
   // v_writelane drops each word into the lane that will store it -- afterwards lane p (< 32) owns row p.
   // BITPACKED output: bit = acc > thr (accum > threshold <=> 2*accum > 2*threshold, output_transform.h:160-168);
-  // second output of a float layer: bit = y < 0, the LceQuantize of the value the lane just produced
-  // (core/bitpacking/bitpack.h:72-110; -0.0 and NaN give 0 there and here).
+  // second output of a float / int8 layer: the LceQuantize of the value the lane just produced, bit = y < bit_thr --
+  // float: bit_thr = 0 (core/bitpacking/bitpack.h:72-110; -0.0 and NaN give 0 there and here); int8: the planner's
+  // threshold for "rounds to an int8 below the zero point" (int8_below_threshold, lce_plan.cpp).
   auto bit_rows = [&](int i, auto below_zero, uint32_t* dst_words) LCE_LAMBDA_INLINE {
     constexpr bool SIGN = decltype(below_zero)::value;
     uint32_t words[WN];
@@ -586,7 +587,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
       unsigned long long bits[WN];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bits[j] = wave_ballot(SIGN ? acc[i][j][r] < 0.0f : acc[i][j][r] > tj[j]);
+      for (int j = 0; j < WN; ++j) bits[j] = wave_ballot(SIGN ? acc[i][j][r] < G.bit_thr : acc[i][j][r] > tj[j]);
       settle_ballots(bits);                    // ONE hazard pad for the WN compares, not one per v_writelane
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
@@ -702,14 +703,28 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
                                    : kOobOffset;                  // N % 16 == 0: whole group or nothing
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+      if (sign_words != nullptr) {
+        // with a second output the transform happens in place first (the accumulators become the values the
+        // rounding will see), then their "below the zero point" bits, then the transpose
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float x = med3(acc[i][j][r], cminf, cmaxf);
-          scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
-        }
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = mul_then_add(med3(acc[i][j][r], cminf, cmaxf), mj[j], bj[j]);
+        bit_rows(i, StepSteady{}, sign_words);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] = acc[i][j][r];
+      } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float x = med3(acc[i][j][r], cminf, cmaxf);
+            scratch[row * RW + j * 32 + l31] = mul_then_add(x, mj[j], bj[j]);
+          }
+      }
       wave_lds_fence();
       const int g = lane % GPR;
       // all LDS reads of a batch first (one LDS latency per batch, not one per store), then convert + store

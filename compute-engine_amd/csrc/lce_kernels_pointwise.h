@@ -35,7 +35,7 @@ template <int DST, int NC, int NJ>
 LCE_KERNEL void __launch_bounds__(256, pw_min_blocks(NC, NJ))
 bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t* __restrict__ wq,
                   const float* __restrict__ mul, const float* __restrict__ bias,
-                  const float* __restrict__ thrf, void* __restrict__ out) {
+                  const float* __restrict__ thrf, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
   const int tid = thread_idx_x();
   const int lane = tid & (kWave - 1), wave = uniform(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -158,9 +158,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
     } else {
       // the transform on the accumulators (output_transform.h:93-157), then the transpose: a lane holds one
       // channel of 16 pixel rows, the output wants rows of consecutive channels
-      auto slot = [&](int j, int r) LCE_LAMBDA_INLINE -> float& {
-        return scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31];
-      };
+      // in place: the accumulators become the values the output (or its int8 rounding) is made of
       if constexpr (DST == kDstInt8) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -168,8 +166,8 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
           for (int r = 0; r < 16; r += 2) {
             const f32x2 x = {acc[j][r], acc[j][r + 1]};
             const f32x2 y = mul_then_add2(x, mj[j], bj[j]);
-            slot(j, r) = med3(y[0], tj[j], uj[j]);
-            slot(j, r + 1) = med3(y[1], tj[j], uj[j]);
+            acc[j][r] = med3(y[0], tj[j], uj[j]);
+            acc[j][r + 1] = med3(y[1], tj[j], uj[j]);
           }
       } else if (P.noclamp) {
 #pragma unroll
@@ -178,8 +176,8 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
           for (int r = 0; r < 16; r += 2) {
             const f32x2 x = {acc[j][r], acc[j][r + 1]};
             const f32x2 y = mul_then_add2(x, mj[j], bj[j]);
-            slot(j, r) = y[0];
-            slot(j, r + 1) = y[1];
+            acc[j][r] = y[0];
+            acc[j][r + 1] = y[1];
           }
       } else {
 #pragma unroll
@@ -188,10 +186,43 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
           for (int r = 0; r < 16; r += 2) {
             const f32x2 x = {med3(acc[j][r], P.cmin, P.cmax), med3(acc[j][r + 1], P.cmin, P.cmax)};
             const f32x2 y = mul_then_add2(x, mj[j], bj[j]);
-            slot(j, r) = y[0];
-            slot(j, r + 1) = y[1];
+            acc[j][r] = y[0];
+            acc[j][r + 1] = y[1];
           }
       }
+      // optional second output: the LceQuantize of those values (bit = value < bit_thr: 0 for float, the planner's
+      // "rounds below the zero point" threshold for int8), gathered like the bitpacked output above
+      if (sign_words != nullptr) {
+        uint32_t words[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) words[j] = 0u;
+        auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
+          constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
+          unsigned long long bits[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bits[j] = wave_ballot(acc[j][r] < P.bit_thr);
+          settle_ballots(bits);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);
+            words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);
+          }
+        };
+        gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
+        gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
+        gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
+        gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
+        const uint32_t m = row0 + (uint32_t)lane;
+        if (lane < 32 && m < (uint32_t)P.M) {
+          uint32_t* o = sign_words + (size_t)m * (size_t)P.Wout + (size_t)(n0 >> 5);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) o[j] = words[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * half) * RW + j * 32 + l31] = acc[j][r];
       wave_lds_fence();
       if constexpr (DST == kDstFloat) {
         constexpr int LPR = RW / 4, RPI = 64 / LPR, NK = 32 / RPI;   // lanes per row, rows per store, stores per tile

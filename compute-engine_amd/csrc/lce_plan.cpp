@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <cstdio>
 
 namespace lce {
@@ -128,6 +130,29 @@ static void fill_zero_pad_cache(HostPlan& p, const float* post_mul) {
       }
 }
 
+// LceQuantize of an int8 tensor sets bit = (q < zero_point) (quantization.cc:76-114, bitpack.h:72-110).  The kernels
+// hold the value BEFORE the int8 rounding, q = round_sat_i8(c) = trunc(c + copysign(pred(0.5), c)) after saturation, which
+// is monotone in c, so "q < zero_point" is "c < T" for the smallest float T whose rounding reaches zero_point.  Found by
+// bisection over the ordered float bit patterns with the very expression the kernels evaluate (no case analysis of ties).
+static int round_sat_i8_host(float c) {
+  c = c < -128.0f ? -128.0f : (c > 127.0f ? 127.0f : c);
+  volatile float s = c + std::copysign(0x1.fffffep-2f, c);
+  return (int)s;
+}
+float int8_below_threshold(int32_t zero_point) {
+  if (zero_point <= -128) return -std::numeric_limits<float>::infinity();   // no int8 is below it
+  if (zero_point > 127) return std::numeric_limits<float>::infinity();      // every int8 is
+  // monotone key over floats: negative floats descend with their bit pattern
+  auto from_key = [](int64_t k) { uint32_t u = k >= 0 ? (uint32_t)k : 0x80000000u | (uint32_t)(-k - 1); float f; memcpy(&f, &u, 4); return f; };
+  auto to_key = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? -(int64_t)(u & 0x7fffffffu) - 1 : (int64_t)u; };
+  int64_t lo = to_key(-128.0f), hi = to_key(127.0f);   // round(lo) = -128 < zero_point <= 127 = round(hi)
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (round_sat_i8_host(from_key(mid)) >= zero_point) hi = mid; else lo = mid;
+  }
+  return from_key(hi);
+}
+
 void fold_parameters(HostPlan& p, const int32_t* filter_ohwi, const float* post_mul,
                      const float* post_bias, const int32_t* thresholds) {
   const lce_hip_bconv2d_desc& d = p.d;
@@ -165,6 +190,7 @@ void fold_parameters(HostPlan& p, const int32_t* filter_ohwi, const float* post_
     p.clamp_min = -hi + p.backtransform_add;
     p.clamp_max = -lo + p.backtransform_add;
     if (p.zero_pad_mode == kZeroPadCorrection) fill_zero_pad_cache(p, post_mul);
+    p.bit_thr = d.dst_type == LCE_HIP_I8 ? int8_below_threshold(d.out_zero_point) : 0.0f;
   }
   p.have_weights = true;
   p.packed.clear();  // force a repack on the next select_kernel
@@ -270,6 +296,7 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   P.a_bt = (float)p.backtransform_add;
   P.cmin = (float)p.clamp_min;
   P.cmax = (float)p.clamp_max;
+  P.bit_thr = p.bit_thr;
   return P;
 }
 
@@ -466,6 +493,7 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   G.cmin = (float)p.clamp_min;
   G.cmax = (float)p.clamp_max;
   G.noclamp = (p.clamp_min <= 0 && (int64_t)p.clamp_max >= 2 * (int64_t)p.backtransform_add) ? 1 : 0;
+  G.bit_thr = p.bit_thr;
   // the wide int8 epilogue transposes WN tiles at once: only where the block's LDS allocation
   // already covers waves * WN * 4 KiB (it must not cost a resident block)
   {

@@ -51,6 +51,7 @@ struct HostPlan {
   bool have_weights = false;
   std::vector<float> mul, bias;            // channels_out entries
   int32_t clamp_min = 0, clamp_max = 0;
+  float bit_thr = 0.0f;                    // LceQuantize of the output as a compare: bit = value < bit_thr
   std::vector<int32_t> thresholds;
   std::vector<uint32_t> filter;            // OHWI copy (general kernel + repacking source)
   std::vector<float> zero_pad_cache;       // zero_padding_correction.h:39-176
@@ -96,6 +97,9 @@ std::string validate_and_infer(HostPlan& p);
 // thresholds, compute the zero-padding correction cache.
 void fold_parameters(HostPlan& p, const int32_t* filter_ohwi, const float* post_mul,
                      const float* post_bias, const int32_t* thresholds);
+
+// Smallest float T with round_sat_i8(T) >= zero_point: LceQuantize's "q < zero_point" on the value before rounding.
+float int8_below_threshold(int32_t zero_point);
 
 // Can the tiled kernel with channel tile `tn` run this convolution?
 bool tiled_supports(const HostPlan& p, int tn);

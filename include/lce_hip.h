@@ -201,15 +201,16 @@ lce_hip_status lce_hip_bconv2d_run(lce_hip_bconv2d_plan* plan, const int32_t* in
 /* The HIP device the plan is bound to, -1 before its first run. */
 int lce_hip_bconv2d_plan_device(const lce_hip_bconv2d_plan* plan);
 
-/* LceBconv2d (float output) and the LceQuantize that follows it in a converted graph
+/* LceBconv2d (float or int8 output) and the LceQuantize that follows it in a converted graph
  * (tflite/kernels/quantization.cc:76-114 on the convolution's output), in one pass: `output_dev` gets the
- * float tensor [B,OH,OW,Cout] exactly as lce_hip_bconv2d_run writes it, `output_bits_dev` its sign bits
- * [B,OH,OW,ceil(Cout/32)] exactly as lce_hip_bitpack(F32, output_dev, ...) would -- from the same epilogue
- * (the value a lane just produced is balloted) where the kernel variant allows, by a second launch on the
- * same stream otherwise.  Saves re-reading the float tensor between the binary convolutions of a
- * device-resident chain.  The plan's dst_type must be LCE_HIP_F32. */
+ * tensor [B,OH,OW,Cout] exactly as lce_hip_bconv2d_run writes it, `output_bits_dev` its quantization
+ * [B,OH,OW,ceil(Cout/32)] exactly as lce_hip_bitpack(F32, output_dev, ..., 0, ...) -- sign bits -- or, for an int8
+ * plan, lce_hip_bitpack(I8, output_dev, ..., out_zero_point, ...) -- bit = (q < zero_point) -- would: from the same
+ * epilogue (the value a lane just produced is compared and balloted) where the kernel variant allows, by a second
+ * launch on the same stream otherwise.  Saves re-reading the tensor between the binary convolutions of a
+ * device-resident chain.  The plan's dst_type must be LCE_HIP_F32 or LCE_HIP_I8. */
 lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_t* input_dev,
-                                        float* output_dev, int32_t* output_bits_dev, void* stream);
+                                        void* output_dev, int32_t* output_bits_dev, void* stream);
 
 /* Same as lce_hip_bconv2d_run with host tensors (the interpreter arena), synchronous.  The batch is cut
  * into slices that flow through three streams (H2D | kernel | D2H) so that the copies of neighbouring

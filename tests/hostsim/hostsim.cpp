@@ -86,6 +86,7 @@ void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call 
 extern "C" {
 
 const char* hostsim_last_error() { return g_err.c_str(); }
+float hostsim_int8_below_threshold(int32_t zero_point) { return int8_below_threshold(zero_point); }
 void hostsim_set_sign_output(void* words) { g_sign_out = words; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
@@ -131,7 +132,8 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       wq.resize(wq.size() + 64, 0);
       // a small grid: waves loop over several tiles
       launch_block_lockstep(std::min((P.tiles + 3) / 4, 2), h.d.channels_out / (32 * h.pw_nj), 256, (size_t)(4 * h.pw_nj * 4096), [&] {
-        fn(P, in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), out);
+        fn(P, in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), out,
+           g_sign_out ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr);
       });
     } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,

@@ -286,6 +286,40 @@ def test_conv_grouped_on_the_matrix_cores(cin, cout, groups, engine):
         assert all(n.startswith("bconv2d_mfma") for n in names), names
 
 
+@pytest.mark.parametrize("engine,kernel,k", [("auto", "auto", 3), ("direct", "auto", 3), ("mfma", "auto", 3), ("valu", "auto", 3),
+                                             ("valu", "general", 3), ("auto", "auto", 1), ("direct", "auto", 1)])
+@pytest.mark.parametrize("zp", [-128, -5, 0, 3, 127])
+def test_run_dual_on_an_int8_plan_is_run_followed_by_lcequantize(engine, kernel, k, zp):
+    """lce_hip_bconv2d_run_dual with an int8 plan: the int8 tensor bit-equal to lce_hip_bconv2d_run's, the bits
+    bit-equal to lce_hip_bitpack(I8, ., zero_point) of it (quantization.cc:76-114: bit = q < zero_point) -- from the
+    same epilogue where the kernel variant can (block GEMM with the joint transpose, the pointwise kernel), by a
+    second launch where not.  Scale and multipliers put results on and around the zero point, exact ties included."""
+    for shape in ((3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 136)):
+        b, h, w_, cin, cout = shape
+        spec = O.ConvSpec(b, h, w_, cin, k, k, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_NONE)
+        x, w, mul, bias = synth.conv_inputs(spec, sum(shape) + zp, negative_mul_fraction=0.3)
+        mul = (np.sign(mul) * 0.5).astype(np.float32)
+        bias = np.zeros_like(bias)
+        scale = float(k * k * cin) / 16.0
+        plan = amd.Bconv2dPlan(_params(spec, amd.I8, out_scale=scale, out_zero_point=zp))
+        plan.set_weights(w, mul, bias)
+        plan.set_option("engine", engine)
+        plan.set_option("kernel", kernel)
+        xd = torch.from_numpy(x).to(DEV)
+        y = plan.run(xd)
+        y2 = torch.full_like(y, 0x5A)
+        bits = torch.full((b, spec.out_h, spec.out_w, (cout + 31) // 32), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+        plan.run_dual(xd, y2, bits)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), plan.kernel_name()
+        assert torch.equal(bits, amd.bitpack(y, zp)), plan.kernel_name()
+        want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp)
+        assert np.array_equal(y.cpu().numpy(), want), plan.kernel_name()
+        assert np.array_equal(bits.cpu().numpy(), O.bitpack(want, zp)), plan.kernel_name()
+        if -128 < zp < 127:
+            assert (want < zp).any() and (want >= zp).any()
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32), (128, 512)])
 def test_pointwise_streaming_kernel(cin, cout):
     """lce_kernels_pointwise.h (1x1 stride 1: filter bank in registers, waves walk 32-pixel tiles) against the
@@ -295,6 +329,17 @@ def test_pointwise_streaming_kernel(cin, cout):
         spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, padding=O.PADDING_SAME, pad_values=1, activation=act)
         names = _check_all_dst(spec, cin + 3 * cout + b, engine="pointwise")
         assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+        # ... and the float layer's second output (sign bits) from the same kernel
+        x, w, mul, bias = synth.conv_inputs(spec, cin + b, negative_mul_fraction=0.3)
+        bias = (bias - 0.4 * cin * np.abs(mul)).astype(np.float32)
+        plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+        plan.set_weights(w, mul, bias)
+        plan.set_option("engine", "pointwise")
+        y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
+        torch.cuda.synchronize()
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        assert np.array_equal(y.cpu().numpy().view(np.int32), want.view(np.int32))
+        assert np.array_equal(bits.cpu().numpy(), O.bitpack(want))
 
 
 @pytest.mark.parametrize("engine,kernel", [("auto", "auto"), ("direct", "auto"), ("mfma", "auto"), ("valu", "auto"), ("valu", "general")])
@@ -322,10 +367,11 @@ def test_run_dual_is_run_followed_by_lcequantize(shape, engine, kernel):
         frac = np.unpackbits(bits.cpu().numpy().view(np.uint8)).mean() * 32 * ((cout + 31) // 32) / cout
         assert 0.02 < frac < 0.98, frac                 # both signs occur (30 % of the multipliers are negative)
     spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1)
-    with pytest.raises(amd.LceHipError, match="float32"):
-        p8 = amd.Bconv2dPlan(_params(spec, amd.I8, out_scale=0.5))
-        p8.set_weights(w, mul, bias)
-        amd.check(amd.lib().lce_hip_bconv2d_run_dual(p8._h, xd.data_ptr(), y.data_ptr(), bits.data_ptr(), None))
+    with pytest.raises(amd.LceHipError, match="float32 or int8"):       # a bit-writing plan has no second output
+        thr = O.thresholds_converter(spec, mul, bias)
+        pb = amd.Bconv2dPlan(_params(spec, amd.BITPACKED))
+        pb.set_weights(w, None, None, thr)
+        amd.check(amd.lib().lce_hip_bconv2d_run_dual(pb._h, xd.data_ptr(), bits.data_ptr(), bits.data_ptr(), None))
 
 
 def test_run_host_pipelines_large_batches_and_binds_the_plan_to_its_device():

@@ -6,6 +6,8 @@ right before GPU minutes are spent."""
 import itertools
 import zlib
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -400,6 +402,60 @@ def test_mfma_second_output_is_the_lcequantize_of_the_float_output(engine, tile)
         assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
         assert np.array_equal(words, O.bitpack(want)), name
         assert 0.02 < ((words.view(np.uint32)[..., 0] & 1) == 1).mean() < 0.98
+
+
+@pytest.mark.parametrize("engine,tile,k", [("direct", (128, 256), 3), ("direct", (128, 128), 3), ("mfma", (256, 128), 3),
+                                          ("pointwise", (0, 0), 1)])
+@pytest.mark.parametrize("zp", [-128, -127, -3, 0, 1, 5, 127])
+def test_second_output_of_an_int8_layer_is_its_lcequantize(engine, tile, k, zp):
+    """lce_hip_bconv2d_run_dual on an int8 plan: bit = (q < out_zero_point), word for word what LceQuantize makes of
+    the int8 tensor (quantization.cc:76-114) -- computed from the value BEFORE the rounding against the planner's
+    threshold (int8_below_threshold).  The scale is chosen so that results land on and around the zero point,
+    ties included (multipliers are multiples of 1/2)."""
+    cout = 128
+    spec = O.ConvSpec(2, 9, 11, 64, k, k, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_NONE)
+    x, w, mul, bias = synth.conv_inputs(spec, 31 + zp, negative_mul_fraction=0.3)
+    mul = (np.sign(mul) * 0.5).astype(np.float32)
+    bias = np.zeros_like(bias)
+    scale = float(k * k * 4)                        # |y| up to ~ K/scale = 8 around zp; halves occur -> exact ties
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp, tile=tile, engine=engine,
+                          sign_words=words)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp)
+    assert np.array_equal(got, want), name
+    assert np.array_equal(words, O.bitpack(want, zp)), name
+    if -127 < zp < 127:
+        assert 0.02 < (want < zp).mean() < 0.98 and (want == zp).any()
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (96, 32)])
+def test_pointwise_second_output_of_a_float_layer(cin, cout):
+    spec = O.ConvSpec(3, 7, 9, cin, 1, 1, cout, activation=O.ACT_RELU)
+    x, w, mul, bias = synth.conv_inputs(spec, cin + cout, negative_mul_fraction=0.3)
+    bias = (bias - 10.0 * np.abs(mul)).astype(np.float32)
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="pointwise", sign_words=words)
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+    assert name.startswith("bconv2d_pointwise<"), name
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+    assert np.array_equal(words, O.bitpack(want)), name
+
+
+def test_int8_below_threshold_against_the_rounding():
+    """The planner's threshold T(zp): for EVERY float c in [-129, 128) sampled densely around each half-integer,
+    (round_sat_i8(c) < zp) == (c < T) -- round_sat_i8 being the kernels' own expression (checked against
+    saturate(roundf) for every float by test_round_sat_i8_every_float)."""
+    l = H.lib()
+    l.hostsim_int8_below_threshold.restype = C.c_float
+    for zp in (-200, -128, -127, -64, -1, 0, 1, 2, 63, 126, 127, 128, 300):
+        t = np.float32(l.hostsim_int8_below_threshold(C.c_int32(zp)))
+        centers = np.arange(-129.0, 128.5, 0.5, dtype=np.float32)
+        c = np.concatenate([centers, np.nextafter(centers, np.float32(np.inf)), np.nextafter(centers, np.float32(-np.inf)),
+                            np.float32([-0.0, 0.0, 1e-30, -1e-30, 126.99999, -127.99999])]).astype(np.float32)
+        sat = np.clip(c, np.float32(-128), np.float32(127))
+        q = np.trunc(sat + np.copysign(np.float32(0.49999997), sat)).astype(np.int32)
+        assert np.array_equal(q, np.clip(np.sign(c) * np.floor(np.abs(c.astype(np.float64)) + 0.5), -128, 127).astype(np.int32))
+        assert np.array_equal(q < zp, c < t), zp
 
 
 def test_mfma_engine_refuses_grouped():

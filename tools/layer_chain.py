@@ -48,8 +48,8 @@ class LayerChain:
             p.run(x, y)
 
     def run_chain(self, fused=True):
-        """The chain: output k is quantized into the input of layer k + 1 (float: sign bits from the same
-        epilogue when `fused`, else a separate LceQuantize pass; int8: LceQuantize at the output zero point)."""
+        """The chain: output k is quantized into the input of layer k + 1 -- by the convolution's own epilogue when
+        `fused` (float: sign bits; int8: q < output zero point), else by a separate LceQuantize pass."""
         amd = self.amd
         for k, p in enumerate(self.plans):
             x = self.bits[k - 1] if self.fed[k] else self.x[k]
@@ -59,6 +59,8 @@ class LayerChain:
                 else:
                     p.run(x, self.y[k])
                     amd.bitpack(self.y[k], out=self.bits[k])
+            elif fused:
+                p.run_dual(x, self.y[k], self.bits[k])       # int8 output + (q < zero point) bits from one epilogue
             else:
                 p.run(x, self.y[k])
                 amd.bitpack(self.y[k], self.quant[k][1], out=self.bits[k])
