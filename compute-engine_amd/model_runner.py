@@ -152,6 +152,7 @@ class Interpreter:
                     "only LCE custom ops run here; the model contains builtin operator %d %r"
                     % (op.builtin_code, op.custom_code))
         self._plans = {}   # (operator index, batch) -> Bconv2dPlan
+        self._fused = None  # LceBconv2d operator index -> LceQuantize consumers of its output (see _quantize_consumers)
 
     # ---- the reference Interpreter's properties (interpreter_base.py:34-72) -------------------
     def _props(self, ids):
@@ -197,13 +198,36 @@ class Interpreter:
             self._plans[key] = self.model.bconv2d_plan(op_index, batch, self._sem)
         return self._plans[key]
 
+    def _quantize_consumers(self):
+        """op index of an LceBconv2d with a float / int8 output -> the LceQuantize ops that read that output: the
+        convolution's epilogue writes their result as its second output (lce_hip_bconv2d_run_dual)."""
+        if self._fused is None:
+            ops = self.model.operators
+            self._fused = {}
+            for i, op in enumerate(ops):
+                if op.custom_code != "LceBconv2d" or self.model.tensors[op.outputs[0]].type not in (FLOAT32, INT8):
+                    continue
+                js = [j for j in range(i + 1, len(ops))
+                      if ops[j].custom_code == "LceQuantize" and ops[j].inputs[0] == op.outputs[0]]
+                if js:
+                    self._fused[i] = js
+        return self._fused
+
     def _run_ops(self, live, batch):
         """Runs the graph on device tensors; `live` maps tensor index -> CUDA tensor."""
         import torch
+        fused, done = self._quantize_consumers(), set()
         for i, op in enumerate(self.model.operators):
+            if i in done:
+                continue
             x = live[op.inputs[0]]
             out_t = self.model.tensors[op.outputs[0]]
-            if op.custom_code == "LceQuantize":      # quantization.cc:76-114
+            if i in fused:                           # LceBconv2d + the LceQuantize of its output, one pass
+                y, bits = self._plan(i, batch).run_dual(x)
+                for j in fused[i]:
+                    live[self.model.operators[j].outputs[0]] = bits
+                    done.add(j)
+            elif op.custom_code == "LceQuantize":    # quantization.cc:76-114
                 in_t = self.model.tensors[op.inputs[0]]
                 y = _amd.bitpack(x, in_t.zero_point if x.dtype == torch.int8 else 0)
             elif op.custom_code == "LceDequantize":  # quantization.cc:116-147

@@ -27,6 +27,8 @@ def test_interpreter_predict_matches_oracle_in_true_batches():
     got_i8, got_deq = it.predict(x)
     assert got_i8.shape == want_i8.shape and np.array_equal(got_i8, want_i8)
     assert np.array_equal(got_deq, want_deq)
+    # the float LceBconv2d and the LceQuantize of its output ran as ONE pass (second output of the epilogue)
+    assert it._quantize_consumers() == {1: [2]}
     # plans were made once per distinct batch size: 16 and the ragged 5
     assert sorted({b for (_, b) in it._plans}) == [5, 16]
     # the reference's contract (interpreter_base.py:74-95): sample by sample gives the same answer
