@@ -489,7 +489,6 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #ifndef LCE_ABL_NOBAR   // timing ablation (results are wrong): no barrier in the steady K-step
       block_barrier_keep_vm();
 #endif
-
       LCE_TL(1);
       LCE_TL(2);
     } else {
