@@ -347,6 +347,15 @@ def extra_measurements(amd, torch, spec, args, dev):
         extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sp1.binary_macs / s_, "kernel": kn,
                                                        **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_)}
 
+    # the north star's synthetic 224x224xC feature maps (3x3, C -> C, float output), 16 images = the pixel count of the
+    # 56x56 layers at batch 256
+    for c in (64, 128, 256):
+        spf = SL.Layer(batch=max(1, args.batch // 16), in_h=224, in_w=224, channels_in=c, filter_h=3, filter_w=3,
+                       channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
+        s_, kn, *_ = time_layer(amd, torch, spf, amd.F32, st, wu, 224 + c, dev)
+        extra[f"feature_map_224x224x{c}_f32_batch{spf.batch}"] = {"ms": s_ * 1e3, "bmac_per_s": spf.binary_macs / s_, "kernel": kn,
+                                                                 **hbm(spf.algorithmic_bytes(SL.DST_F32), s_)}
+
     # configs 3, 4 (one GPU's shard) and 5 as REAL stacks: every layer has its own plan, weights and
     # buffers, run back to back on one stream -- (a) the convolutions alone, each on its own input;
     # (b) the device-resident chain, each output quantized into the next layer's input by the same

@@ -56,33 +56,35 @@ typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const ui
                         const float*, const float*, const float*, void*, uint32_t*);
 
 // CORR = the optimized kernels' SAME-zero float correction in the epilogue (float output only)
-// DIRECT = LDS-resident input halo instead of the FP4 workspace (lce_kernels_mfma.h)
-template <int DST, bool CORR, bool DIRECT>
+// DIRECT = LDS-resident input halo instead of the FP4 workspace; T2D = its 2-D tiles for wide images (lce_kernels_mfma.h)
+template <int DST, bool CORR, bool DIRECT, bool T2D>
 mfma_fn mfma_by_tile(int bm, int bn) {
-  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR, DIRECT>;
-  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR, DIRECT>;
-  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR, DIRECT>;
-  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR, DIRECT>;
-  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR, DIRECT>;
-  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR, DIRECT>;
-  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR, DIRECT>;
+  constexpr int ST = DIRECT ? 3 : 4;
+  if (bm == 256 && bn == 256) return bconv2d_mfma<DST, 4, 2, 2, 4, CORR, DIRECT, ST, T2D>;
+  if (bm == 256 && bn == 128) return bconv2d_mfma<DST, 4, 2, 2, 2, CORR, DIRECT, ST, T2D>;
+  if (bm == 512 && bn == 64) return bconv2d_mfma<DST, 8, 1, 2, 2, CORR, DIRECT, ST, T2D>;
+  if (bm == 128 && bn == 256) return bconv2d_mfma<DST, 2, 2, 2, 4, CORR, DIRECT, ST, T2D>;
+  if (bm == 128 && bn == 128) return bconv2d_mfma<DST, 2, 2, 2, 2, CORR, DIRECT, ST, T2D>;
+  if (bm == 256 && bn == 64) return bconv2d_mfma<DST, 4, 1, 2, 2, CORR, DIRECT, ST, T2D>;
+  if (bm == 128 && bn == 64) return bconv2d_mfma<DST, 2, 1, 2, 2, CORR, DIRECT, ST, T2D>;
   return nullptr;
 }
 
-template <bool DIRECT>
+template <bool DIRECT, bool T2D>
 mfma_fn find_mfma_v(int dst, int bm, int bn, bool zero_pad_correction) {
   switch (dst) {
     case LCE_HIP_F32:
-      return zero_pad_correction ? mfma_by_tile<kDstFloat, true, DIRECT>(bm, bn)
-                                 : mfma_by_tile<kDstFloat, false, DIRECT>(bm, bn);
-    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false, DIRECT>(bm, bn);
-    default: return mfma_by_tile<kDstBitpacked, false, DIRECT>(bm, bn);
+      return zero_pad_correction ? mfma_by_tile<kDstFloat, true, DIRECT, T2D>(bm, bn)
+                                 : mfma_by_tile<kDstFloat, false, DIRECT, T2D>(bm, bn);
+    case LCE_HIP_I8: return mfma_by_tile<kDstInt8, false, DIRECT, T2D>(bm, bn);
+    default: return mfma_by_tile<kDstBitpacked, false, DIRECT, T2D>(bm, bn);
   }
 }
 
-inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false) {
-  return direct ? find_mfma_v<true>(dst, bm, bn, zero_pad_correction)
-                : find_mfma_v<false>(dst, bm, bn, zero_pad_correction);
+inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false, bool tile2d = false) {
+  if (direct && tile2d) return find_mfma_v<true, true>(dst, bm, bn, zero_pad_correction);
+  return direct ? find_mfma_v<true, false>(dst, bm, bn, zero_pad_correction)
+                : find_mfma_v<false, false>(dst, bm, bn, zero_pad_correction);
 }
 
 typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, const float*, const float*, const float*, void*, uint32_t*);

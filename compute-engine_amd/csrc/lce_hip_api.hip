@@ -523,7 +523,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       sign_fused = true;   // (also when there is none to write)
     } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
-                             h.use_direct);
+                             h.use_direct, h.use_direct && h.tile_tx > 0);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
       const int bm = h.mfma.bm(), bn = h.mfma.bn();

@@ -79,7 +79,7 @@ struct MfmaArgs {
   int32_t QG;              // 16-byte groups of input words per pixel = ceil(CPW / 4)
   int32_t IPT;             // whole images per tile (> 1 only when OH*OW <= BM / 2; then TPI == 1)
   int32_t B;               // images of this launch
-  int32_t HPIX;            // halo pixels per image = halo_rows * Wp
+  int32_t HPIX;            // halo pixels per image = halo_rows * (strip tiles: Wp; 2-D tiles: Wh)
   int32_t f32_wide;        // float epilogue may transpose the WN tiles of a row block together
   int32_t i8_wide;         // int8 epilogue may use WN*4 KiB of LDS scratch per wave (16-byte row stores)
   int32_t noclamp;         // the output transform's clamp is the identity on [0, 2*K_bt] (activation NONE)
@@ -90,6 +90,12 @@ struct MfmaArgs {
   // slice [g*Cin_g, (g+1)*Cin_g) of the same pixels; its K loop covers the KCH 64-channel chunks that
   // contain the slice, starting at chunk (g*Cwg)/2 (weights outside the slice are FP4 zeros)
   FastDiv div_npg;
+  // 2-D tiles of the direct variant (bconv2d_mfma<..., TILE2D>; wide images, where a strip of BM consecutive pixels
+  // would stage whole image rows): TH = BM/32 output rows x 32 output columns, TX of them across the image,
+  // TPI = TX * ceil(OH / TH); the halo is the tile's own neighbourhood, Wh = 31 * SW + effective filter width wide.
+  // (Kept at the end: the strip variant's kernel-argument loads stay as they were.)
+  int32_t Wh, TX;
+  FastDiv div_wh, div_tx;
 };
 
 

@@ -171,7 +171,7 @@ struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
 
 template <int DST, int WGM, int WGN, int WM, int WN, bool CORR = false, bool DIRECT = false,
-          int STAGES = DIRECT ? 3 : 4>
+          int STAGES = DIRECT ? 3 : 4, bool TILE2D = false>
 LCE_KERNEL void __launch_bounds__(64 * WGM * WGN, 2)
 bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
              const uint8_t* __restrict__ wq, const float* __restrict__ mul,
@@ -216,6 +216,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   // GEMM variant: tile = BM consecutive pixels of the whole batch.  Direct variant: tile =
   // BM consecutive pixels of ONE image (the last tile of an image is partial).
   int m0 = bx * BM, m_end = A.M, p0 = 0, img = 0;
+  int tile_oy0 = 0, tile_ox0 = 0;          // 2-D tiles (TILE2D; G.TX > 0): first output row / column of the tile
+  constexpr bool tile2d = TILE2D;
+  static_assert(!TILE2D || DIRECT, "2-D tiles belong to the direct variant");
   if constexpr (DIRECT) {
     if (G.IPT > 1) {                       // small images: IPT whole images per tile
       img = bx * G.IPT;
@@ -223,11 +226,34 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       m_end = (img + G.IPT < G.B ? img + G.IPT : G.B) * G.OHOW;
     } else {
       img = (int)fastdiv((uint32_t)bx, G.div_tpi);
-      p0 = (bx - img * G.TPI) * BM;
+      const int t = bx - img * G.TPI;
+      if constexpr (TILE2D) {              // wide images: BM/32 output rows x 32 output columns
+        const int ty = (int)fastdiv((uint32_t)t, G.div_tx);
+        tile_oy0 = ty * (BM / 32);
+        tile_ox0 = (t - ty * G.TX) * 32;
+        p0 = tile_oy0 * A.OW;              // (only its row, oy0 below, is used)
+      } else {
+        p0 = t * BM;
+      }
       m0 = img * G.OHOW + p0;
       m_end = (img + 1) * G.OHOW;
     }
   }
+  // The tile's 32-row blocks (one per MFMA row tile of this wave): first output pixel and how many of the 32 are
+  // real.  Strip tiles: consecutive pixels up to the end of the image(s); 2-D tiles: one image-row segment each.
+  auto blk_m = [&](int i) LCE_LAMBDA_INLINE -> int {
+    if constexpr (TILE2D) return img * G.OHOW + (tile_oy0 + wm * WM + i) * A.OW + tile_ox0;
+    else return m0 + (wm * WM + i) * 32;
+  };
+  auto blk_valid = [&](int i) LCE_LAMBDA_INLINE -> int {
+    if constexpr (TILE2D) {
+      const int left = A.OW - tile_ox0;
+      return tile_oy0 + wm * WM + i < A.OH ? (left < 32 ? left : 32) : 0;
+    } else {
+      const int left = m_end - (m0 + (wm * WM + i) * 32);
+      return left < 0 ? 0 : (left < 32 ? left : 32);
+    }
+  };
   const int n0 = block_idx_y() * BN;
   // grouped convolution: first 64-channel chunk of this block's group (0 when groups == 1: Npg == N > n0)
   const int chunk0 = ((int)fastdiv((uint32_t)n0, G.div_npg) * A.Cwg) >> 1;
@@ -354,8 +380,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
   uint32_t a_cur = (uint32_t)chunk0 * 32u;   // byte offset of the K-step whose fragments are read next
   int c_kc = 0, c_fx = 0;
   if constexpr (DIRECT) {
-    const int oy0 = (int)fastdiv((uint32_t)p0, A.div_ow);
-    const int iy_first = oy0 * A.SH - G.PH;
+    const int oy0 = tile2d ? tile_oy0 : (int)fastdiv((uint32_t)p0, A.div_ow);
+    const int iy_first = oy0 * A.SH - G.PH, ix_first = tile_ox0 * A.SW - G.PW;   // input pixel of halo slot (0, 0)
+    const int halo_w = TILE2D ? G.Wh : G.Wp;                                      // halo pixels per slot row
     const uint32_t img_bytes = (uint32_t)G.H * (uint32_t)G.W * (uint32_t)G.Cw * 4u;
     // the rows come through a buffer resource over [first image of the tile, end of the launch's
     // input): a tap outside the image (or an image past the batch) is steered to an out-of-range
@@ -384,8 +411,8 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           const int c0 = (e - pix * G.QG) * 4;
           const int li = (int)fastdiv((uint32_t)pix, G.div_hpix);  // image of the tile (0 unless IPT > 1)
           const int ipix = pix - li * G.HPIX;
-          const int slot = (int)fastdiv((uint32_t)ipix, G.div_wp);
-          const int iy = iy_first + slot, ix = ipix - slot * G.Wp - G.PW;
+          const int slot = (int)fastdiv((uint32_t)ipix, TILE2D ? G.div_wh : G.div_wp);
+          const int iy = iy_first + slot, ix = ipix - slot * halo_w + ix_first;
           const bool inside = e < items && (uint32_t)iy < (uint32_t)G.H && (uint32_t)ix < (uint32_t)G.W && img + li < G.B;
           pixv[k] = e < items ? pix : -1; c0v[k] = c0; inv[k] = inside;
           const uint32_t off = (uint32_t)li * img_bytes + (uint32_t)((iy * G.W + ix) * G.Cw + c0) * 4u;
@@ -440,12 +467,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       const int oy = (int)fastdiv((uint32_t)p, A.div_ow);
       const int ox = p - oy * A.OW;
       a_base[i] = (uint32_t)((li * G.HPIX + (oy - oy0) * A.SH * G.Wp + ox * A.SW) * G.PS + half * 16);
+      if constexpr (TILE2D)   // row block rb of the tile = tile row rb, this lane's pixel = column l31 (past the image: unused, in range)
+        a_base[i] = (uint32_t)(((wm * WM + i) * A.SH * G.Wh + l31 * A.SW) * G.PS + half * 16);
     }
   }
   LCE_PH(1);
   constexpr uint32_t kAStep = 32u;               // bytes of halo per K-step and pixel: 64 FP4 codes
   const uint32_t c_step_fx = (uint32_t)(A.DW * G.PS) - (uint32_t)G.KCH * kAStep;
-  const uint32_t c_step_fy = (uint32_t)((A.DH * G.Wp - A.KW * A.DW) * G.PS);
+  const uint32_t c_step_fy = (uint32_t)((A.DH * (TILE2D ? G.Wh : G.Wp) - A.KW * A.DW) * G.PS);
 
   // A-operand cursor of the direct variants: advances by one K-step (branch-free, as in fill())
   auto advance_a = [&]() LCE_LAMBDA_INLINE {
@@ -600,9 +629,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
     gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
     // lane p (< 32) now owns pixel row p of the tile: WN consecutive output words
-    const int m = m0 + (wm * WM + i) * 32 + lane;
+    const int m = blk_m(i) + lane;
     const int w0 = (n0 + wn * WN * 32) >> 5;
-    if (lane < 32 && m < m_end) {
+    if (TILE2D ? lane < blk_valid(i) : (lane < 32 && m < m_end)) {
       uint32_t* o = dst_words + (size_t)m * (size_t)A.Wout + (size_t)w0;
       if (WN == 4 && w0 + 4 <= A.Wout && (A.Wout & 3) == 0) {
         u32x4 v = {words[0], words[WN > 1 ? 1 : 0], words[WN > 2 ? 2 : 0], words[WN > 3 ? 3 : 0]};
@@ -637,14 +666,18 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     constexpr int LPR = RW / 4, RPI = 64 / LPR;                  // lanes per row (16 bytes each), rows per store instruction
     constexpr int NK = 32 / RPI, KB = NK < 8 ? NK : 8;           // store instructions per row block, in batches of KB
     float* scratch = (float*)(lds0 + wave * (WN * 4096));
-    const int tile_rows = m_end - m0 < BM ? m_end - m0 : BM;
     const uint32_t row_bytes = (uint32_t)A.N * 4u;
-    const rsrc_t ro = make_rsrc((float*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows * row_bytes);
+    // strip tiles: ONE resource over the tile's real rows (rows past it fall off its end); 2-D tiles: one per 32-row
+    // block (an image-row segment each), made inside the loop
+    const int tile_rows = m_end - m0 < BM ? m_end - m0 : BM;
+    const rsrc_t ro_tile = make_rsrc((float*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows * row_bytes);
     const int g = lane % LPR;
     const int n = n0 + wn * RW + g * 4;
     const uint32_t lane_off = n < A.N ? (uint32_t)(lane / LPR) * row_bytes + (uint32_t)n * 4u : kOobOffset;   // N % 4 == 0
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+      const rsrc_t ro = TILE2D ? make_rsrc((float*)out + (size_t)blk_m(i) * (size_t)A.N, (uint32_t)blk_valid(i) * row_bytes) : ro_tile;
+      const uint32_t blk_off = TILE2D ? 0u : (uint32_t)((wm * WM + i) * 32) * row_bytes;
       // the transform in place (the accumulators become the outputs) ...
       if (G.noclamp) {
 #pragma unroll
@@ -676,7 +709,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #ifdef LCE_ABL_NOSTORE   // timing ablation (results are wrong): the float epilogue without its global stores
           if (y[k][0] == 1234.5678f)
 #endif
-          buf_store_streaming(ro, lane_off + (uint32_t)((wm * WM + i) * 32 + (k0 + k) * RPI) * row_bytes, y[k]);
+          buf_store_streaming(ro, lane_off + blk_off + (uint32_t)((k0 + k) * RPI) * row_bytes, y[k]);
           // pace the burst: 128 KiB per block pushed out back to back fills the CU's memory pipeline and
           // the co-resident block's weight DMAs queue behind it (its K loop 18.7k -> 16.4k cycles with the
           // pause, L0 float -2.5 %, tools/phases.py); the sleeping wave also leaves its issue slots to it
@@ -697,12 +730,14 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     float* scratch = (float*)(lds0 + wave * (WN * 4096));
     // stores through a buffer resource over the tile's real rows (no per-store predicates, as in the float path)
     const int tile_rows8 = m_end - m0 < BM ? m_end - m0 : BM;
-    const rsrc_t ro8 = make_rsrc((int8_t*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows8 * (uint32_t)A.N);
+    const rsrc_t ro8_tile = make_rsrc((int8_t*)out + (size_t)m0 * (size_t)A.N, (uint32_t)tile_rows8 * (uint32_t)A.N);
     const uint32_t lane_off8 = n0 + wn * RW + (lane % GPR) * 16 < A.N
                                    ? (uint32_t)(lane / GPR) * (uint32_t)A.N + (uint32_t)(n0 + wn * RW + (lane % GPR) * 16)
                                    : kOobOffset;                  // N % 16 == 0: whole group or nothing
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+      const rsrc_t ro8 = TILE2D ? make_rsrc((int8_t*)out + (size_t)blk_m(i) * (size_t)A.N, (uint32_t)blk_valid(i) * (uint32_t)A.N) : ro8_tile;
+      const uint32_t blk_off8 = TILE2D ? 0u : (uint32_t)((wm * WM + i) * 32) * (uint32_t)A.N;
       if (sign_words != nullptr) {
         // with a second output the transform happens in place first (the accumulators become the values the
         // rounding will see), then their "below the zero point" bits, then the transpose
@@ -745,7 +780,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           for (int q = 0; q < 4; ++q)
             pk[q] = pack4_u8(round_sat_i8(y[k][q][0]), round_sat_i8(y[k][q][1]), round_sat_i8(y[k][q][2]),
                              round_sat_i8(y[k][q][3]));
-          buf_store(ro8, lane_off8 + (uint32_t)((wm * WM + i) * 32 + (k0 + k) * RPI) * (uint32_t)A.N, pk);
+          buf_store(ro8, lane_off8 + blk_off8 + (uint32_t)((k0 + k) * RPI) * (uint32_t)A.N, pk);
         }
       }
       wave_lds_fence();
@@ -769,10 +804,10 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int row = trow + 8 * k;
-          const int m = m0 + (wm * WM + i) * 32 + row;
+          const int m = blk_m(i) + row;
           const int n = nbase + tcol;
           f32x4 y = *(const f32x4*)(scratch + row * 32 + tcol);
-          if (m < m_end && n < A.N) {
+          if ((TILE2D ? row < blk_valid(i) : m < m_end) && n < A.N) {
             if constexpr (DST == kDstFloat) {
               if constexpr (CORR) {                             // optimized_bgemm.h:153-177
                 const uint32_t rw_ = fastdiv((uint32_t)m, A.div_ow);

@@ -402,7 +402,7 @@ static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
 // fits LDS.  Images of at most BM/2 pixels are tiled IPT whole images at a time, larger ones
 // in BM-pixel pieces of ONE image.
 bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
-                     int* ipt, int lds_budget) {
+                     int* ipt, int lds_budget, int* tile_tx, int* halo_w) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!mfma_supported(p)) return false;
   const int cpad = ceil_div(d.channels_in, 64) * 64;
@@ -423,13 +423,37 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
     const int rows_out = std::min(p.out_h, (bm + p.out_w - 2) / p.out_w + 1);
     rows = (int64_t)(rows_out - 1) * d.stride_height + (int64_t)(d.filter_height - 1) * d.dilation_height + 1;
   }
-  const int64_t bytes = ((int64_t)images * rows * wp * stride + 1023) / 1024 * 1024;
+  int64_t bytes = ((int64_t)images * rows * wp * stride + 1023) / 1024 * 1024;
+  int tx = 0;
+  int64_t wh = wp;
+  // Wide images: a strip of bm consecutive pixels is a sliver of one or two rows whose halo spans their whole width
+  // (224-wide, 256 pixels: 4 rows x 226 columns staged for 256 outputs).  2-D tiles of bm/32 rows x 32 columns stage
+  // (bm/32 - 1) * SH + eKH rows x 31 * SW + eKW columns instead.  Taken when that is at most 0.7 of the strip's halo
+  // and pads the image by no more than 3 % beyond what strips do (56-wide: 64 columns for 56 -- stays with strips).
+  if (ohow * 2 > bm && tile_tx != nullptr) {
+    const int th = bm / 32, tw = 32;
+    const int64_t rows2 = (int64_t)(th - 1) * d.stride_height + (int64_t)(d.filter_height - 1) * d.dilation_height + 1;
+    const int64_t wh2 = (int64_t)(tw - 1) * d.stride_width + (int64_t)(d.filter_width - 1) * d.dilation_width + 1;
+    const int64_t bytes2 = (rows2 * wh2 * stride + 1023) / 1024 * 1024;
+    const int ty_n = ceil_div(p.out_h, th), tx_n = ceil_div(p.out_w, tw);
+    const double pad_strip = (double)ceil_div(ohow, bm) * bm / ohow, pad_2d = (double)ty_n * tx_n * bm / ohow;
+    const bool strip_fits = bytes + ring <= lds_budget;
+    if (bytes2 + ring <= lds_budget && pad_2d <= pad_strip + 0.03 && (!strip_fits || bytes2 * 10 <= bytes * 7)) {
+      tx = tx_n;
+      rows = rows2;
+      wh = wh2;
+      bytes = bytes2;
+      *tpi = ty_n * tx_n;
+    }
+  }
   if (bytes + ring > lds_budget) return false;
-  *tpi = ohow * 2 <= bm ? 1 : ceil_div(ohow, bm);
+  if (tx == 0) *tpi = ohow * 2 <= bm ? 1 : ceil_div(ohow, bm);
   *halo_rows = (int)rows;
   *ps = (int)stride;
   *halo_bytes = (int)bytes;
   *ipt = images;
+  if (tile_tx) *tile_tx = tx;
+  if (halo_w) *halo_w = (int)wh;
   return true;
 }
 
@@ -452,11 +476,12 @@ bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out) {
   Cand cand[2];
   int n = 0;
   for (int bm : {256, 128}) {
+    if (bm == 256 && bn == 256) continue;   // the 8-wave 256x256 block loses to two 128x256 blocks per CU on every layer measured
     const MfmaCfg* c = mfma_cfg_by_tile(bm, bn);
-    int tpi, rows, ps, bytes, ipt;
+    int tpi, rows, ps, bytes, ipt, ttx, hw;
     // two blocks per CU (80 KiB each) is where the variant pays: with one, nothing overlaps a
     // block's halo expansion (measured: 28x28x1024 at 138 KiB loses to the workspace GEMM)
-    if (!c || !direct_geometry(p, *c, &tpi, &rows, &ps, &bytes, &ipt, kDirectLdsAuto)) continue;
+    if (!c || !direct_geometry(p, *c, &tpi, &rows, &ps, &bytes, &ipt, kDirectLdsAuto, &ttx, &hw)) continue;
     // rows of a tile that are real pixels
     const double padded = ohow * 2 <= bm ? (double)bm / ((double)ipt * ohow) : (double)tpi * bm / (double)ohow;
     if (padded > 1.0 / 0.7) continue;
@@ -509,7 +534,10 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   if (p.use_direct) {
     G.TPI = p.tpi; G.OHOW = p.out_h * p.out_w; G.halo_rows = p.halo_rows; G.PS = p.ps;
     G.halo_bytes = p.halo_bytes; G.QG = (G.CPW + 3) / 4;
-    G.IPT = p.ipt; G.B = batch_chunk; G.HPIX = p.halo_rows * p.wp;
+    G.Wh = p.halo_w; G.TX = p.tile_tx;
+    G.IPT = p.ipt; G.B = batch_chunk; G.HPIX = p.halo_rows * p.halo_w;
+    G.div_wh = make_fastdiv((uint32_t)G.Wh);
+    G.div_tx = make_fastdiv((uint32_t)(G.TX > 0 ? G.TX : 1));
     G.div_tpi = make_fastdiv((uint32_t)G.TPI);
     G.div_qg = make_fastdiv((uint32_t)G.QG);
     G.div_ohow = make_fastdiv((uint32_t)G.OHOW);
@@ -571,13 +599,15 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     if (repack && p.have_weights) pack_for_mfma(p);
     if (direct) {
       if (!direct_geometry(p, want, &p.tpi, &p.halo_rows, &p.ps, &p.halo_bytes, &p.ipt,
-                           p.engine_pref == 3 ? kDirectLdsMax : kDirectLdsAuto))
+                           p.engine_pref == 3 ? kDirectLdsMax : kDirectLdsAuto, &p.tile_tx, &p.halo_w))
         return "bconv2d: the direct matrix-core variant cannot hold this tile's input halo in LDS";
       p.use_direct = true;
     }
     char nm[96];
-    snprintf(nm, sizeof nm, "bconv2d_mfma%s<%s,%dx%d>", p.use_direct ? "_direct" : "",
-             d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", want.bm(), want.bn());
+    if (!direct) { p.tile_tx = 0; p.halo_w = p.wp; }
+    snprintf(nm, sizeof nm, "bconv2d_mfma%s<%s,%dx%d>%s", p.use_direct ? "_direct" : "",
+             d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", want.bm(), want.bn(),
+             p.use_direct && p.tile_tx > 0 ? "/2d" : "");
     p.kernel_name = nm;
     // 1x1 stride-1 layers: the streaming kernel on top of the same weight image (the block GEMM stays the
     // fallback for output pointers that are not 16-byte aligned)

@@ -70,6 +70,7 @@ struct HostPlan {
                                            // 4 pointwise (1x1 streaming kernel, lce_kernels_pointwise.h)
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
+  int tile_tx = 0, halo_w = 0;             // ... 2-D tiles: tiles across the image (0 = strip tiles), halo width in pixels
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   int epilogue_pref = 0;                   // float/int8 epilogue: 0 auto, 1 per-tile transpose, 2 joint transpose
   bool use_mfma = false;
@@ -117,7 +118,7 @@ bool choose_direct_cfg(const HostPlan& p, MfmaCfg* out);
 constexpr int kDirectLdsMax = 160 * 1024;   // one block per CU
 constexpr int kDirectLdsAuto = 80 * 1024;   // two blocks per CU: what the auto rule requires
 bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_rows, int* ps, int* halo_bytes,
-                     int* ipt, int lds_budget);
+                     int* ipt, int lds_budget, int* tile_tx = nullptr, int* halo_w = nullptr);
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
 // 1x1 streaming kernel: can it run this convolution (fills nc / nj), and its launch constants.
 bool pointwise_supported(const HostPlan& p, int* nc, int* nj);

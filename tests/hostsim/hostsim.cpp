@@ -137,7 +137,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       });
     } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
-                             h.use_direct);
+                             h.use_direct, h.use_direct && h.tile_tx > 0);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const MfmaArgs G = make_mfma_args(h, nb);
       std::vector<uint8_t> wq = h.wq;

@@ -286,6 +286,34 @@ def test_conv_grouped_on_the_matrix_cores(cin, cout, groups, engine):
         assert all(n.startswith("bconv2d_mfma") for n in names), names
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 224, 64, 64, 3, 1, "ONE"), (2, 40, 96, 64, 96, 3, 1, "SAME"), (1, 64, 128, 128, 64, 3, 2, "ONE"),
+                                   (1, 250, 64, 64, 33, 3, 1, "VALID"), (1, 48, 160, 64, 64, 5, 1, "ONE"), (2, 224, 224, 64, 64, 3, 1, "ONE"),
+                                   (1, 224, 224, 256, 256, 3, 1, "ONE")],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_direct_variant_2d_tiles_on_wide_images(shape):
+    """Wide images (the north star's 224x224xC feature maps): the direct variant tiles the output in BM/32 rows x 32
+    columns, the halo being the tile's own neighbourhood instead of whole image rows.  All three output types against
+    the oracle, partial tiles at the right / bottom edge, strides, a 5x5 filter, exact SAME-zero padding; the planner
+    picks the variant by itself."""
+    b, h, w_, cin, cout, k, st, pad = shape
+    padding, pv = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, k, k, cout, 1, st, st, 1, 1, padding, pv, O.ACT_RELU if pad == "VALID" else O.ACT_NONE,
+                      O.SEM_REFERENCE)
+    names = _check_all_dst(spec, h + w_ + cin, engine="auto")
+    assert all(n.startswith("bconv2d_mfma_direct<") and n.endswith("/2d") for n in names), names
+    # the float layer's second output from the same tiles
+    x, w, mul, bias = synth.conv_inputs(spec, h, negative_mul_fraction=0.3)
+    bias = (bias - 0.45 * k * k * cin * np.abs(mul)).astype(np.float32)
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
+    torch.cuda.synchronize()
+    assert plan.kernel_name().endswith("/2d")
+    assert torch.equal(bits, amd.bitpack(y))
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=8)
+    assert np.array_equal(y.cpu().numpy().view(np.int32), want.view(np.int32))
+
+
 @pytest.mark.parametrize("engine,kernel,k", [("auto", "auto", 3), ("direct", "auto", 3), ("mfma", "auto", 3), ("valu", "auto", 3),
                                              ("valu", "general", 3), ("auto", "auto", 1), ("direct", "auto", 1)])
 @pytest.mark.parametrize("zp", [-128, -5, 0, 3, 127])

@@ -458,6 +458,39 @@ def test_int8_below_threshold_against_the_rounding():
         assert np.array_equal(q < zp, c < t), zp
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 224, 64, 64, 3, 1, "ONE"), (2, 40, 96, 64, 96, 3, 1, "SAME"), (1, 64, 128, 128, 64, 3, 2, "ONE"),
+                                   (1, 250, 64, 64, 33, 3, 1, "VALID"), (1, 48, 160, 64, 64, 5, 1, "ONE"), (1, 24, 192, 256, 64, 1, 1, "VALID")],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_mfma_direct_variant_2d_tiles_on_wide_images(shape):
+    """Wide images: the direct variant tiles the output in BM/32 rows x 32 columns instead of row-major strips (the halo is
+    the tile's own neighbourhood, not whole image rows).  Partial tiles at the right and bottom edges, strides, a 5x5
+    filter, exact SAME-zero padding, all three output types, and the float layer's second output."""
+    b, h, w_, cin, cout, k, st, pad = shape
+    padding, pv = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, k, k, cout, 1, st, st, 1, 1, padding, pv, O.ACT_RELU if pad == "VALID" else O.ACT_NONE,
+                      O.SEM_REFERENCE)
+    names = _run_all_dst_mfma(spec, seed=h + w_ + cin, engine="direct")
+    assert all(n.startswith("bconv2d_mfma_direct<") and n.endswith("/2d") for n in names), names
+    x, w, mul, bias = synth.conv_inputs(spec, h, negative_mul_fraction=0.3)
+    bias = (bias - 0.45 * spec.filter_h * spec.filter_w * cin * np.abs(mul)).astype(np.float32)
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="direct", sign_words=words)
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+    if cout % 4 == 0:
+        assert np.array_equal(words, O.bitpack(want)), name
+
+
+def test_direct_variant_keeps_strips_where_2d_tiles_would_pad():
+    for h, w_ in ((56, 56), (28, 28), (30, 224), (112, 112)):
+        spec = O.ConvSpec(1, h, w_, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1)
+        x, w, mul, bias = synth.conv_inputs(spec, 1)
+        if h * w_ > 4000:
+            continue   # (planner rule only; the big ones are not run here)
+        _, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="direct")
+        assert not name.endswith("/2d"), name
+
+
 def test_mfma_engine_refuses_grouped():
     spec = O.ConvSpec(1, 6, 6, 128, 3, 3, 64, groups=2)
     x, w, mul, bias = synth.conv_inputs(spec, 1)
