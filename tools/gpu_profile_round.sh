@@ -18,7 +18,7 @@ import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
     n=r["Name"].split("(")[0].replace("void ","")
     if "at::native" in n or "rocclr" in n or "elementwise" in n: continue
-    print("%-52s calls %5s avg %9.2f us  min %9.2f  max %9.2f  total %10.1f us" % (n[:52], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3, float(r["TotalDurationNs"])/1e3))
+    print("%-64s calls %5s avg %9.2f us  min %9.2f  max %9.2f  total %10.1f us" % (n[:64], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3, float(r["TotalDurationNs"])/1e3))
 PY
 }
 # 1 -------------------------------------------------------------------------------------------------
