@@ -5,6 +5,7 @@ import importlib
 import json
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +24,8 @@ dsts = [("f32", amd.F32, SL.DST_F32), ("i8", amd.I8, SL.DST_I8), ("bp", amd.BITP
 tiles = ([] if os.environ.get("SWEEP_MATRIX_ONLY") else ["4x16", "2x32", "2x16", "1x32", "1x16"]) + [
          "m256x256", "m256x128", "m512x64", "m128x256", "m128x128", "m256x64", "m128x64",
          "d256x256", "d256x128", "d512x64", "d128x256", "d128x128", "d256x64", "d128x64"]
+if os.environ.get("SWEEP_PREFIX"):   # e.g. "d": the direct variant's tiles only
+    tiles = [t for t in tiles if t.startswith(os.environ["SWEEP_PREFIX"])]
 only = set(sys.argv[1:])
 for lname, hw, c in layers:
     spec = SL.Layer(batch=B, in_h=hw, in_w=hw, channels_in=c, filter_h=K, filter_w=K, channels_out=c,
@@ -50,9 +53,12 @@ for lname, hw, c in layers:
             except Exception:
                 continue
             out = plan.run(x)
-            for _ in range(2):
-                plan.run(x, out)
             torch.cuda.synchronize()
+            _t = time.perf_counter()   # untimed clock spin-up, as bench.py
+            while (time.perf_counter() - _t) * 1e3 < float(os.environ.get("LCE_SPINUP_MS", "40")):
+                for _ in range(16):
+                    plan.run(x, out)
+                torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(steps):
