@@ -426,6 +426,14 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key, const char* value) {
   if (!plan || !key || !value) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: null argument");
   lce::HostPlan& h = plan->host;
+  if (!strcmp(key, "tile2d")) {   // tuning aid for the direct variant: auto | on | off
+    if (!strcmp(value, "auto")) h.tile2d_pref = 0;
+    else if (!strcmp(value, "on")) h.tile2d_pref = 1;
+    else if (!strcmp(value, "off")) h.tile2d_pref = 2;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: tile2d must be auto|on|off");
+    plan->selected_for_pixels = -1;
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "pointwise_tiles")) {   // tuning aid for the 1x1 streaming kernel: tiles per wave
     h.pw_tiles_pref = atoi(value);
     return LCE_HIP_OK;

@@ -438,7 +438,8 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
     const int ty_n = ceil_div(p.out_h, th), tx_n = ceil_div(p.out_w, tw);
     const double pad_strip = (double)ceil_div(ohow, bm) * bm / ohow, pad_2d = (double)ty_n * tx_n * bm / ohow;
     const bool strip_fits = bytes + ring <= lds_budget;
-    if (bytes2 + ring <= lds_budget && pad_2d <= pad_strip + 0.03 && (!strip_fits || bytes2 * 10 <= bytes * 7)) {
+    const bool rule = pad_2d <= pad_strip + 0.03 && (!strip_fits || bytes2 * 10 <= bytes * 7);
+    if (bytes2 + ring <= lds_budget && p.tile2d_pref != 2 && (rule || p.tile2d_pref == 1)) {
       tx = tx_n;
       rows = rows2;
       wh = wh2;

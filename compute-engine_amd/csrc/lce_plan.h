@@ -71,6 +71,7 @@ struct HostPlan {
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int tile_tx = 0, halo_w = 0;             // ... 2-D tiles: tiles across the image (0 = strip tiles), halo width in pixels
+  int tile2d_pref = 0;                     // tuning aid: 0 auto, 1 always when it fits, 2 never
   int phase = 0;                           // profiling aid: 0 all, 1 expand_fp4 only, 2 GEMM only
   int epilogue_pref = 0;                   // float/int8 epilogue: 0 auto, 1 per-tile transpose, 2 joint transpose
   bool use_mfma = false;

@@ -177,7 +177,9 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *                       (pixels x channels; with engine = mfma or direct);
  *   "phase"  = "all" | "expand" | "gemm"   (engine = mfma, profiling aid: run one of its two kernels);
  *   "epilogue" = "auto" | "tile" | "wide"   (matrix-core float / int8 epilogue: per-tile or joint transpose);
- *   "pointwise_tiles" = "0" (auto) | "1".."8"   (pointwise kernel: 32-pixel tiles per wave). */
+ *   "pointwise_tiles" = "0" (auto) | "1".."8"   (pointwise kernel: 32-pixel tiles per wave);
+ *   "tile2d" = "auto" | "on" | "off"   (direct variant: 2-D tiles of BM/32 rows x 32 columns instead of row-major strips;
+ *              auto takes them on wide images, where they stage <= 0.7 of the strip's halo at <= 3 % more padding). */
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key,
                                                const char* value);
 /* Name of the kernel variant the next run will launch (static string owned by the plan). */
