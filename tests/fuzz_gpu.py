@@ -1,5 +1,8 @@
 import importlib, sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
+"""Extended randomized parity run on the GPU (not collected by pytest; `python tests/fuzz_gpu.py`): 360 specs -- random
+geometry, wide images, 1x1 layers -- every output type and the second output against the oracle."""
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import oracle_lib as O, synth
 import test_gpu_parity as T
