@@ -43,6 +43,13 @@ for _ in range(5):
     plan.run(x, o)
 torch.cuda.synchronize()
 lib = amd.lib()
+# untimed clock spin-up (as bench.py): the stamped launch below runs at the warmed-up clock unless LCE_SPINUP_MS=0
+import time  # noqa: E402
+_t = time.perf_counter()
+while (time.perf_counter() - _t) * 1e3 < float(os.environ.get("LCE_SPINUP_MS", "40")):
+    for _ in range(16):
+        plan.run(x, o)
+    torch.cuda.synchronize()
 assert lib.lce_hip_debug_clear_phases() == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
