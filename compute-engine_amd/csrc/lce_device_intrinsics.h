@@ -120,6 +120,12 @@ LCE_DEVICE f32x2 mul_then_add2(f32x2 a, float b, float c) {
 }
 LCE_DEVICE f32x2 add2(f32x2 a, f32x2 b) { return a + b; }   // v_pk_add_f32
 #endif
+// ... with the per-channel constants already duplicated into register pairs
+LCE_DEVICE f32x2 mul_then_add_pk(f32x2 a, f32x2 b, f32x2 c) {
+#pragma clang fp contract(off)
+  const f32x2 p = a * b;
+  return p + c;
+}
 // A use of `v` that generates nothing: keeps its registers allocated (and unmodified) up to this point.
 LCE_DEVICE void keep_alive(const u32x4& v) { asm volatile("" ::"v"(v)); }
 
@@ -214,6 +220,12 @@ LCE_DEVICE void wait_vmcnt() {
 // accesses go through differently-typed pointers: wait for the LDS queue, and stop the
 // compiler from moving LDS accesses across.
 LCE_DEVICE void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Orders a wave's own LDS accesses in PROGRAM order without waiting: the LDS executes one wave's DS operations in
+// issue order, so a later read sees an earlier write of another lane of the same wave; only the compiler must be
+// stopped from moving accesses across.  (The host simulation, whose lanes are threads, synchronises here.)
+LCE_DEVICE void wave_lds_order() { asm volatile("" ::: "memory"); }
+// Nothing is scheduled across this point (the stream kernel places its fillers K-step by K-step).
+LCE_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // s_sleep N: the wave gives up its issue slots for ~64*N cycles
 template <int N>
 LCE_DEVICE void yield_issue_slots() { __builtin_amdgcn_s_sleep(N); }
@@ -221,6 +233,22 @@ LCE_DEVICE void yield_issue_slots() { __builtin_amdgcn_s_sleep(N); }
 // be sunk below (hipcc otherwise moves the register-only MFMAs of a K-step past the NEXT
 // step's barrier, which serialises LDS latency and matrix work).
 LCE_DEVICE void pin(f32x16& c) { asm volatile("" : "+v"(c)); }
+// Register-class hints for operands that stay resident for the life of a wave (the stream kernel's filter bank):
+// the MFMA A/B operands may be AGPRs on gfx950, and a value that passes through an "a"-constrained asm lives in the
+// accumulator half of the unified register file from then on -- without it the allocator keeps such values in VGPRs,
+// runs out, and copies them through v_accvgpr_read in front of every use.
+LCE_DEVICE void keep_in_agpr(u32x4& v) { asm volatile("" : "+a"(v)); }
+LCE_DEVICE void keep_in_vgpr(u32x4& v) { asm volatile("" : "+v"(v)); }
+LCE_DEVICE void keep_in_vgpr(float& v) { asm volatile("" : "+v"(v)); }   // a uniform value kept per lane (spares a scalar register)
+// a + b, saturating at 2^32 - 1 (v_add_u32 ... clamp): two "out of range" markers must not add up to an in-range offset
+LCE_DEVICE uint32_t sat_add_u32(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
+// Between a wave's scratch writes and its reads of other lanes' values.  The LDS runs one wave's DS operations in
+// issue order, so ordering the instructions is enough (LCE_STREAM_LDS_WAIT: also wait for the LDS queue).
+#ifdef LCE_STREAM_LDS_WAIT
+LCE_DEVICE void wave_lds_scratch_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+LCE_DEVICE void wave_lds_scratch_fence() { asm volatile("" ::: "memory"); }
+#endif
 // Ask the scheduler for the issue pattern {1 MFMA, 1 LDS read} x n inside the current region.
 template <int N>
 LCE_DEVICE void interleave_mfma_ldsread() {
@@ -265,6 +293,15 @@ LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
 LCE_DEVICE void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, 0, LCE_STORE8_AUX);
 }
+// ... with a scalar byte offset on top of the per-lane one (a K-step's row offset costs no vector instruction)
+LCE_DEVICE void buf_store_streaming_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, uniform_off, LCE_STORE_AUX);
+}
+LCE_DEVICE void buf_store_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, uniform_off, LCE_STORE8_AUX);
+}
+LCE_DEVICE void buf_store2(rsrc_t r, uint32_t lane_off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_off, 0, 0); }
+LCE_DEVICE void buf_store1(rsrc_t r, uint32_t lane_off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_off, 0, 0); }
 // ... and the matching load for inputs that are read exactly once
 LCE_DEVICE f32x4 load_streaming(const f32x4* p) { return __builtin_nontemporal_load(p); }
 LCE_DEVICE u32x4 load_streaming(const u32x4* p) { return __builtin_nontemporal_load(p); }

@@ -5,6 +5,7 @@
 #include "lce_kernels.h"
 #include "lce_kernels_mfma.h"
 #include "lce_kernels_pointwise.h"
+#include "lce_kernels_stream.h"
 
 namespace lce {
 
@@ -114,5 +115,34 @@ inline pointwise_fn find_pointwise(int dst, int nc, int nj) {
     default: return pointwise_by_nc<kDstBitpacked>(nc, nj);
   }
 }
+
+
+typedef void (*stream_fn)(const StreamArgs, const uint8_t*, const uint8_t*, const float*, const float*, const float*,
+                          const uint32_t*, void*);
+
+// 3x3 filters over 64 / 128 / 256 (padded) input channels; FAST = every padded word exists and padding is +1;
+// CLAMP = the float transform's clamp is not the identity
+template <int DST, bool FAST, bool CLAMP>
+stream_fn stream_by_kch(int kch) {
+  switch (kch) {
+    case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP>;
+    case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP>;
+    case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP>;
+    default: return nullptr;
+  }
+}
+inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp) {
+  switch (dst) {
+    case LCE_HIP_F32:
+      if (clamp) return fast ? stream_by_kch<kDstFloat, true, true>(kch) : stream_by_kch<kDstFloat, false, true>(kch);
+      return fast ? stream_by_kch<kDstFloat, true, false>(kch) : stream_by_kch<kDstFloat, false, false>(kch);
+    case LCE_HIP_I8: return fast ? stream_by_kch<kDstInt8, true, false>(kch) : stream_by_kch<kDstInt8, false, false>(kch);
+    default: return fast ? stream_by_kch<kDstBitpacked, true, false>(kch) : stream_by_kch<kDstBitpacked, false, false>(kch);
+  }
+}
+// the FAST variant's precondition (lce_kernels_stream.h)
+inline bool stream_fast(const StreamArgs& G) { return G.Cin % 64 == 0 && !G.zero_border; }
+// the clamp is the identity on [0, 2 * K_bt] (activation NONE)
+inline bool stream_clamps(const StreamArgs& G) { return !(G.cmin <= 0.0f && G.cmax >= 2.0f * G.a_bt); }
 
 }  // namespace lce

@@ -94,6 +94,8 @@ struct lce_hip_bconv2d_plan {
   DevBuf<int32_t> d_thr, d_oobc;
   DevBuf<uint8_t> d_wq;
   DevBuf<float> d_thrq;
+  DevBuf<uint32_t> d_sched;        // streaming kernel: its production schedule
+  bool cus_forced = false;         // num_cus was set through the "compute_units" option
   int device = -1;                 // the HIP device the plan's buffers live on (bound at the first upload)
   void* workspace = nullptr;       // FP4 expanded activations (matrix-core engine, workspace variant)
   void* lds_opt_in = nullptr;      // kernel already granted > 64 KiB of dynamic LDS
@@ -142,6 +144,18 @@ lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
       (!h.use_tiled || !h.packed.empty() || !h.have_weights) &&
       (!h.use_mfma || !h.wq.empty() || !h.have_weights))
     return LCE_HIP_OK;
+  if (!plan->cus_forced) {
+    // the streaming kernel sizes its grid by the device's compute units (asked once per process)
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+      }
+      return n;
+    }();
+    if (cus > 0) h.num_cus = cus;
+  }
   const std::string err = lce::select_kernel(h, pixels);
   if (!err.empty()) return fail(LCE_HIP_ERR_UNSUPPORTED, "%s", err.c_str());
   plan->selected_for_pixels = pixels;
@@ -171,6 +185,8 @@ lce_hip_status ensure_uploaded(lce_hip_bconv2d_plan* plan) {
     LCE_HIP_TRY(plan->d_mul.upload(h.mul_q));
     LCE_HIP_TRY(plan->d_bias.upload(h.bias_q));
     LCE_HIP_TRY(plan->d_thrq.upload(h.thr_q));
+    if (h.use_stream) LCE_HIP_TRY(plan->d_sched.upload(h.st_tabs));
+    else plan->d_sched.release();
     plan->d_packed.release();
     plan->d_filter.release();
     plan->d_oobc.release();
@@ -435,7 +451,28 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     return LCE_HIP_OK;
   }
   if (!strcmp(key, "pointwise_tiles")) {   // tuning aid for the 1x1 streaming kernel: tiles per wave
-    h.pw_tiles_pref = atoi(value);
+    const int v = atoi(value);
+    if (v < 0 || v > 8 || (v == 0 && strcmp(value, "0")))
+      return fail(LCE_HIP_ERR_INVALID, "plan_set_option: pointwise_tiles must be 0 (auto) .. 8");
+    h.pw_tiles_pref = v;
+    return LCE_HIP_OK;
+  }
+  if (!strcmp(key, "stream_rows")) {       // tuning aid for the streaming kernel: output rows per segment (0 = auto)
+    const int v = atoi(value);
+    if (v < 0 || (v == 0 && strcmp(value, "0")))
+      return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_rows must be 0 (auto) or a positive row count");
+    h.stream_rows_pref = v;
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
+  if (!strcmp(key, "compute_units")) {     // testing aid: the device's CU count as the streaming kernel's planner sees it
+    const int v = atoi(value);
+    if (v < 1) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: compute_units must be positive");
+    h.num_cus = v;
+    plan->cus_forced = true;
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
     return LCE_HIP_OK;
   }
   if (!strcmp(key, "engine")) {
@@ -444,7 +481,8 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     else if (!strcmp(value, "mfma")) h.engine_pref = 2;
     else if (!strcmp(value, "direct")) h.engine_pref = 3;
     else if (!strcmp(value, "pointwise")) h.engine_pref = 4;
-    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|pointwise");
+    else if (!strcmp(value, "stream")) h.engine_pref = 5;
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|pointwise|stream");
   } else if (!strcmp(key, "phase")) {
     // profiling aid for the matrix-core engine: time its two kernels separately
     if (!strcmp(value, "all")) h.phase = 0;
@@ -529,6 +567,20 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
                          plan->d_bias.ptr, plan->d_thrq.ptr, out, sgn);
       LCE_HIP_TRY(hipGetLastError());
       sign_fused = true;   // (also when there is none to write)
+    } else if (h.use_mfma && h.use_stream) {
+      // weight-stationary streaming kernel: one persistent block per CU walks its run of segments
+      const lce::StreamArgs G = lce::make_stream_args(h, nb);
+      lce::stream_fn fn = lce::find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G));
+      if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
+      const size_t lds = (size_t)lce::stream_lds_bytes(h);
+      if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
+        LCE_HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        plan->lds_opt_in = (void*)fn;
+      }
+      const dim3 grid((unsigned)((G.S + G.SPB - 1) / G.SPB), (unsigned)h.st_ny);
+      hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, G, (const uint8_t*)in, plan->d_wq.ptr, plan->d_mul.ptr,
+                         plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_sched.ptr, out);
+      LCE_HIP_TRY(hipGetLastError());
     } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct, h.use_direct && h.tile_tx > 0);

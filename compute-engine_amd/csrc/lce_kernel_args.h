@@ -116,4 +116,41 @@ struct PwArgs {
   float bit_thr;        // second output: bit = value < bit_thr (as MfmaArgs::bit_thr)
 };
 
+
+
+// Launch constants of the weight-stationary streaming kernel (lce_kernels_stream.h).  A launch is cut into
+// SEGMENTS = (image, run of RS output rows); a persistent block owns SPB consecutive segments and walks them as ONE
+// stream of 32-pixel blocks, fed by ONE stream of input rows (a segment contributes SRS = (RS-1)*SH + KH of them,
+// its halo included) that are expanded to FP4 into a ring of R row slots in LDS.  An ITEM = 16 bytes (4 words) of
+// one input pixel.  The planner simulates the stream and uploads tables: sched[T] = items that must be resident
+// before tile step T (4 block steps of 2^pph_log pixel blocks each) begins -- quotas of 256 items (one per lane)
+// wherever that keeps up, 512 where it does not --, and per (pixel block, lane) the LDS addresses and output offset.
+// RS divides OH, so every segment has RS * OW output pixels and output offsets are linear in the segment index.
+constexpr int kStreamItemsPerLane = 2;   // items a lane can produce per tile step (the schedule is smoothed to fit)
+struct StreamArgs {
+  int32_t H, W, Cw, Cin;       // source (bitpacked) tensor
+  int32_t OH, OW, N, Npad, Wout;
+  int32_t SH, SW, PH, PW;
+  int32_t B;                   // images of this launch
+  int32_t Wp;                  // pixels per ring row slot (padded width)
+  int32_t R;                   // ring row slots
+  int32_t ring_bytes;          // R * Wp * PS rounded up to 1 KiB; 4 x 8 KiB epilogue scratch + 4 KiB dump follow
+  int32_t zero_border;         // 1: padding is 0 (exact SAME-zero), 0: +1 (one-padding)
+  int32_t QG;                  // items per pixel = ceil(padded words / 4)
+  int32_t IPR;                 // items per stream row = W * QG
+  int32_t RS;                  // output rows per segment
+  int32_t SPI;                 // segments per image = ceil(OH / RS)
+  int32_t SRS;                 // stream rows per segment
+  int32_t PBS;                 // pixel blocks per segment = ceil(RS * OW / 32)
+  int32_t S;                   // segments of this launch = B * SPI
+  int32_t SPB;                 // segments per block
+  int32_t pph_log;             // log2 of the pixel blocks per block step: 4 waves = (4 >> pph_log) channel slices x that
+  uint32_t in_bytes, w_bytes, out_bytes;   // bytes bound to the input / weight / output buffer resources (< 2^31)
+  // the planner's tables (one buffer): sched at byte 0, one dword per tile step; lim: one dword per pixel block (its
+  // last real row); ctx: 16 bytes per (pixel block, lane) = {tap-row LDS addresses 0..2, output byte offset}
+  uint32_t tab_bytes, tab_lim, tab_ctx;
+  float a_bt, cmin, cmax;
+  FastDiv div_ipr, div_qg, div_srs, div_spi, div_r;
+};
+
 }  // namespace lce

@@ -1,0 +1,512 @@
+// Weight-stationary streaming variant of the matrix-core engine ("engine=stream").
+//
+// Why it exists: the block GEMM of lce_kernels_mfma.h re-streams a tile's weights
+// through an LDS ring (a barrier, a counted wait and two LDS-DMA issues per K-step) and runs every tile's
+// prologue (halo expansion) and epilogue (transform, transpose, stores) beside ANOTHER block's K loop -- two
+// waves per SIMD that share one issue port; the matrix pipe ends up 46 % busy on the BASELINE layer.  Here:
+//
+//   * ONE wave per SIMD owns 64 output channels and keeps ALL their FP4 weights in registers for its whole
+//     life (KH*KW*KCH K-steps x 2 channel tiles x 4 registers: 288 of the 512 for a 3x3x256 filter, most of
+//     them in the accumulator half of the register file, which MFMA reads directly).  The K loop has no weight
+//     traffic, no barrier and no per-step wait: a K-step is one ds_read_b128 (the A fragment, at an immediate
+//     offset from a per-lane tap-row address) and two MFMAs.
+//   * The block is PERSISTENT: it walks a run of (image, output-row range) segments as a stream of 32-pixel
+//     blocks.  The bitpacked input rows are expanded to FP4 ONCE each into a ring of row slots in LDS (a rolling
+//     halo), by the same four waves, as filler between their MFMAs.  Everything that is pure index arithmetic
+//     is done by the planner and uploaded as tables (StreamArgs): `sched` says how many 16-byte items must be
+//     resident before each tile step (four block steps, one block barrier), `ctx` holds, per pixel block and
+//     lane, the three tap-row LDS addresses and the output offset.
+//   * The output transform of pixel block u-1 (transform, transpose through a wave-private LDS scratch,
+//     16-byte row stores) is woven, unit by unit, between the MFMAs of pixel block u, which accumulate into
+//     the other of two accumulator sets.
+//
+// One wave per SIMD means one instruction issue slot per ~4 cycles for EVERYTHING (scalar instructions and waits
+// included), 8 per MFMA: the kernel is written for instruction count -- packed-f32 transform, fragment reads in
+// groups of four behind one counted wait, the first MFMA of a block reads a constant K_bt tile instead of
+// re-arming accumulators, stores take their row offsets as scalar offsets, no per-block scalar arithmetic.
+//
+// Same arithmetic as the block GEMM -- the planner's FP4 weight image (pack_for_mfma: negated,
+// [K-step][K-half][Npad][16 B]), accumulators start at K_bt and end as 2 * popcount-accumulator
+// (output_transform.h:62-91), float transform with two roundings (:99-106), int8 round-half-away + saturate
+// (:31-44), bitpacked compare (:160-168) -- so results are bit-identical to it and to the oracle.
+#pragma once
+#include <lce_device_intrinsics.h>
+#include "lce_kernel_args.h"
+#include "lce_kernels.h"
+#include "lce_kernels_mfma.h"
+
+namespace lce {
+
+#ifdef LCE_STREAM_PHASES
+// Profiling aid (never defined in the product build): wave 0 of every block stamps s_memtime at entry, first rows
+// resident, and after every tile step (up to 60), the last slot at exit.
+__device__ unsigned long long lce_stream_tl[512 * 64];
+#define LCE_SPH(slot)                                                                               \
+  do {                                                                                              \
+    if (thread_idx_x() == 0 && block_idx_x() < 512 && (slot) < 64)                                  \
+      lce_stream_tl[block_idx_x() * 64 + (slot)] = __builtin_readcyclecounter();                    \
+  } while (0)
+#else
+#define LCE_SPH(slot) do {} while (0)
+#endif
+
+// fastdiv without the divisor-1 branch: a divisor of 1 has magic 0, so the multiply-high contributes 0 and the
+// masked addend is n itself.
+LCE_DEVICE uint32_t fastdiv_nb(uint32_t n, FastDiv d) {
+  const uint32_t one = 0u - (uint32_t)(d.magic == 0u);
+  return (mulhi_u32(n, d.magic) >> d.shift) + (n & one);
+}
+
+// Units of an epilogue phase that belong to K-step i of n steps (an even spread of `units`).
+constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
+
+// FAST (compile-time): every padded input word exists in full and padding is +1 (Cin == 64 * KCH, no exact
+// SAME-zero border) -- the BASELINE layers -- so neither the loads nor the expansion carry per-word conditions.
+// CLAMP (float output): the transform's clamp is not the identity (a fused activation).
+template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP>
+LCE_KERNEL void __launch_bounds__(256, 1)
+bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
+               const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
+               const uint32_t* __restrict__ tabs, void* __restrict__ out) {
+  constexpr int KS = KH * KW * KCH;            // K-steps of one pixel block
+  constexpr int PS = KCH * 32 + 16;            // LDS bytes per ring pixel (the +16 staggers the banks)
+  constexpr int GA = 4;                        // K-steps per fragment group (one counted wait per group)
+  constexpr int NG = (KS + GA - 1) / GA;
+  static_assert(KH == 3, "the context table holds three tap-row addresses");
+  static_assert(KS >= 8 && KS * 8 <= 288, "the filter bank must fit the register file");
+
+  const int tid = thread_idx_x();
+  const int lane = tid & (kWave - 1), wave = uniform(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  // waves -> (64-channel slice, pixel phase): N >= 256: four slices of one pixel block; N = 128: two slices x two
+  // pixel blocks; N = 64: four pixel blocks
+  const int nslb = 4 >> G.pph_log;
+  const int slice = wave & (nslb - 1), pp = wave >> (2 - G.pph_log);
+  const int n0 = (block_idx_y() * nslb + slice) * 64;
+  const bool slice_ok = n0 < G.Npad;
+
+  uint8_t* const lds0 = lds_base();
+  float* const scratch = (float*)(lds0 + G.ring_bytes) + wave * (32 * 64);   // [32 pixel rows][64 channels]
+  const uint32_t dump = (uint32_t)G.ring_bytes + 4u * 8192u + (uint32_t)lane * 64u;   // where idle lanes' items go
+
+  LCE_SPH(0);
+  // ---- the filter bank of this wave's 64 channels, resident for the life of the block ----
+  u32x4 W[KS][2];
+  {
+    const rsrc_t rw = make_rsrc(wq, G.w_bytes);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        W[ks][j] = buf_load(rw, slice_ok ? (uint32_t)((ks * 2 + half) * G.Npad + n0 + j * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
+        // 256 accumulator registers hold the first 32 K-steps' fragments, the rest stay in VGPRs
+        if (ks < 32) keep_in_agpr(W[ks][j]);
+        else keep_in_vgpr(W[ks][j]);
+      }
+  }
+  // per-channel constants of this lane's two channels; multiplier and bias twice each: the transform works on
+  // register pairs (v_pk_mul_f32 / v_pk_add_f32, each element rounded twice as output_transform.h:105 does)
+  float tj[2], uj[2];
+  f32x2 mj[2], bj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = slice_ok ? n0 + j * 32 + l31 : 0;
+    tj[j] = uj[j] = 0.0f;
+    mj[j] = f32x2{0.0f, 0.0f};
+    bj[j] = f32x2{0.0f, 0.0f};
+    if constexpr (DST == kDstBitpacked) tj[j] = thrf[n];
+    else { mj[j] = f32x2{mul[n], mul[n]}; bj[j] = f32x2{bias[n], bias[n]}; }
+    if constexpr (DST == kDstInt8) { tj[j] = thrf[n]; uj[j] = thrf[G.Npad + n]; }
+  }
+  // the accumulators' start value K_bt as a constant C tile (the first MFMA of every pixel block reads it)
+  f32x16 kbt = f32x16_fill(G.a_bt);
+  pin(kbt);
+  float cminv = G.cmin, cmaxv = G.cmax;     // per-lane copies: the scalar registers are for the loop's addressing
+  keep_in_vgpr(cminv);
+  keep_in_vgpr(cmaxv);
+
+  // ---- this block's run of segments ----
+  const int g0 = block_idx_x() * G.SPB;
+  int nseg = G.S - g0;
+  nseg = nseg < 0 ? 0 : (nseg > G.SPB ? G.SPB : nseg);
+  const int nblk = slice_ok ? nseg * G.PBS : 0;        // pixel blocks of this block's stream that produce output
+  const int usteps = (nseg * G.PBS + (1 << G.pph_log) - 1) >> G.pph_log;   // block steps (2^pph_log pixel blocks each)
+  const int ntile = (usteps + 3) >> 2;                 // tile steps (four block steps + one barrier)
+  const uint32_t* const sched = tabs;
+  const rsrc_t rtab = make_rsrc(tabs, G.tab_bytes);
+
+  // ---- the ring: every slot starts as padding (+1 codes, or zeros for exact SAME-zero) ----
+  {
+    const uint32_t code = G.zero_border ? 0u : 0x22222222u;
+    const u32x4 v = {code, code, code, code};
+    for (int o = tid * 16; o < G.ring_bytes; o += 256 * 16) *(u32x4*)(lds0 + o) = v;
+  }
+  block_barrier_keep_vm();
+
+  // ---- production: item e of the block's stream = 16 bytes (4 input words) of one input pixel ----
+  //   e -> stream row s = e / IPR, pixel x, word group qg; s -> (local segment, row in segment) -> image row iy.
+  // Rows outside the image (and images past the batch) are steered to an out-of-range offset and read 0 = the
+  // "+1" padding word, exactly as in the direct variant.
+  const rsrc_t rin = make_rsrc(xin, G.in_bytes);
+  auto item_issue = [&](uint32_t e, uint32_t e_end, u32x4& wv, uint32_t& dst, int& meta) LCE_LAMBDA_INLINE {
+    const bool on = e < e_end;
+    const uint32_t s = fastdiv_nb(e, G.div_ipr);
+    const uint32_t rem = e - s * (uint32_t)G.IPR;
+    const uint32_t x = fastdiv_nb(rem, G.div_qg);
+    const int c0 = (int)(rem - x * (uint32_t)G.QG) * 4;
+    const uint32_t gl = fastdiv_nb(s, G.div_srs);
+    const int j = (int)(s - gl * (uint32_t)G.SRS);
+    const uint32_t g = (uint32_t)g0 + gl;
+    const uint32_t img = fastdiv_nb(g, G.div_spi);
+    const int c = (int)(g - img * (uint32_t)G.SPI);
+    const int iy = c * G.RS * G.SH - G.PH + j;
+    const bool inside = on && (uint32_t)iy < (uint32_t)G.H && img < (uint32_t)G.B;
+    const uint32_t slot = s - fastdiv_nb(s, G.div_r) * (uint32_t)G.R;
+    dst = on ? (slot * (uint32_t)G.Wp + (uint32_t)G.PW + x) * (uint32_t)PS + (uint32_t)c0 * 16u : dump;
+    meta = c0 | (inside ? 0x100 : 0);
+    const uint32_t off = (uint32_t)(((int)img * G.H + iy) * G.W + (int)x) * (uint32_t)G.Cw * 4u + (uint32_t)c0 * 4u;
+    if constexpr (FAST && KCH == 1) {
+      const u32x2 v2 = buf_load(rin, inside ? off : kOobOffset, (u32x2*)nullptr);
+      wv[0] = v2[0]; wv[1] = v2[1]; wv[2] = 0u; wv[3] = 0u;
+    } else if (FAST || (G.Cw & 3) == 0) {
+      wv = buf_load(rin, inside ? off : kOobOffset, (u32x4*)nullptr);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = buf_load(rin, inside && c0 + q < G.Cw ? off + 4u * q : kOobOffset, (uint32_t*)nullptr);
+    }
+  };
+  // word q of an item -> 16 bytes of FP4 in the ring
+  auto item_write_word = [&](auto qc, const u32x4& wv, uint32_t dst, int meta) LCE_LAMBDA_INLINE {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < (KCH * 2 < 4 ? KCH * 2 : 4)) {      // words past the padded channel count do not exist
+      u32x4 v;
+      if constexpr (FAST) {
+        v = fp4_of_full_word(wv[q]);
+      } else {
+        const int cc = (meta & 0xff) + q;
+        int valid = G.Cin - cc * 32;                      // channels of this word that exist
+        valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
+        if (!(meta & 0x100) && G.zero_border) valid = 0;  // exact SAME-zero: 0 contributes 0
+        v = valid == 32 ? fp4_of_full_word(wv[q]) : fp4_of_word(wv[q], valid);
+        // (a word group that starts past the last plane cannot occur: QG = ceil(planes / 4))
+        if (cc >= KCH * 2) return;
+      }
+      *(u32x4*)(lds0 + dst + q * 16) = v;
+    }
+  };
+  auto item_write = [&](const u32x4& wv, uint32_t dst, int meta) LCE_LAMBDA_INLINE {
+    item_write_word(IntC<0>{}, wv, dst, meta);
+    item_write_word(IntC<1>{}, wv, dst, meta);
+    item_write_word(IntC<2>{}, wv, dst, meta);
+    item_write_word(IntC<3>{}, wv, dst, meta);
+  };
+
+  // prologue: everything tile step 0 needs, loads first
+  {
+    const uint32_t need0 = sched[0];
+    for (uint32_t e0 = 0; e0 < need0; e0 += 4u * 256u) {
+      u32x4 wv[4];
+      uint32_t dv[4];
+      int mv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) item_issue(e0 + (uint32_t)(k * 256 + tid), need0, wv[k], dv[k], mv[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) item_write(wv[k], dv[k], mv[k]);
+    }
+  }
+  // The items tile step 0 writes (needed from tile step 1 on) are on their way.  Item A (the first 256 of a tile
+  // step's quota) rides between the MFMAs; item B (the rest -- the planner's schedule makes it rare) is handled
+  // out of line at the end of a tile step.
+  u32x4 pwa, pwb = {0u, 0u, 0u, 0u};
+  uint32_t pda, pdb = dump;
+  int pma, pmb = 0;
+  bool have_b;
+  {
+    const uint32_t a = sched[0], b = sched[1];
+    item_issue(a + (uint32_t)tid, b, pwa, pda, pma);
+    have_b = b - a > 256u;
+    if (have_b) item_issue(a + (uint32_t)(256 + tid), b, pwb, pdb, pmb);
+  }
+  block_barrier_keep_vm();
+  LCE_SPH(1);
+
+  // ---- per-pixel-block context, from the planner's table: entry (q, lane) = {addr0, addr1, addr2, out offset} ----
+  //   addr[fy] : LDS byte address of the lane's pixel in tap row fy (K-half included) at (fx, kc) = (0, 0)
+  //   out      : byte offset of the lane's first output row, relative to the block's first output pixel, bit 31 set
+  //              when the pixel block is the partial last one of its segment (its stores then go out of line)
+  struct Ctx {
+    u32x4 t;
+  };
+  const uint32_t row_bytes = DST == kDstBitpacked ? (uint32_t)G.Wout * 4u : (uint32_t)G.N * (DST == kDstInt8 ? 1u : 4u);
+  const rsrc_t rout = make_rsrc(out, G.out_bytes);
+  // this lane's share of a stored row, and the block's first output pixel
+  uint32_t chan_off;
+  if constexpr (DST == kDstFloat) {
+    const int n = n0 + (lane & 15) * 4;                                // 16 lanes x 16 bytes = a pixel's 64 channels
+    chan_off = n < G.N ? (uint32_t)n * 4u : kOobOffset;
+  } else if constexpr (DST == kDstInt8) {
+    const int n = n0 + (lane & 3) * 16;                                // 4 lanes x 16 bytes = a pixel's 64 channels
+    chan_off = n < G.N ? (uint32_t)n : kOobOffset;
+  } else {
+    chan_off = lane < 32 ? (uint32_t)(n0 >> 5) * 4u : kOobOffset;      // lane p owns pixel row p: two words
+  }
+  chan_off += (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * row_bytes;      // < 2^31 with the whole output
+  const int nq = G.SPB * G.PBS;
+  auto load_ctx = [&](int u, Ctx& cx) LCE_LAMBDA_INLINE {
+    int q = (u << G.pph_log) + pp;
+    q = q < nq ? q : nq - 1;
+    cx.t = buf_load(rtab, (uint32_t)G.tab_ctx + (uint32_t)(q * 64 + lane) * 16u, (u32x4*)nullptr);
+  };
+  // the store offset of a context: out of range for pixel blocks past the stream and for partial blocks
+  auto out_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
+    const int q = (u << G.pph_log) + pp;
+    return sat_add_u32(cx.t[3], q < nblk ? chan_off : kOobOffset);   // saturating: two markers must not wrap around
+  };
+
+  // ---- the epilogue of one pixel block, cut into units that ride between the next block's MFMAs ----
+  // float / int8, phase A (16 units): two accumulator registers of tile j = t / 8 -> transformed -> scratch
+  //   (register r of a tile holds pixel rows (r & 3) + 8 * (r >> 2) + 4 * half of channel column l31)
+  // phase B (8 units): ds_read_b128 of the transposed tile; phase C (8 units): [int8: round + pack] + stores
+  f32x4 yb[8];
+  u32x4 pk[2];
+  uint32_t bw[2] = {0u, 0u};
+  auto epi_a = [&](auto tc, f32x16 (&acc)[2]) LCE_LAMBDA_INLINE {
+    constexpr int t = decltype(tc)::value;
+    if constexpr (DST == kDstBitpacked) {
+      // unit t = register r: the 32 channel bits of rows q and q + 4, dropped into the lanes that will store them
+      constexpr int r = t, q = (r & 3) + 8 * (r >> 2);
+      unsigned long long bits[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bits[j] = wave_ballot(acc[j][r] > tj[j]);
+      settle_ballots(bits);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bw[j] = write_lane_settled<q>((uint32_t)bits[j], bw[j]);
+        bw[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), bw[j]);
+      }
+    } else {
+      constexpr int j = t >> 3, r0 = (t & 7) * 2;          // registers r0, r0 + 1: pixel rows row0, row0 + 1
+      const int row0 = (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+      f32x2 y;
+      if constexpr (DST == kDstFloat) {
+        f32x2 x = {acc[j][r0], acc[j][r0 + 1]};
+        if constexpr (CLAMP) { x[0] = med3(x[0], cminv, cmaxv); x[1] = med3(x[1], cminv, cmaxv); }
+        y = mul_then_add_pk(x, mj[j], bj[j]);
+      } else {
+        const f32x2 x = {acc[j][r0], acc[j][r0 + 1]};
+        y = mul_then_add_pk(x, mj[j], bj[j]);
+        y[0] = med3(y[0], tj[j], uj[j]);                   // one clamp: see lce_kernels_pointwise.h
+        y[1] = med3(y[1], tj[j], uj[j]);
+      }
+      scratch[row0 * 64 + j * 32 + l31] = y[0];
+      scratch[(row0 + 1) * 64 + j * 32 + l31] = y[1];
+    }
+  };
+  auto epi_b = [&](auto kc) LCE_LAMBDA_INLINE {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (DST == kDstFloat) {
+      yb[k] = *(const f32x4*)(scratch + ((lane >> 4) + 4 * k) * 64 + (lane & 15) * 4);
+    } else if constexpr (DST == kDstInt8) {
+      // store instruction k / 4 covers rows (lane >> 2) + 16 * (k / 4); a lane's 16 channels = reads 4 (k % 4) .. + 3
+      yb[k] = *(const f32x4*)(scratch + ((lane >> 2) + 16 * (k >> 2)) * 64 + (lane & 3) * 16 + (k & 3) * 4);
+    }
+  };
+  // `ob` = this lane's byte offset for store instruction 0 (out of range: nothing is stored)
+  auto epi_c = [&](auto kc, uint32_t ob) LCE_LAMBDA_INLINE {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (DST == kDstFloat) {
+      buf_store_streaming_so(rout, ob, (uint32_t)(4 * k) * row_bytes, yb[k]);
+    } else if constexpr (DST == kDstInt8) {
+      int q0, q1, q2, q3;
+      round_i8_clamped2(yb[k][0], yb[k][1], q0, q1);
+      round_i8_clamped2(yb[k][2], yb[k][3], q2, q3);
+      pk[k >> 2][k & 3] = pack4_u8(q0, q1, q2, q3);
+      if constexpr ((k & 3) == 3) buf_store_so(rout, ob, (uint32_t)(16 * (k >> 2)) * row_bytes, pk[k >> 2]);
+    } else {
+      if constexpr (k == 0) {
+        // lane p (< 32) owns pixel row p: the two words of this wave's 64 channels
+        if ((G.Wout & 1) == 0) {
+          const u32x2 v = {bw[0], bw[1]};
+          buf_store2(rout, ob, v);
+        } else {
+          buf_store1(rout, ob, bw[0]);
+          buf_store1(rout, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(ob, 4u) : kOobOffset, bw[1]);   // (ob may be the saturated marker)
+        }
+      }
+    }
+  };
+  // A partial pixel block (the last of a segment whose pixel count is not a multiple of 32): rows past the segment
+  // hold copies of its last pixel (their lanes re-read it), so every store is redirected to min(row, last real
+  // row) -- the same bytes to the same place.  Out of line, after the K loop that carried the block's epilogue.
+  auto epi_partial = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE {
+    int q = (u << G.pph_log) + pp;
+    if (q >= nblk) return;
+    const uint32_t lim1 = tabs[G.tab_lim / 4 + q];                     // last real row of the block
+    const uint32_t base = (cx.t[3] & 0x7fffffffu) + chan_off;          // the table's offset is for row (lane's first row)
+    if constexpr (DST == kDstFloat) {
+      const uint32_t rowl = (uint32_t)(lane >> 4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t row = rowl + 4u * k < lim1 ? rowl + 4u * k : lim1;
+        buf_store_streaming(rout, base + (row - rowl) * row_bytes, yb[k]);
+      }
+    } else if constexpr (DST == kDstInt8) {
+      const uint32_t rowl = (uint32_t)(lane >> 2);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t row = rowl + 16u * k < lim1 ? rowl + 16u * k : lim1;
+        buf_store(rout, base + (row - rowl) * row_bytes, pk[k]);
+      }
+    } else {
+      const uint32_t rowl = (uint32_t)(lane & 31);
+      const uint32_t row = rowl < lim1 ? rowl : lim1;
+      const uint32_t o = base + (row - rowl) * row_bytes;
+      buf_store1(rout, o, bw[0]);
+      buf_store1(rout, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(o, 4u) : kOobOffset, bw[1]);
+    }
+  };
+  // which units ride in K-step ks: A in the first 4/9 of the steps, B from the middle on, C at the end
+  constexpr int SA = KS * 4 / 9, SB0 = KS / 2, SBN = (KS * 2 + 8) / 9, SC0 = KS - SBN;
+  static_assert(SA <= SB0 && SB0 + SBN <= SC0, "phase layout");
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[a][j] = kbt;
+
+  Ctx cur, nxt;             // block being multiplied, the one after it
+  load_ctx(0, cur);
+  uint32_t epi_ob = kOobOffset;      // the block being drained: nothing yet
+  bool epi_part = false;
+  int epi_u = 0;
+  Ctx epi_cx = cur;
+  u32x4 af[2][GA];
+
+  auto frag_addr = [&](const Ctx& cx, int ks) LCE_LAMBDA_INLINE -> uint32_t {
+    const int fy = ks / (KW * KCH), fx = (ks / KCH) % KW, kc = ks % KCH;
+    return cx.t[fy] + (uint32_t)(fx * PS + kc * 32);
+  };
+
+  // One block step: K loop of pixel block u into accumulator set PAR, with the epilogue of block u - 1
+  // (set PAR ^ 1) and this step's share of the production riding between the MFMAs.
+  auto step = [&](auto kc_, int u, uint32_t sch1, uint32_t sch2) LCE_LAMBDA_INLINE {
+    constexpr int k = decltype(kc_)::value, PAR = k & 1;
+    if constexpr (k == 0) {
+      // first block of a tile step: its fragments may live in rows the previous tile step wrote
+#pragma unroll
+      for (int d = GA - 1; d >= 0; --d) af[0][d] = *(const u32x4*)(lds0 + frag_addr(cur, d));
+    }
+    load_ctx(u + 1, nxt);
+    auto kstep = [&](auto ksc) LCE_LAMBDA_INLINE {
+      constexpr int ks = decltype(ksc)::value;
+      if constexpr (ks < KS) {
+        constexpr int g = ks / GA;
+        // the fragments of the NEXT group, all at once (the next block's first group rides at the end, except across
+        // the barrier): one counted wait per group instead of one per K-step
+        constexpr int fs = (g + k * NG) & 1;     // the fragment set this block's group g lives in (set 0 after a barrier)
+        if constexpr (ks % GA == 0) {
+          // (issued last-used first: the wait for the group's first fragment then covers the whole group)
+          if constexpr (g + 1 < NG) {
+#pragma unroll
+            for (int d = GA - 1; d >= 0; --d)
+              if ((g + 1) * GA + d < KS) af[fs ^ 1][d] = *(const u32x4*)(lds0 + frag_addr(cur, (g + 1) * GA + d));
+          } else if constexpr (k < 3) {
+#pragma unroll
+            for (int d = GA - 1; d >= 0; --d) af[fs ^ 1][d] = *(const u32x4*)(lds0 + frag_addr(nxt, d));
+          }
+        }
+        if constexpr (ks == 0) {
+          acc[PAR][0] = mfma_fp4_32x32x64(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
+          acc[PAR][1] = mfma_fp4_32x32x64(af[fs][0], W[0][1], kbt);
+        } else {
+          acc[PAR][0] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
+          acc[PAR][1] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][1], acc[PAR][1]);
+        }
+        pin(acc[PAR][0]);    // the MFMAs stay in THIS K-step (they have no side effects the sched_fence could hold)
+        pin(acc[PAR][1]);
+        // ---- fillers ----
+        if constexpr (ks < SA) {
+          constexpr int lo = stream_unit_lo(16, ks, SA), hi = stream_unit_lo(16, ks + 1, SA);
+          if constexpr (lo == 0) wave_lds_order();     // the scratch's previous readers are done (in-order LDS)
+          if constexpr (lo + 0 < hi) epi_a(IntC<lo + 0>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 1 < hi) epi_a(IntC<lo + 1>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 2 < hi) epi_a(IntC<lo + 2>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 3 < hi) epi_a(IntC<lo + 3>{}, acc[PAR ^ 1]);
+          static_assert(hi - lo <= 4, "units per step");
+        }
+        if constexpr (ks >= SB0 && ks < SB0 + SBN) {
+          constexpr int lo = stream_unit_lo(8, ks - SB0, SBN), hi = stream_unit_lo(8, ks - SB0 + 1, SBN);
+          if constexpr (lo == 0) wave_lds_scratch_fence();   // phase A's writes before phase B's reads
+          if constexpr (lo + 0 < hi) epi_b(IntC<lo + 0>{});
+          if constexpr (lo + 1 < hi) epi_b(IntC<lo + 1>{});
+          if constexpr (lo + 2 < hi) epi_b(IntC<lo + 2>{});
+          if constexpr (lo + 3 < hi) epi_b(IntC<lo + 3>{});
+          static_assert(hi - lo <= 4, "units per step");
+        }
+        if constexpr (ks >= SC0) {
+          constexpr int lo = stream_unit_lo(8, ks - SC0, SBN), hi = stream_unit_lo(8, ks - SC0 + 1, SBN);
+          if constexpr (lo + 0 < hi) epi_c(IntC<lo + 0>{}, epi_ob);
+          if constexpr (lo + 1 < hi) epi_c(IntC<lo + 1>{}, epi_ob);
+          if constexpr (lo + 2 < hi) epi_c(IntC<lo + 2>{}, epi_ob);
+          if constexpr (lo + 3 < hi) epi_c(IntC<lo + 3>{}, epi_ob);
+        }
+        // production: block step 0 expands item A, block step 1 issues the next one (three block steps to arrive)
+        if constexpr (k == 0) {
+          constexpr int w0 = stream_unit_lo(4, ks, KS), w1 = stream_unit_lo(4, ks + 1, KS);
+          if constexpr (w0 < w1) item_write_word(IntC<w0>{}, pwa, pda, pma);
+        }
+        if constexpr (k == 1 && ks == KS - 1) item_issue(sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
+        sched_fence();
+      }
+    };
+    kstep(IntC<0>{}); kstep(IntC<1>{}); kstep(IntC<2>{}); kstep(IntC<3>{}); kstep(IntC<4>{}); kstep(IntC<5>{});
+    kstep(IntC<6>{}); kstep(IntC<7>{}); kstep(IntC<8>{}); kstep(IntC<9>{}); kstep(IntC<10>{}); kstep(IntC<11>{});
+    kstep(IntC<12>{}); kstep(IntC<13>{}); kstep(IntC<14>{}); kstep(IntC<15>{}); kstep(IntC<16>{}); kstep(IntC<17>{});
+    kstep(IntC<18>{}); kstep(IntC<19>{}); kstep(IntC<20>{}); kstep(IntC<21>{}); kstep(IntC<22>{}); kstep(IntC<23>{});
+    kstep(IntC<24>{}); kstep(IntC<25>{}); kstep(IntC<26>{}); kstep(IntC<27>{}); kstep(IntC<28>{}); kstep(IntC<29>{});
+    kstep(IntC<30>{}); kstep(IntC<31>{}); kstep(IntC<32>{}); kstep(IntC<33>{}); kstep(IntC<34>{}); kstep(IntC<35>{});
+    static_assert(KS <= 36, "kstep calls above");
+    // the drained block was a partial one: its stores, redirected, out of line
+    if (epi_part) epi_partial(epi_u, epi_cx);
+    // this block becomes the one being drained
+    epi_ob = out_base(u, cur);
+    epi_part = (int)(uniform(cur.t[3]) >> 31) != 0;
+    epi_u = u;
+    epi_cx = cur;
+    cur = nxt;
+  };
+
+  for (int T = 0; T < ntile; ++T) {
+    const uint32_t sch1 = sched[T + 1], sch2 = sched[T + 2];
+    step(IntC<0>{}, 4 * T + 0, sch1, sch2);
+    step(IntC<1>{}, 4 * T + 1, sch1, sch2);
+    step(IntC<2>{}, 4 * T + 2, sch1, sch2);
+    step(IntC<3>{}, 4 * T + 3, sch1, sch2);
+    // the rare second item of a tile step's quota
+    if (have_b) item_write(pwb, pdb, pmb);
+    have_b = sch2 - sch1 > 256u;
+    if (have_b) item_issue(sch1 + (uint32_t)(256 + tid), sch2, pwb, pdb, pmb);
+    block_barrier_keep_vm();     // this tile step's rows are visible; the rows it read may be overwritten
+    LCE_SPH(2 + T);
+  }
+
+  // drain: the last block step's accumulators (set 1: block steps come in fours)
+  {
+    wave_lds_order();
+    auto drain_a = [&](auto tc) LCE_LAMBDA_INLINE { epi_a(tc, acc[1]); };
+    drain_a(IntC<0>{}); drain_a(IntC<1>{}); drain_a(IntC<2>{}); drain_a(IntC<3>{});
+    drain_a(IntC<4>{}); drain_a(IntC<5>{}); drain_a(IntC<6>{}); drain_a(IntC<7>{});
+    drain_a(IntC<8>{}); drain_a(IntC<9>{}); drain_a(IntC<10>{}); drain_a(IntC<11>{});
+    drain_a(IntC<12>{}); drain_a(IntC<13>{}); drain_a(IntC<14>{}); drain_a(IntC<15>{});
+    wave_lds_fence();
+    epi_b(IntC<0>{}); epi_b(IntC<1>{}); epi_b(IntC<2>{}); epi_b(IntC<3>{});
+    epi_b(IntC<4>{}); epi_b(IntC<5>{}); epi_b(IntC<6>{}); epi_b(IntC<7>{});
+    epi_c(IntC<0>{}, epi_ob); epi_c(IntC<1>{}, epi_ob); epi_c(IntC<2>{}, epi_ob); epi_c(IntC<3>{}, epi_ob);
+    epi_c(IntC<4>{}, epi_ob); epi_c(IntC<5>{}, epi_ob); epi_c(IntC<6>{}, epi_ob); epi_c(IntC<7>{}, epi_ob);
+    if (epi_part) epi_partial(epi_u, epi_cx);
+  }
+  LCE_SPH(63);
+}
+
+}  // namespace lce

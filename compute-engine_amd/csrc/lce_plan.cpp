@@ -300,6 +300,183 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   return P;
 }
 
+
+// ------------------------------------------------------------------------------------
+// weight-stationary streaming kernel (lce_kernels_stream.h)
+// ------------------------------------------------------------------------------------
+bool stream_supported(const HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  if (!mfma_supported(p) || d.groups != 1) return false;
+  if (d.filter_height != 3 || d.filter_width != 3) return false;          // the instantiated filter extents
+  if (d.dilation_height != 1 || d.dilation_width != 1) return false;       // tap offsets are instruction immediates
+  if (p.zero_pad_mode == kZeroPadCorrection) return false;                 // that epilogue lives in the block GEMM
+  // a lane stores 16 bytes of one pixel's channels: whole groups of 4 floats / 16 int8 only
+  if (d.dst_type == LCE_HIP_F32 && d.channels_out % 4) return false;
+  if (d.dst_type == LCE_HIP_I8 && d.channels_out % 16) return false;
+  const int kch = ceil_div(d.channels_in, 64);
+  return kch == 1 || kch == 2 || kch == 4;                                 // the filter bank must fit the register file
+}
+
+// Simulates a block's stream for segments of `rs` output rows, `spb` segments per block: what each tile step needs
+// resident, a production schedule in quotas of 256 items (one per lane; 512 where 256 would fall behind) that meets
+// it, and the ring rows that keep every row a tile step reads apart from every row it writes.
+static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, int* ring_rows, std::vector<uint32_t>* sched) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const int ow = p.out_w, kh = d.filter_height, sh = d.stride_height;
+  const int srs = (rs - 1) * sh + kh, pbs = ceil_div(rs * ow, 32);
+  const int cpw = ceil_div(d.channels_in, 64) * 2, qg = ceil_div(cpw, 4);
+  const int64_t ipr = (int64_t)d.in_width * qg;
+  const int pph = 1 << pph_log;
+  const int64_t nblk = (int64_t)spb * pbs;
+  const int64_t usteps = (nblk + pph - 1) / pph, ntile = (usteps + 3) / 4;
+  const int64_t total = (int64_t)spb * srs * ipr;
+  if (ntile < 1 || total >= (1ll << 31) || ntile > (1 << 20)) return false;
+  std::vector<int64_t> need(ntile + 2), first(ntile);
+  for (int64_t t = 0; t < ntile; ++t) {
+    int64_t hi = 0, lo = INT64_MAX;
+    for (int64_t q = 4 * t * pph; q < std::min<int64_t>(nblk, 4 * (t + 1) * pph); ++q) {
+      const int64_t gl = q / pbs, pb = q % pbs;
+      const int64_t r_first = std::min<int64_t>(pb * 32 / ow, rs - 1), r_last = std::min<int64_t>((pb * 32 + 31) / ow, rs - 1);
+      lo = std::min(lo, gl * srs + r_first * sh);
+      hi = std::max(hi, gl * srs + r_last * sh + kh - 1);
+    }
+    need[t] = std::min(total, (hi + 1) * ipr);
+    first[t] = lo;
+  }
+  need[ntile] = need[ntile + 1] = need[ntile - 1];
+  for (int64_t t = 1; t < ntile; ++t) need[t] = std::max(need[t], need[t - 1]);
+  // latest production that still works with at most 512 items per tile step ...
+  std::vector<int64_t> m(ntile + 2), s(ntile + 2);
+  m[ntile + 1] = m[ntile] = need[ntile];
+  for (int64_t t = ntile - 1; t >= 0; --t) m[t] = std::max(need[t], m[t + 1] - 512);
+  // ... and going forward, the smallest quota (nothing, one item per lane, two) that keeps up with it
+  s[0] = m[0];
+  for (int64_t t = 0; t <= ntile; ++t) {
+    int64_t inc = 0;
+    while (s[t] + inc < m[t + 1]) inc += 256;
+    s[t + 1] = std::min(total, s[t] + inc);
+    if (s[t + 1] < m[t + 1] || inc > 512) return false;   // cannot happen (m is feasible by construction)
+  }
+  int64_t rows = kh;
+  for (int64_t t = 0; t < ntile; ++t)
+    if (s[t + 1] > 0) rows = std::max(rows, (s[t + 1] - 1) / ipr - first[t] + 1);
+  *ring_rows = (int)rows;
+  sched->resize(ntile + 2);
+  for (int64_t t = 0; t < ntile + 2; ++t) (*sched)[t] = (uint32_t)s[t];
+  return true;
+}
+
+static uint32_t stream_row_bytes(const HostPlan& p) {
+  return p.d.dst_type == LCE_HIP_BITPACKED ? (uint32_t)p.wout * 4u : (uint32_t)p.d.channels_out * (p.d.dst_type == LCE_HIP_I8 ? 1u : 4u);
+}
+
+std::string plan_stream(HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  if (!stream_supported(p))
+    return "bconv2d: the streaming kernel runs ungrouped 3x3 convolutions without dilation, with at most 256 input "
+           "channels (64, 128 or 256 after padding) and whole 16-byte groups of output channels (float: a multiple of 4, "
+           "int8: of 16), and not the SAME-zero correction semantics";
+  const uint32_t row_bytes = stream_row_bytes(p);
+  if ((int64_t)batch_chunk * p.out_h * p.out_w * row_bytes >= (1ll << 31))
+    return "bconv2d: the streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
+  const int nsl = ceil_div(d.channels_out, 64);
+  const int pph_log = nsl >= 3 ? 0 : nsl == 2 ? 1 : 2;
+  const int nslb = 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
+  const int wp = (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
+  const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16;
+  const int cus = std::max(1, p.num_cus / ny);
+  // segment size (a divisor of the output height: every segment is whole): the fewest block steps on the busiest
+  // block (ties: the longer segment, whose halo is re-expanded less)
+  struct Cand { int rs; int64_t cost; };
+  std::vector<Cand> cands;
+  for (int rs = p.out_h; rs >= 1; --rs) {
+    if (p.out_h % rs) continue;
+    if (p.stream_rows_pref > 0 && rs != p.stream_rows_pref) continue;
+    const int64_t s = (int64_t)batch_chunk * (p.out_h / rs), gx = std::min<int64_t>(s, cus), spb = (s + gx - 1) / gx;
+    const int64_t steps = (spb * ceil_div(rs * p.out_w, 32) + pph - 1) / pph;
+    cands.push_back(Cand{rs, steps + 4});
+  }
+  if (cands.empty()) return "bconv2d: stream_rows must divide the output height";
+  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.cost < b.cost; });
+  for (const Cand& c : cands) {
+    const int rs = c.rs, spi = p.out_h / rs;
+    const int64_t s = (int64_t)batch_chunk * spi, gx = std::min<int64_t>(s, cus), spb = (s + gx - 1) / gx;
+    int rows = 0;
+    std::vector<uint32_t> sched;
+    if (!simulate_stream(p, rs, (int)spb, pph_log, &rows, &sched)) continue;
+    const int64_t ring = ((int64_t)rows * wp * ps + 1023) / 1024 * 1024;
+    if (ring + kStreamLdsExtra > 160 * 1024) continue;
+    const int pbs = ceil_div(rs * p.out_w, 32);
+    const int64_t nq = spb * pbs;
+    if (nq * 1024 > (64ll << 20)) continue;               // the context table: 1 KiB per pixel block
+    p.st_rs = rs; p.st_spi = spi; p.st_srs = (rs - 1) * d.stride_height + d.filter_height;
+    p.st_pbs = pbs; p.st_pph_log = pph_log; p.st_ny = ny;
+    p.st_qg = ceil_div(kch * 2, 4); p.st_ipr = d.in_width * p.st_qg;
+    p.st_spb = (int)spb; p.st_gx = (int)ceil_div((int)s, (int)spb); p.st_rows = rows; p.st_ring_bytes = (int)ring;
+    p.st_batch = batch_chunk;
+    p.wp = wp;
+    // ---- the tables: [sched | lim | ctx] ----
+    const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
+    p.st_tab_lim = (uint32_t)(n_sched * 4);
+    p.st_tab_ctx = (uint32_t)((n_sched + n_lim) * 4);
+    p.st_tabs.assign(n_sched + n_lim + (size_t)nq * 256, 0u);
+    std::copy(sched.begin(), sched.end(), p.st_tabs.begin());
+    for (size_t i = sched.size(); i < n_sched; ++i) p.st_tabs[i] = sched.back();
+    const int npx = rs * p.out_w, sh = d.stride_height, sw = d.stride_width;
+    const bool ragged = npx % 32 != 0;
+    for (int64_t q = 0; q < nq; ++q) {
+      const int64_t gl = q / pbs, pb = q % pbs;
+      p.st_tabs[n_sched + q] = (uint32_t)std::min<int64_t>(31, npx - pb * 32 - 1);
+      for (int lane = 0; lane < 64; ++lane) {
+        const int l31 = lane & 31, half = lane >> 5;
+        const int64_t pix = std::min<int64_t>(pb * 32 + l31, npx - 1);     // rows past the segment re-read its last pixel
+        const int64_t r = pix / p.out_w, ox = pix % p.out_w;
+        const int64_t s0 = gl * p.st_srs + r * sh;
+        uint32_t* e = &p.st_tabs[n_sched + n_lim + ((size_t)q * 64 + lane) * 4];
+        for (int fy = 0; fy < 3; ++fy)
+          e[fy] = (uint32_t)((((s0 + fy) % rows) * wp + ox * sw) * ps + half * 16);
+        const int rowl = d.dst_type == LCE_HIP_F32 ? lane >> 4 : d.dst_type == LCE_HIP_I8 ? lane >> 2 : l31;
+        e[3] = (uint32_t)((gl * npx + pb * 32 + rowl) * (int64_t)row_bytes);
+        if (ragged && pb == pbs - 1) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
+      }
+    }
+    return "";
+  }
+  return "bconv2d: the streaming kernel's row ring does not fit LDS for this layer";
+}
+
+StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  StreamArgs G{};
+  G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
+  G.OH = p.out_h; G.OW = p.out_w; G.N = d.channels_out; G.Npad = p.npad; G.Wout = p.wout;
+  G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h; G.PW = p.pad_w;
+  G.B = batch_chunk;
+  G.Wp = p.wp; G.R = p.st_rows; G.ring_bytes = p.st_ring_bytes;
+  G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
+  G.QG = p.st_qg; G.IPR = p.st_ipr; G.RS = p.st_rs; G.SPI = p.st_spi; G.SRS = p.st_srs; G.PBS = p.st_pbs;
+  G.S = batch_chunk * p.st_spi;
+  // a smaller launch than the one planned for (the last chunk of a batch): the same segments and tables, fewer per block
+  const int gx = std::min(G.S, std::max(1, p.num_cus / p.st_ny));
+  G.SPB = std::min(p.st_spb, ceil_div(G.S, std::max(1, gx)));
+  G.pph_log = p.st_pph_log;
+  G.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
+  G.w_bytes = (uint32_t)p.wq.size();
+  G.out_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p));
+  G.tab_bytes = (uint32_t)(p.st_tabs.size() * 4);
+  G.tab_lim = p.st_tab_lim;
+  G.tab_ctx = p.st_tab_ctx;
+  G.a_bt = (float)p.backtransform_add;
+  G.cmin = (float)p.clamp_min;
+  G.cmax = (float)p.clamp_max;
+  G.div_ipr = make_fastdiv((uint32_t)G.IPR);
+  G.div_qg = make_fastdiv((uint32_t)G.QG);
+  G.div_srs = make_fastdiv((uint32_t)G.SRS);
+  G.div_spi = make_fastdiv((uint32_t)G.SPI);
+  G.div_r = make_fastdiv((uint32_t)G.R);
+  return G;
+}
+
 static const MfmaCfg kMfmaCfgs[] = {
     {4, 2, 2, 4},  // 256 x 256, 8 waves
     {4, 2, 2, 2},  // 256 x 128, 8 waves
@@ -547,6 +724,12 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   return G;
 }
 
+// Auto rule for the streaming kernel: see DESIGN.md 4.6 (set from the measurements of profiles/r03/).
+static bool stream_preferred(const HostPlan& p, int64_t pixels) {
+  (void)p; (void)pixels;
+  return false;
+}
+
 std::string select_kernel(HostPlan& p, int64_t pixels) {
   const lce_hip_bconv2d_desc& d = p.d;
   const bool bp = d.dst_type == LCE_HIP_BITPACKED;
@@ -560,6 +743,30 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     return "bconv2d: the pointwise kernel runs 1x1 stride-1 ungrouped convolutions with <= 256 input channels (64, 128 or 256 after padding) and a multiple of 32 output channels";
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
+  p.use_stream = false;
+  if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_preferred(p, pixels))) {
+    // weight-stationary streaming kernel: the planner's FP4 weight image with 64-channel granularity
+    const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
+    const std::string err = plan_stream(p, batch_chunk);
+    if (err.empty()) {
+      const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
+      const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
+      p.mfma = want;
+      p.use_mfma = true;
+      p.use_stream = true;
+      p.use_tiled = false;
+      p.cpad = ceil_div(d.channels_in, 64) * 64;
+      p.npad = ceil_div(d.channels_out, 64) * 64;
+      p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height, (int64_t)(p.out_h - 1) * d.stride_height + d.filter_height);
+      if (repack && p.have_weights) pack_for_mfma(p);
+      char nm[96];
+      snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d>",
+               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.st_rs);
+      p.kernel_name = nm;
+      return "";
+    }
+    if (p.engine_pref == 5) return err;
+  }
   if (p.engine_pref >= 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
                              mfma_supported(p) && pixels * d.channels_out >= (1 << 16))) {
     p.use_mfma = true;

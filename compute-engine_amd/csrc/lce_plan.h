@@ -67,7 +67,8 @@ struct HostPlan {
 
   // matrix-core engine (lce_kernels_mfma.h)
   int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo),
-                                           // 4 pointwise (1x1 streaming kernel, lce_kernels_pointwise.h)
+                                           // 4 pointwise (1x1 streaming kernel, lce_kernels_pointwise.h),
+                                           // 5 stream (weight-stationary persistent kernel, lce_kernels_stream.h)
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int tile_tx = 0, halo_w = 0;             // ... 2-D tiles: tiles across the image (0 = strip tiles), halo width in pixels
@@ -84,6 +85,15 @@ struct HostPlan {
                                            // or the chunks one group's channel slice touches
   std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
   std::vector<float> mul_q, bias_q, thr_q; // Npad entries
+
+  // weight-stationary streaming kernel (lce_kernels_stream.h); with use_mfma
+  bool use_stream = false;
+  int num_cus = 256;                       // compute units of the device (the C ABI fills it in; the stream kernel's grid)
+  int stream_rows_pref = 0;                // tuning aid: output rows per segment (0 = auto)
+  int st_rs = 0, st_spi = 0, st_srs = 0, st_pbs = 0, st_pph_log = 0, st_ny = 1, st_qg = 0, st_ipr = 0;
+  int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images
+  std::vector<uint32_t> st_tabs;           // [sched | lim | ctx]: the kernel's tables (lce_kernel_args.h, StreamArgs)
+  uint32_t st_tab_lim = 0, st_tab_ctx = 0; // byte offsets of lim and ctx inside st_tabs
 
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
@@ -127,5 +137,13 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk);
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 
 ConvArgs make_conv_args(const HostPlan& p, int batch_chunk);
+
+// Streaming kernel: can it run this convolution at all; segment size, grid, ring and production schedule for
+// launches of `batch_chunk` images (fills the st_* fields; "" or why not); its launch constants.
+bool stream_supported(const HostPlan& p);
+std::string plan_stream(HostPlan& p, int batch_chunk);
+StreamArgs make_stream_args(const HostPlan& p, int batch_chunk);
+constexpr int kStreamLdsExtra = 4 * 8192 + 4096;   // four waves' epilogue scratch + the dump area of idle producer lanes
+inline int stream_lds_bytes(const HostPlan& p) { return p.st_ring_bytes + kStreamLdsExtra; }
 
 }  // namespace lce

@@ -88,6 +88,8 @@ void launch_block_lockstep(int grid_x, int grid_y, int block, size_t lds_bytes, 
 
 std::string g_err;
 void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call (float output, matrix-core engine)
+int g_num_cus = 256;          // what the streaming kernel's planner takes for the device's CU count
+int g_stream_rows = 0;        // its segment size (0 = auto)
 
 }  // namespace
 
@@ -96,6 +98,7 @@ extern "C" {
 const char* hostsim_last_error() { return g_err.c_str(); }
 float hostsim_int8_below_threshold(int32_t zero_point) { return int8_below_threshold(zero_point); }
 void hostsim_set_sign_output(void* words) { g_sign_out = words; }
+void hostsim_set_stream(int num_cus, int rows) { g_num_cus = num_cus; g_stream_rows = rows; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
 // engine_pref: 0 auto, 1 valu, 2 mfma
@@ -109,6 +112,8 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   if (!err.empty()) { g_err = err; return 1; }
   fold_parameters(h, filter, post_mul, post_bias, thresholds);
   h.engine_pref = engine_pref;
+  h.num_cus = g_num_cus;
+  h.stream_rows_pref = g_stream_rows;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};
   int chunk = max_batch_per_launch(h);
@@ -132,7 +137,18 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     const ConvArgs A = make_conv_args(h, nb);
     const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
-    if (h.use_mfma && h.use_pointwise) {
+    if (h.use_mfma && h.use_stream) {
+      const StreamArgs G = make_stream_args(h, nb);
+      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G));
+      if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
+      std::vector<uint8_t> wq = h.wq;
+      wq.resize(wq.size() + 64, 0);
+      std::vector<uint32_t> sched = h.st_tabs;
+      sched.resize(sched.size() + 16, 0u);
+      launch_block_lockstep((G.S + G.SPB - 1) / G.SPB, h.st_ny, 256, (size_t)stream_lds_bytes(h), [&] {
+        fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out);
+      });
+    } else if (h.use_mfma && h.use_pointwise) {
       pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const PwArgs P = make_pw_args(h, nb);

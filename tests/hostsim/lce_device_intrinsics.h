@@ -80,6 +80,7 @@ inline float mul_then_add(float a, float b, float c) { volatile float p = a * b;
 inline f32x2 mul_then_add2(f32x2 a, float b, float c) { f32x2 r; r[0] = mul_then_add(a[0], b, c); r[1] = mul_then_add(a[1], b, c); return r; }
 inline f32x2 add2(f32x2 a, f32x2 b) { f32x2 r; { volatile float s = a[0] + b[0]; r[0] = s; } { volatile float s = a[1] + b[1]; r[1] = s; } return r; }
 
+inline f32x2 mul_then_add_pk(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; r[0] = mul_then_add(a[0], b[0], c[0]); r[1] = mul_then_add(a[1], b[1], c[1]); return r; }
 inline void keep_alive(const u32x4&) {}
 
 inline unsigned long long wave_ballot(bool p) {
@@ -170,7 +171,14 @@ template <int N> inline void wait_vmcnt() {     // retire the oldest pieces unti
   }
 }
 inline void wave_lds_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
+inline void wave_lds_order() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
+inline void sched_fence() {}
 inline void pin(f32x16&) {}
+inline void keep_in_agpr(u32x4&) {}
+inline void keep_in_vgpr(u32x4&) {}
+inline void keep_in_vgpr(float&) {}
+inline uint32_t sat_add_u32(uint32_t a, uint32_t b) { const uint64_t r = (uint64_t)a + b; return r > 0xffffffffull ? 0xffffffffu : (uint32_t)r; }
+inline void wave_lds_scratch_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
 template <int N> inline void yield_issue_slots() {}
 template <int N> inline void interleave_mfma_ldsread() {}
 template <int NMFMA, int NDS, int NVMEM> inline void interleave_step() {}
@@ -181,6 +189,19 @@ inline void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
 }
 inline void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
   if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 16);
+}
+// the scalar offset moves the address but is outside the range check (as on the hardware)
+inline void buf_store_streaming_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, f32x4 v) {
+  if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off + uniform_off, &v, 16);
+}
+inline void buf_store_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, u32x4 v) {
+  if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off + uniform_off, &v, 16);
+}
+inline void buf_store2(rsrc_t r, uint32_t lane_off, u32x2 v) {
+  if ((uint64_t)lane_off + 8 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 8);
+}
+inline void buf_store1(rsrc_t r, uint32_t lane_off, uint32_t v) {
+  if ((uint64_t)lane_off + 4 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 4);
 }
 inline f32x4 load_streaming(const f32x4* p) { return *p; }
 inline u32x4 load_streaming(const u32x4* p) { return *p; }

@@ -73,11 +73,16 @@ def bconv2d(spec: O.ConvSpec, dst_type: int, inp, filt, post_mul=None, post_bias
     lib().hostsim_set_sign_output(_p(sign_words))
     rc = lib().hostsim_bconv2d(C.byref(d), _p(filt), _p(mul), _p(bias), _p(thr), _p(inp), _p(out),
                                {"auto": 0, "tiled": 1, "general": 2}[kernel], tile[0], tile[1],
-                               max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3, "pointwise": 4}[engine])
+                               max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3, "pointwise": 4, "stream": 5}[engine])
     lib().hostsim_set_sign_output(None)
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
     return out, name.value.decode()
+
+
+def set_stream(num_cus: int = 256, rows: int = 0):
+    """What the streaming kernel's planner takes for the device's CU count, and its segment size (0 = auto)."""
+    lib().hostsim_set_stream(int(num_cus), int(rows))
 
 
 def bitpack(x: np.ndarray, zero_point: int = 0, force_rows: bool = False) -> np.ndarray:

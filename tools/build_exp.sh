@@ -8,7 +8,7 @@ cd $ROOT/compute-engine_amd/csrc
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   [ "$flags" == "$spec" ] && flags=""
-  ( hipcc $flags -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -I. -Wno-unused-result -shared \
+  ( hipcc $flags -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I. -Wno-unused-result -shared \
       -o $ROOT/build_exp/lib_$name.so lce_hip_api.hip lce_plan.cpp lce_prepare.cpp 2>&1 | grep -E " error|Error" ) &
 done
 wait

@@ -4,7 +4,7 @@ import re
 import subprocess
 import sys
 
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Icompute-engine_amd/csrc",
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Icompute-engine_amd/csrc",
        "-Rpass-analysis=kernel-resource-usage", "-c", "compute-engine_amd/csrc/lce_hip_api.hip", "-o", "/dev/null"]
 txt = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}
