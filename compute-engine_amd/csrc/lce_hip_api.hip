@@ -842,6 +842,14 @@ int lce_hip_debug_read_timeline(void* host, size_t bytes) {
 }
 #endif
 
+#ifdef LCE_STREAM_PHASES
+// profiling aid (tools/stream_phases.py), not part of the ABI: the per-block tile-step stamps of the last stream launch
+int lce_hip_debug_read_stream_tl(void* host, size_t bytes) {
+  if (bytes > sizeof(lce::lce_stream_tl)) bytes = sizeof(lce::lce_stream_tl);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lce::lce_stream_tl), bytes);
+}
+#endif
+
 #ifdef LCE_PHASES
 // profiling aid (tools/phases.py), not part of the ABI: the per-block phase stamps of the last launch
 int lce_hip_debug_read_phases(void* host, size_t bytes) {

@@ -57,6 +57,14 @@ LCE_DEVICE uint32_t fastdiv_nb(uint32_t n, FastDiv d) {
   return (mulhi_u32(n, d.magic) >> d.shift) + (n & one);
 }
 
+// Dword DD of fp4_of_full_word (lce_kernels_mfma.h): byte DD of the word as eight FP4 codes, 4 VALU.
+template <int DD>
+LCE_DEVICE uint32_t fp4_full_dword(uint32_t word) {
+  constexpr uint32_t sel = DD == 0 ? 0x04000400u : DD == 1 ? 0x05010501u : DD == 2 ? 0x06020602u : 0x07030703u;
+  const uint32_t u = pk_lshr_b16<0, 4>(perm_b32(word >> 2, word, sel)) & 0x03030303u;
+  return perm_b32(0u, 0xAAA22A22u, u);
+}
+
 // Units of an epilogue phase that belong to K-step i of n steps (an even spread of `units`).
 constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 
@@ -90,41 +98,6 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   const uint32_t dump = (uint32_t)G.ring_bytes + 4u * 8192u + (uint32_t)lane * 64u;   // where idle lanes' items go
 
   LCE_SPH(0);
-  // ---- the filter bank of this wave's 64 channels, resident for the life of the block ----
-  u32x4 W[KS][2];
-  {
-    const rsrc_t rw = make_rsrc(wq, G.w_bytes);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        W[ks][j] = buf_load(rw, slice_ok ? (uint32_t)((ks * 2 + half) * G.Npad + n0 + j * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
-        // 256 accumulator registers hold the first 32 K-steps' fragments, the rest stay in VGPRs
-        if (ks < 32) keep_in_agpr(W[ks][j]);
-        else keep_in_vgpr(W[ks][j]);
-      }
-  }
-  // per-channel constants of this lane's two channels; multiplier and bias twice each: the transform works on
-  // register pairs (v_pk_mul_f32 / v_pk_add_f32, each element rounded twice as output_transform.h:105 does)
-  float tj[2], uj[2];
-  f32x2 mj[2], bj[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = slice_ok ? n0 + j * 32 + l31 : 0;
-    tj[j] = uj[j] = 0.0f;
-    mj[j] = f32x2{0.0f, 0.0f};
-    bj[j] = f32x2{0.0f, 0.0f};
-    if constexpr (DST == kDstBitpacked) tj[j] = thrf[n];
-    else { mj[j] = f32x2{mul[n], mul[n]}; bj[j] = f32x2{bias[n], bias[n]}; }
-    if constexpr (DST == kDstInt8) { tj[j] = thrf[n]; uj[j] = thrf[G.Npad + n]; }
-  }
-  // the accumulators' start value K_bt as a constant C tile (the first MFMA of every pixel block reads it)
-  f32x16 kbt = f32x16_fill(G.a_bt);
-  pin(kbt);
-  float cminv = G.cmin, cmaxv = G.cmax;     // per-lane copies: the scalar registers are for the loop's addressing
-  keep_in_vgpr(cminv);
-  keep_in_vgpr(cmaxv);
-
   // ---- this block's run of segments ----
   const int g0 = block_idx_x() * G.SPB;
   int nseg = G.S - g0;
@@ -135,45 +108,57 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   const uint32_t* const sched = tabs;
   const rsrc_t rtab = make_rsrc(tabs, G.tab_bytes);
 
-  // ---- the ring: every slot starts as padding (+1 codes, or zeros for exact SAME-zero) ----
-  {
-    const uint32_t code = G.zero_border ? 0u : 0x22222222u;
-    const u32x4 v = {code, code, code, code};
-    for (int o = tid * 16; o < G.ring_bytes; o += 256 * 16) *(u32x4*)(lds0 + o) = v;
-  }
-  block_barrier_keep_vm();
-
   // ---- production: item e of the block's stream = 16 bytes (4 input words) of one input pixel ----
   //   e -> stream row s = e / IPR, pixel x, word group qg; s -> (local segment, row in segment) -> image row iy.
   // Rows outside the image (and images past the batch) are steered to an out-of-range offset and read 0 = the
-  // "+1" padding word, exactly as in the direct variant.
+  // "+1" padding word, exactly as in the direct variant.  Cut into six chunks of a handful of instructions each:
+  // in the K loop a chunk rides behind one MFMA.
   const rsrc_t rin = make_rsrc(xin, G.in_bytes);
-  auto item_issue = [&](uint32_t e, uint32_t e_end, u32x4& wv, uint32_t& dst, int& meta) LCE_LAMBDA_INLINE {
-    const bool on = e < e_end;
-    const uint32_t s = fastdiv_nb(e, G.div_ipr);
-    const uint32_t rem = e - s * (uint32_t)G.IPR;
-    const uint32_t x = fastdiv_nb(rem, G.div_qg);
-    const int c0 = (int)(rem - x * (uint32_t)G.QG) * 4;
-    const uint32_t gl = fastdiv_nb(s, G.div_srs);
-    const int j = (int)(s - gl * (uint32_t)G.SRS);
-    const uint32_t g = (uint32_t)g0 + gl;
-    const uint32_t img = fastdiv_nb(g, G.div_spi);
-    const int c = (int)(g - img * (uint32_t)G.SPI);
-    const int iy = c * G.RS * G.SH - G.PH + j;
-    const bool inside = on && (uint32_t)iy < (uint32_t)G.H && img < (uint32_t)G.B;
-    const uint32_t slot = s - fastdiv_nb(s, G.div_r) * (uint32_t)G.R;
-    dst = on ? (slot * (uint32_t)G.Wp + (uint32_t)G.PW + x) * (uint32_t)PS + (uint32_t)c0 * 16u : dump;
-    meta = c0 | (inside ? 0x100 : 0);
-    const uint32_t off = (uint32_t)(((int)img * G.H + iy) * G.W + (int)x) * (uint32_t)G.Cw * 4u + (uint32_t)c0 * 4u;
-    if constexpr (FAST && KCH == 1) {
-      const u32x2 v2 = buf_load(rin, inside ? off : kOobOffset, (u32x2*)nullptr);
-      wv[0] = v2[0]; wv[1] = v2[1]; wv[2] = 0u; wv[3] = 0u;
-    } else if (FAST || (G.Cw & 3) == 0) {
-      wv = buf_load(rin, inside ? off : kOobOffset, (u32x4*)nullptr);
+  struct Issue {
+    uint32_t s, rem, x, gl, g, img;
+    int c0, iy;
+    bool on, inside;
+  };
+  auto issue_chunk = [&](auto cc_, Issue& I, uint32_t e, uint32_t e_end, u32x4& wv, uint32_t& dst, int& meta) LCE_LAMBDA_INLINE {
+    constexpr int c = decltype(cc_)::value;
+    if constexpr (c == 0) {
+      I.on = e < e_end;
+      I.s = fastdiv_nb(e, G.div_ipr);
+      I.rem = e - I.s * (uint32_t)G.IPR;
+    } else if constexpr (c == 1) {
+      I.x = fastdiv_nb(I.rem, G.div_qg);
+      I.c0 = (int)(I.rem - I.x * (uint32_t)G.QG) * 4;
+    } else if constexpr (c == 2) {
+      I.gl = fastdiv_nb(I.s, G.div_srs);
+      I.g = (uint32_t)g0 + I.gl;
+      I.img = fastdiv_nb(I.g, G.div_spi);
+    } else if constexpr (c == 3) {
+      const int j = (int)(I.s - I.gl * (uint32_t)G.SRS);
+      const int cseg = (int)(I.g - I.img * (uint32_t)G.SPI);
+      I.iy = cseg * G.RS * G.SH - G.PH + j;
+      I.inside = I.on && (uint32_t)I.iy < (uint32_t)G.H && I.img < (uint32_t)G.B;
+    } else if constexpr (c == 4) {
+      const uint32_t slot = I.s - fastdiv_nb(I.s, G.div_r) * (uint32_t)G.R;
+      dst = I.on ? (slot * (uint32_t)G.Wp + (uint32_t)G.PW + I.x) * (uint32_t)PS + (uint32_t)I.c0 * 16u : dump;
+      meta = I.c0 | (I.inside ? 0x100 : 0);
     } else {
+      const uint32_t off = (uint32_t)(((int)I.img * G.H + I.iy) * G.W + (int)I.x) * (uint32_t)G.Cw * 4u + (uint32_t)I.c0 * 4u;
+      if constexpr (FAST && KCH == 1) {
+        const u32x2 v2 = buf_load(rin, I.inside ? off : kOobOffset, (u32x2*)nullptr);
+        wv[0] = v2[0]; wv[1] = v2[1]; wv[2] = 0u; wv[3] = 0u;
+      } else if (FAST || (G.Cw & 3) == 0) {
+        wv = buf_load(rin, I.inside ? off : kOobOffset, (u32x4*)nullptr);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) wv[q] = buf_load(rin, inside && c0 + q < G.Cw ? off + 4u * q : kOobOffset, (uint32_t*)nullptr);
+        for (int q = 0; q < 4; ++q) wv[q] = buf_load(rin, I.inside && I.c0 + q < G.Cw ? off + 4u * q : kOobOffset, (uint32_t*)nullptr);
+      }
     }
+  };
+  auto item_issue = [&](uint32_t e, uint32_t e_end, u32x4& wv, uint32_t& dst, int& meta) LCE_LAMBDA_INLINE {
+    Issue I;
+    issue_chunk(IntC<0>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<1>{}, I, e, e_end, wv, dst, meta);
+    issue_chunk(IntC<2>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<3>{}, I, e, e_end, wv, dst, meta);
+    issue_chunk(IntC<4>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<5>{}, I, e, e_end, wv, dst, meta);
   };
   // word q of an item -> 16 bytes of FP4 in the ring
   auto item_write_word = [&](auto qc, const u32x4& wv, uint32_t dst, int meta) LCE_LAMBDA_INLINE {
@@ -200,20 +185,90 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     item_write_word(IntC<2>{}, wv, dst, meta);
     item_write_word(IntC<3>{}, wv, dst, meta);
   };
-
-  // prologue: everything tile step 0 needs, loads first
-  {
-    const uint32_t need0 = sched[0];
-    for (uint32_t e0 = 0; e0 < need0; e0 += 4u * 256u) {
-      u32x4 wv[4];
-      uint32_t dv[4];
-      int mv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) item_issue(e0 + (uint32_t)(k * 256 + tid), need0, wv[k], dv[k], mv[k]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) item_write(wv[k], dv[k], mv[k]);
+  // ... and in the K loop dword by dword: chunk c = 4 * word + dword of item A (FAST: one output dword = 4 VALU;
+  // otherwise the whole word rides in its last chunk)
+  u32x4 pv = {0u, 0u, 0u, 0u};
+  auto write_chunk = [&](auto cc_, const u32x4& wv, uint32_t dst, int meta) LCE_LAMBDA_INLINE {
+    constexpr int c = decltype(cc_)::value, q = c >> 2, dd = c & 3;
+    if constexpr (q < (KCH * 2 < 4 ? KCH * 2 : 4)) {
+      if constexpr (FAST) {
+        pv[dd] = fp4_full_dword<dd>(wv[q]);
+        if constexpr (dd == 3) *(u32x4*)(lds0 + dst + q * 16) = pv;
+      } else {
+        if constexpr (dd == 3) item_write_word(IntC<q>{}, wv, dst, meta);
+      }
     }
+  };
+
+  // ---- prologue.  The first rows' loads go out FIRST: the memory counter retires in order, so behind the filter
+  // bank's 72 loads per lane they could not be consumed before the whole bank had arrived. ----
+  const uint32_t need0 = sched[0];
+  u32x4 wv0[4];
+  uint32_t dv0[4];
+  int mv0[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) item_issue((uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
+  LCE_SPH(58);
+
+  // the filter bank of this wave's 64 channels, resident for the life of the block
+  u32x4 W[KS][2];
+  {
+    const rsrc_t rw = make_rsrc(wq, G.w_bytes);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        W[ks][j] = buf_load(rw, slice_ok ? (uint32_t)((ks * 2 + half) * G.Npad + n0 + j * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
+    // 256 accumulator registers hold the first 32 K-steps' fragments, the rest stay in VGPRs.  (The hint is a use of
+    // the value: only after ALL loads are in flight -- behind each load it would wait for that load.)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (ks < 32) keep_in_agpr(W[ks][j]);
+        else keep_in_vgpr(W[ks][j]);
+      }
   }
+  LCE_SPH(59);
+  // per-channel constants of this lane's two channels; multiplier and bias twice each: the transform works on
+  // register pairs (v_pk_mul_f32 / v_pk_add_f32, each element rounded twice as output_transform.h:105 does)
+  float tj[2], uj[2];
+  f32x2 mj[2], bj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = slice_ok ? n0 + j * 32 + l31 : 0;
+    tj[j] = uj[j] = 0.0f;
+    mj[j] = f32x2{0.0f, 0.0f};
+    bj[j] = f32x2{0.0f, 0.0f};
+    if constexpr (DST == kDstBitpacked) tj[j] = thrf[n];
+    else { mj[j] = f32x2{mul[n], mul[n]}; bj[j] = f32x2{bias[n], bias[n]}; }
+    if constexpr (DST == kDstInt8) { tj[j] = thrf[n]; uj[j] = thrf[G.Npad + n]; }
+  }
+  // the accumulators' start value K_bt as a constant C tile (the first MFMA of every pixel block reads it)
+  f32x16 kbt = f32x16_fill(G.a_bt);
+  pin(kbt);
+  float cminv = G.cmin, cmaxv = G.cmax;     // per-lane copies: the scalar registers are for the loop's addressing
+  keep_in_vgpr(cminv);
+  keep_in_vgpr(cmaxv);
+
+  // the ring: every slot starts as padding (+1 codes, or zeros for exact SAME-zero)
+  {
+    const uint32_t code = G.zero_border ? 0u : 0x22222222u;
+    const u32x4 v = {code, code, code, code};
+    for (int o = tid * 16; o < G.ring_bytes; o += 256 * 16) *(u32x4*)(lds0 + o) = v;
+  }
+  block_barrier_keep_vm();
+  LCE_SPH(60);
+  // everything tile step 0 needs
+#pragma unroll
+  for (int k = 0; k < 4; ++k) item_write(wv0[k], dv0[k], mv0[k]);
+  for (uint32_t e0 = 4u * 256u; e0 < need0; e0 += 4u * 256u) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) item_issue(e0 + (uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) item_write(wv0[k], dv0[k], mv0[k]);
+  }
+  LCE_SPH(61);
   // The items tile step 0 writes (needed from tile step 1 on) are on their way.  Item A (the first 256 of a tile
   // step's quota) rides between the MFMAs; item B (the rest -- the planner's schedule makes it rare) is handled
   // out of line at the end of a tile step.
@@ -267,6 +322,17 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // float / int8, phase A (16 units): two accumulator registers of tile j = t / 8 -> transformed -> scratch
   //   (register r of a tile holds pixel rows (r & 3) + 8 * (r >> 2) + 4 * half of channel column l31)
   // phase B (8 units): ds_read_b128 of the transposed tile; phase C (8 units): [int8: round + pack] + stores
+  // float(x) * mul + bias, two roundings, on a register pair.  Packed-f32 instructions share the matrix pipe's data
+  // path: beside an MFMA stream each costs a dozen cycles more than its issue slot, so the pair is two scalar
+  // multiplies and two adds (LCE_STREAM_PK_F32: the packed form, for comparison).
+  auto transform2 = [&](f32x2 x, f32x2 m, f32x2 b) LCE_LAMBDA_INLINE -> f32x2 {
+#ifdef LCE_STREAM_PK_F32
+    return mul_then_add_pk(x, m, b);
+#else
+    f32x2 y = {mul_then_add(x[0], m[0], b[0]), mul_then_add(x[1], m[1], b[1])};
+    return y;
+#endif
+  };
   f32x4 yb[8];
   u32x4 pk[2];
   uint32_t bw[2] = {0u, 0u};
@@ -291,10 +357,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       if constexpr (DST == kDstFloat) {
         f32x2 x = {acc[j][r0], acc[j][r0 + 1]};
         if constexpr (CLAMP) { x[0] = med3(x[0], cminv, cmaxv); x[1] = med3(x[1], cminv, cmaxv); }
-        y = mul_then_add_pk(x, mj[j], bj[j]);
+        y = transform2(x, mj[j], bj[j]);
       } else {
         const f32x2 x = {acc[j][r0], acc[j][r0 + 1]};
-        y = mul_then_add_pk(x, mj[j], bj[j]);
+        y = transform2(x, mj[j], bj[j]);
         y[0] = med3(y[0], tj[j], uj[j]);                   // one clamp: see lce_kernels_pointwise.h
         y[1] = med3(y[1], tj[j], uj[j]);
       }
@@ -366,8 +432,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     }
   };
   // which units ride in K-step ks: A in the first 4/9 of the steps, B from the middle on, C at the end
-  constexpr int SA = KS * 4 / 9, SB0 = KS / 2, SBN = (KS * 2 + 8) / 9, SC0 = KS - SBN;
-  static_assert(SA <= SB0 && SB0 + SBN <= SC0, "phase layout");
+  // B's gaps are the K-steps ks >= SB0 with ks % 4 in {2, 3} (SBG of them); C's the last SBN K-steps
+  constexpr int SA = KS * 4 / 9, SB0 = (SA + GA - 1) / GA * GA, SBN = (KS * 2 + 8) / 9, SC0 = KS - SBN;
+  constexpr int SBG_avail = (SC0 - SB0) / GA * 2 + ((SC0 - SB0) % GA > 2 ? (SC0 - SB0) % GA - 2 : 0);
+  constexpr int SBG = SBG_avail >= 4 ? 4 : (SBG_avail >= 2 ? 2 : 1);
+  static_assert(SA <= SB0 && SB0 <= SC0 && SBG_avail >= 1, "phase layout");
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -389,7 +458,15 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   };
 
   // One block step: K loop of pixel block u into accumulator set PAR, with the epilogue of block u - 1
-  // (set PAR ^ 1) and this step's share of the production riding between the MFMAs.
+  // (set PAR ^ 1) and this step's share of the production riding between the MFMAs.  A wave issues in order and an
+  // MFMA waits for the matrix pipe, so fillers hide only DIRECTLY behind an MFMA, a handful (<= 5) at a time: a
+  // K-step is  MFMA . gap 0 . MFMA . gap 1  and every piece of work below is cut to fit a gap:
+  //   gap 0: the next fragment group's four reads (every fourth K-step); phase B reads
+  //   gap 1: phase A units, then the next block's context load, then production chunks, with phase C's stores
+  constexpr int NPG = KS - SA - 1;                          // gap-1 slots behind phase A and the context load
+  uint32_t next_ob = kOobOffset;
+  bool next_part = false;
+  Issue isa;
   auto step = [&](auto kc_, int u, uint32_t sch1, uint32_t sch2) LCE_LAMBDA_INLINE {
     constexpr int k = decltype(kc_)::value, PAR = k & 1;
     if constexpr (k == 0) {
@@ -397,66 +474,107 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #pragma unroll
       for (int d = GA - 1; d >= 0; --d) af[0][d] = *(const u32x4*)(lds0 + frag_addr(cur, d));
     }
-    load_ctx(u + 1, nxt);
     auto kstep = [&](auto ksc) LCE_LAMBDA_INLINE {
       constexpr int ks = decltype(ksc)::value;
       if constexpr (ks < KS) {
         constexpr int g = ks / GA;
-        // the fragments of the NEXT group, all at once (the next block's first group rides at the end, except across
-        // the barrier): one counted wait per group instead of one per K-step
         constexpr int fs = (g + k * NG) & 1;     // the fragment set this block's group g lives in (set 0 after a barrier)
-        if constexpr (ks % GA == 0) {
-          // (issued last-used first: the wait for the group's first fragment then covers the whole group)
+        // ---------------- MFMA 0 ----------------
+        if constexpr (ks == 0) acc[PAR][0] = mfma_fp4_32x32x64(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
+        else acc[PAR][0] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
+        pin(acc[PAR][0]);    // (an MFMA has no side effect the sched_fence could hold: the pin keeps it in place)
+        sched_fence();       // ... alone in its scheduling region: no filler may slip in FRONT of it
+        // ---------------- gap 0 ----------------
+#ifndef LCE_ST_NOFRAG   // timing ablation (results are wrong): no fragment reads in the K loop
+        // The fragments of the NEXT group (the next block's first group rides at the end, except across the barrier),
+        // two reads behind each of the group's first two MFMA 0s (more than two LDS reads per gap queue up behind the
+        // other waves'), issued last-used first: the counted wait for the group's first fragment covers the group.
+        if constexpr (ks % GA < 2) {
+          constexpr int d1 = GA - 1 - 2 * (ks % GA), d0 = d1 - 1;      // fragments 3, 2 then 1, 0
           if constexpr (g + 1 < NG) {
-#pragma unroll
-            for (int d = GA - 1; d >= 0; --d)
-              if ((g + 1) * GA + d < KS) af[fs ^ 1][d] = *(const u32x4*)(lds0 + frag_addr(cur, (g + 1) * GA + d));
+            if constexpr ((g + 1) * GA + d1 < KS) af[fs ^ 1][d1] = *(const u32x4*)(lds0 + frag_addr(cur, (g + 1) * GA + d1));
+            if constexpr ((g + 1) * GA + d0 < KS) af[fs ^ 1][d0] = *(const u32x4*)(lds0 + frag_addr(cur, (g + 1) * GA + d0));
           } else if constexpr (k < 3) {
-#pragma unroll
-            for (int d = GA - 1; d >= 0; --d) af[fs ^ 1][d] = *(const u32x4*)(lds0 + frag_addr(nxt, d));
+            af[fs ^ 1][d1] = *(const u32x4*)(lds0 + frag_addr(nxt, d1));
+            af[fs ^ 1][d0] = *(const u32x4*)(lds0 + frag_addr(nxt, d0));
+            if constexpr (KS - (NG - 1) * GA < 2) {     // a last group of one K-step: all four reads behind it
+              af[fs ^ 1][1] = *(const u32x4*)(lds0 + frag_addr(nxt, 1));
+              af[fs ^ 1][0] = *(const u32x4*)(lds0 + frag_addr(nxt, 0));
+            }
           }
         }
-        if constexpr (ks == 0) {
-          acc[PAR][0] = mfma_fp4_32x32x64(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
-          acc[PAR][1] = mfma_fp4_32x32x64(af[fs][0], W[0][1], kbt);
-        } else {
-          acc[PAR][0] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
-          acc[PAR][1] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][1], acc[PAR][1]);
-        }
-        pin(acc[PAR][0]);    // the MFMAs stay in THIS K-step (they have no side effects the sched_fence could hold)
-        pin(acc[PAR][1]);
-        // ---- fillers ----
-        if constexpr (ks < SA) {
-          constexpr int lo = stream_unit_lo(16, ks, SA), hi = stream_unit_lo(16, ks + 1, SA);
-          if constexpr (lo == 0) wave_lds_order();     // the scratch's previous readers are done (in-order LDS)
-          if constexpr (lo + 0 < hi) epi_a(IntC<lo + 0>{}, acc[PAR ^ 1]);
-          if constexpr (lo + 1 < hi) epi_a(IntC<lo + 1>{}, acc[PAR ^ 1]);
-          if constexpr (lo + 2 < hi) epi_a(IntC<lo + 2>{}, acc[PAR ^ 1]);
-          if constexpr (lo + 3 < hi) epi_a(IntC<lo + 3>{}, acc[PAR ^ 1]);
-          static_assert(hi - lo <= 4, "units per step");
-        }
-        if constexpr (ks >= SB0 && ks < SB0 + SBN) {
-          constexpr int lo = stream_unit_lo(8, ks - SB0, SBN), hi = stream_unit_lo(8, ks - SB0 + 1, SBN);
-          if constexpr (lo == 0) wave_lds_scratch_fence();   // phase A's writes before phase B's reads
+#endif
+#ifndef LCE_ST_NOEPI    // timing ablation (results are wrong): no epilogue units
+        // phase B: two reads per gap, in the gaps the fragment reads leave free
+        if constexpr (ks >= SB0 && ks % GA >= 2 && (ks - SB0) / GA * 2 + (ks % GA - 2) < SBG) {
+          constexpr int slot = (ks - SB0) / GA * 2 + (ks % GA - 2);
+          constexpr int lo = stream_unit_lo(8, slot, SBG), hi = stream_unit_lo(8, slot + 1, SBG);
+          if constexpr (slot == 0) wave_lds_scratch_fence();   // phase A's writes before phase B's reads
+#ifndef LCE_ST_NOEPI_B
           if constexpr (lo + 0 < hi) epi_b(IntC<lo + 0>{});
           if constexpr (lo + 1 < hi) epi_b(IntC<lo + 1>{});
           if constexpr (lo + 2 < hi) epi_b(IntC<lo + 2>{});
           if constexpr (lo + 3 < hi) epi_b(IntC<lo + 3>{});
-          static_assert(hi - lo <= 4, "units per step");
+          if constexpr (lo + 4 < hi) epi_b(IntC<lo + 4>{});
+          if constexpr (lo + 5 < hi) epi_b(IntC<lo + 5>{});
+          if constexpr (lo + 6 < hi) epi_b(IntC<lo + 6>{});
+          if constexpr (lo + 7 < hi) epi_b(IntC<lo + 7>{});
+#endif
+        }
+#endif
+        if constexpr (ks == 1) {       // what the NEXT step's drain of this block needs
+          next_ob = out_base(u, cur);
+          next_part = (int)(uniform(cur.t[3]) >> 31) != 0;
+        }
+        sched_fence();
+        // ---------------- MFMA 1 ----------------
+        if constexpr (ks == 0) acc[PAR][1] = mfma_fp4_32x32x64(af[fs][0], W[0][1], kbt);
+        else acc[PAR][1] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][1], acc[PAR][1]);
+        pin(acc[PAR][1]);
+        sched_fence();
+        // ---------------- gap 1 ----------------
+#ifndef LCE_ST_NOEPI
+        if constexpr (ks < SA) {
+          constexpr int lo = stream_unit_lo(16, ks, SA), hi = stream_unit_lo(16, ks + 1, SA);
+          if constexpr (lo == 0) wave_lds_order();     // the scratch's previous readers are done (in-order LDS)
+#ifndef LCE_ST_NOEPI_A
+          if constexpr (lo + 0 < hi) epi_a(IntC<lo + 0>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 1 < hi) epi_a(IntC<lo + 1>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 2 < hi) epi_a(IntC<lo + 2>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 3 < hi) epi_a(IntC<lo + 3>{}, acc[PAR ^ 1]);
+#endif
+          static_assert(hi - lo <= 4, "units per gap");
         }
         if constexpr (ks >= SC0) {
           constexpr int lo = stream_unit_lo(8, ks - SC0, SBN), hi = stream_unit_lo(8, ks - SC0 + 1, SBN);
+#ifndef LCE_ST_NOEPI_C
           if constexpr (lo + 0 < hi) epi_c(IntC<lo + 0>{}, epi_ob);
           if constexpr (lo + 1 < hi) epi_c(IntC<lo + 1>{}, epi_ob);
           if constexpr (lo + 2 < hi) epi_c(IntC<lo + 2>{}, epi_ob);
           if constexpr (lo + 3 < hi) epi_c(IntC<lo + 3>{}, epi_ob);
+#endif
         }
-        // production: block step 0 expands item A, block step 1 issues the next one (three block steps to arrive)
-        if constexpr (k == 0) {
-          constexpr int w0 = stream_unit_lo(4, ks, KS), w1 = stream_unit_lo(4, ks + 1, KS);
-          if constexpr (w0 < w1) item_write_word(IntC<w0>{}, pwa, pda, pma);
+#endif
+        if constexpr (ks == SA) load_ctx(u + 1, nxt);
+#ifndef LCE_ST_NOPROD   // timing ablation (results are wrong): no production between the MFMAs
+        // production: block step 0 expands item A (16 chunks), block step 1 issues the next one (6 chunks; its load
+        // has three block steps to arrive)
+        if constexpr (ks > SA) {
+          if constexpr (k == 0) {
+            constexpr int lo = stream_unit_lo(16, ks - SA - 1, NPG), hi = stream_unit_lo(16, ks - SA, NPG);
+            if constexpr (lo + 0 < hi) write_chunk(IntC<lo + 0>{}, pwa, pda, pma);
+            if constexpr (lo + 1 < hi) write_chunk(IntC<lo + 1>{}, pwa, pda, pma);
+            if constexpr (lo + 2 < hi) write_chunk(IntC<lo + 2>{}, pwa, pda, pma);
+            if constexpr (lo + 3 < hi) write_chunk(IntC<lo + 3>{}, pwa, pda, pma);
+            static_assert(hi - lo <= 4, "chunks per gap");
+          } else if constexpr (k == 1) {
+            constexpr int lo = stream_unit_lo(6, ks - SA - 1, NPG), hi = stream_unit_lo(6, ks - SA, NPG);
+            if constexpr (lo + 0 < hi) issue_chunk(IntC<lo + 0>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
+            if constexpr (lo + 1 < hi) issue_chunk(IntC<lo + 1>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
+            static_assert(hi - lo <= 2, "chunks per gap");
+          }
         }
-        if constexpr (k == 1 && ks == KS - 1) item_issue(sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
+#endif
         sched_fence();
       }
     };
@@ -470,8 +588,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     // the drained block was a partial one: its stores, redirected, out of line
     if (epi_part) epi_partial(epi_u, epi_cx);
     // this block becomes the one being drained
-    epi_ob = out_base(u, cur);
-    epi_part = (int)(uniform(cur.t[3]) >> 31) != 0;
+    epi_ob = next_ob;
+    epi_part = next_part;
     epi_u = u;
     epi_cx = cur;
     cur = nxt;
