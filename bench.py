@@ -169,7 +169,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (weak scaling: the global batch is N times this)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total images over all GPUs (strong scaling: BASELINE config 4 is --gpus 8 --global-batch 2048); "
+                         "overrides --batch")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="measure roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) "
+                         "over the same layer (rank 0, N == 1)")
     ap.add_argument("--spinup-ms", type=float, default=40.0, help="untimed clock spin-up before the warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -205,8 +211,10 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    # weak scaling: the global batch grows with N, every rank owns a contiguous slab of it
-    global_batch = args.batch * world
+    # weak scaling (default): the global batch grows with N; --global-batch fixes it (strong scaling).  Either way
+    # every rank owns a contiguous slab of it
+    strong = args.global_batch > 0
+    global_batch = args.global_batch if strong else args.batch * world
     _, my_batch = shard.shard_range(global_batch, world, rank)
     spec = SL.Layer(batch=my_batch, padding=SL.PADDING_SAME, pad_values=1, **L0)
     # warm up + per-step time from stream events (a step = every kernel of one LceBconv2d call)
@@ -242,23 +250,24 @@ def main():
     elapsed = shard.max_over_ranks(elapsed_local, dist, dev)
     per_rank = shard.gather_over_ranks(elapsed_local, dist, dev)
 
-    total_bmacs = spec.binary_macs * args.steps * world
+    per_image_bmacs = spec.binary_macs // max(1, my_batch)
+    total_bmacs = per_image_bmacs * global_batch * args.steps
     value = total_bmacs / elapsed
     abytes = spec.algorithmic_bytes(SL.DST_F32)
-    mfma = kname.startswith("bconv2d_mfma")
-    direct = kname.startswith("bconv2d_mfma_direct")   # single kernel: the block expands its own input halo
+    mfma = kname.startswith(("bconv2d_mfma", "bconv2d_stream", "bconv2d_pointwise"))   # the matrix-core engine's kernels
+    direct = not kname.startswith("bconv2d_mfma<")     # single kernel: the block expands its own input halo
 
     result = {
         "metric": "binary-MACs/sec (LceBconv2d 3x3 256->256, 56x56, batch 256/GPU, f32 out)",
         "value": value, "unit": "binary-MAC/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": ("fp4-e2m1 (exact +-1) matrix-core dot product, fp32 accumulate, f32 epilogue" if mfma
                   else "u32 xor+popcount, int32 accumulate, f32 epilogue"),
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: LceBconv2d 3x3 s1 SAME(pad_values=1) 56x56x256->256, "
                                "float32 output transform, device-resident bitpacked input",
-                   "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "per_gpu_batch": my_batch if strong else args.batch, "global_batch": global_batch,
                    "parallelism": f"batch-shard x{world} (no data-path collective)"},
         "layer_latency_ms": step_sec * 1e3,
         "clock_spin_up": {"ms": args.spinup_ms, "launches": spin_launches, "note": "untimed, before the W warmup steps"},
@@ -283,7 +292,9 @@ def main():
         ach = abytes / k_sec / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if args.measure_traffic and world == 1:
+            traffic, traffic_src = measure_traffic(kname, my_batch)
+        if traffic is None and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(kname, {}).get("hbm_bytes_per_launch")
                 traffic_src = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this kernel, not measured in this run)"
@@ -314,6 +325,44 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measure_traffic(kname, batch):
+    """HBM bytes per launch of the bench kernel from two rocprofv3 --pmc passes over tools/run_one.py (the same layer, plan
+    and operands; counters collected in their own runs, --kernel-trace only), corrected as MI355X_MICROARCH.md prescribes:
+    both counters are in KiB, and on gfx950 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read (x2;
+    calibrated in profiles/pmc_traffic.json on the LceQuantize stream, whose byte count is exact)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found: traffic not measured"
+    tmp = tempfile.mkdtemp(prefix="lce_pmc_", dir="/tmp")
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "run_one.py"), "56", "256", "f32", "auto", "auto", "10",
+                                str(batch)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): traffic not measured"
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr and row["Kernel_Name"].split("(")[0].find("bconv2d") >= 0:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, f"no {ctr} rows for the bench kernel: traffic not measured"
+            got[ctr] = sum(per.values()) / len(per) * 1024.0, len(per)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, writes = got["FETCH_SIZE"][0] * 2.0, got["WRITE_SIZE"][0]
+    return int(fetch + writes), (f"measured in this run: rocprofv3 --pmc FETCH_SIZE ({got['FETCH_SIZE'][1]} launches, raw "
+                                 f"{got['FETCH_SIZE'][0]:.0f} B x2 = {fetch:.0f} B) + --pmc WRITE_SIZE ({got['WRITE_SIZE'][1]} "
+                                 f"launches, {writes:.0f} B), separate passes over tools/run_one.py, kernel {kname}")
 
 
 def extra_measurements(amd, torch, spec, args, dev):

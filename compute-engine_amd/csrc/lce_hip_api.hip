@@ -604,7 +604,14 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
         LCE_HIP_TRY(hipGetLastError());
       } else {
         const size_t ws = lce::mfma_workspace_bytes(h, nb);
-        if (plan->ws_used && plan->ws_stream != st) LCE_HIP_TRY(hipStreamWaitEvent(st, plan->ws_done, 0));
+        // While `st` is being captured into a graph the cross-stream ordering is left to the capture's own stream order:
+        // an event recorded inside a capture belongs to the graph and must not be waited on or synchronised from outside.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        if (capturing && plan->workspace_bytes < ws)
+          return fail(LCE_HIP_ERR_INVALID, "bconv2d_run: the FP4 workspace must exist before a stream capture (run the plan once first)");
+        if (!capturing && plan->ws_used && plan->ws_stream != st) LCE_HIP_TRY(hipStreamWaitEvent(st, plan->ws_done, 0));
         if (plan->workspace_bytes < ws) {
           // a larger workspace: the old one may still be read by a run in flight on another stream
           if (plan->ws_used) LCE_HIP_TRY(hipEventSynchronize(plan->ws_done));
@@ -628,10 +635,12 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
         } else {
           sign_fused = true;   // profiling mode "expand only": nothing to quantize
         }
-        if (!plan->ws_done) LCE_HIP_TRY(hipEventCreateWithFlags(&plan->ws_done, hipEventDisableTiming));
-        LCE_HIP_TRY(hipEventRecord(plan->ws_done, st));
-        plan->ws_stream = st;
-        plan->ws_used = true;
+        if (!capturing) {
+          if (!plan->ws_done) LCE_HIP_TRY(hipEventCreateWithFlags(&plan->ws_done, hipEventDisableTiming));
+          LCE_HIP_TRY(hipEventRecord(plan->ws_done, st));
+          plan->ws_stream = st;
+          plan->ws_used = true;
+        }
       }
     } else if (h.use_tiled) {
       tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
@@ -733,22 +742,39 @@ lce_hip_status lce_hip_bconv2d_run_host(lce_hip_bconv2d_plan* plan, const int32_
     plan->ev_in.push_back(a);
     plan->ev_run.push_back(b);
   }
+  // on a failure mid-pipeline the copies already queued still read / write the caller's buffers: wait for them before
+  // reporting it
+  auto drain_and = [&](lce_hip_status s) {
+    const std::string keep = g_last_error;
+    (void)hipStreamSynchronize(plan->s_h2d);
+    (void)hipStreamSynchronize(plan->s_run);
+    (void)hipStreamSynchronize(plan->s_d2h);
+    (void)hipGetLastError();
+    g_last_error = keep;
+    return s;
+  };
+#define LCE_HIP_TRY_DRAIN(expr)                                                                            \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess) return drain_and(fail(LCE_HIP_ERR_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
   const int base = h.d.batch / slices, extra = h.d.batch % slices;
   int first = 0;
   for (int k = 0; k < slices; ++k) {
     const int count = base + (k < extra ? 1 : 0);
-    LCE_HIP_TRY(hipMemcpyAsync((char*)plan->stage_in + first * in_img, (const char*)input_host + first * in_img,
+    LCE_HIP_TRY_DRAIN(hipMemcpyAsync((char*)plan->stage_in + first * in_img, (const char*)input_host + first * in_img,
                                count * in_img, hipMemcpyHostToDevice, plan->s_h2d));
-    LCE_HIP_TRY(hipEventRecord(plan->ev_in[k], plan->s_h2d));
-    LCE_HIP_TRY(hipStreamWaitEvent(plan->s_run, plan->ev_in[k], 0));
+    LCE_HIP_TRY_DRAIN(hipEventRecord(plan->ev_in[k], plan->s_h2d));
+    LCE_HIP_TRY_DRAIN(hipStreamWaitEvent(plan->s_run, plan->ev_in[k], 0));
     if (lce_hip_status s = run_images(plan, (const int32_t*)plan->stage_in, plan->stage_out, nullptr, first, count, plan->s_run))
-      return s;
-    LCE_HIP_TRY(hipEventRecord(plan->ev_run[k], plan->s_run));
-    LCE_HIP_TRY(hipStreamWaitEvent(plan->s_d2h, plan->ev_run[k], 0));
-    LCE_HIP_TRY(hipMemcpyAsync((char*)output_host + first * out_img, (const char*)plan->stage_out + first * out_img,
+      return drain_and(s);
+    LCE_HIP_TRY_DRAIN(hipEventRecord(plan->ev_run[k], plan->s_run));
+    LCE_HIP_TRY_DRAIN(hipStreamWaitEvent(plan->s_d2h, plan->ev_run[k], 0));
+    LCE_HIP_TRY_DRAIN(hipMemcpyAsync((char*)output_host + first * out_img, (const char*)plan->stage_out + first * out_img,
                                count * out_img, hipMemcpyDeviceToHost, plan->s_d2h));
     first += count;
   }
+#undef LCE_HIP_TRY_DRAIN
   LCE_HIP_TRY(hipStreamSynchronize(plan->s_d2h));   // the last slice's copy is the last thing queued anywhere
   LCE_HIP_TRY(hipStreamSynchronize(plan->s_run));
   return LCE_HIP_OK;

@@ -111,38 +111,48 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // ---- production: item e of the block's stream = 16 bytes (4 input words) of one input pixel ----
   //   e -> stream row s = e / IPR, pixel x, word group qg; s -> (local segment, row in segment) -> image row iy.
   // Rows outside the image (and images past the batch) are steered to an out-of-range offset and read 0 = the
-  // "+1" padding word, exactly as in the direct variant.  Cut into six chunks of a handful of instructions each:
+  // "+1" padding word, exactly as in the direct variant.  Cut into twelve chunks of a handful of instructions each:
   // in the K loop a chunk rides behind one MFMA.
   const rsrc_t rin = make_rsrc(xin, G.in_bytes);
   struct Issue {
-    uint32_t s, rem, x, gl, g, img;
-    int c0, iy;
+    uint32_t s, rem, x, gl, g, img, slot, t;
+    int c0, iy, cseg;
     bool on, inside;
   };
+  constexpr int kIssueChunks = 12;
   auto issue_chunk = [&](auto cc_, Issue& I, uint32_t e, uint32_t e_end, u32x4& wv, uint32_t& dst, int& meta) LCE_LAMBDA_INLINE {
     constexpr int c = decltype(cc_)::value;
     if constexpr (c == 0) {
       I.on = e < e_end;
       I.s = fastdiv_nb(e, G.div_ipr);
-      I.rem = e - I.s * (uint32_t)G.IPR;
     } else if constexpr (c == 1) {
+      I.rem = e - I.s * (uint32_t)G.IPR;
       I.x = fastdiv_nb(I.rem, G.div_qg);
-      I.c0 = (int)(I.rem - I.x * (uint32_t)G.QG) * 4;
     } else if constexpr (c == 2) {
+      I.c0 = (int)(I.rem - I.x * (uint32_t)G.QG) * 4;
       I.gl = fastdiv_nb(I.s, G.div_srs);
+    } else if constexpr (c == 3) {
       I.g = (uint32_t)g0 + I.gl;
       I.img = fastdiv_nb(I.g, G.div_spi);
-    } else if constexpr (c == 3) {
-      const int j = (int)(I.s - I.gl * (uint32_t)G.SRS);
-      const int cseg = (int)(I.g - I.img * (uint32_t)G.SPI);
-      I.iy = cseg * G.RS * G.SH - G.PH + j;
-      I.inside = I.on && (uint32_t)I.iy < (uint32_t)G.H && I.img < (uint32_t)G.B;
     } else if constexpr (c == 4) {
-      const uint32_t slot = I.s - fastdiv_nb(I.s, G.div_r) * (uint32_t)G.R;
-      dst = I.on ? (slot * (uint32_t)G.Wp + (uint32_t)G.PW + I.x) * (uint32_t)PS + (uint32_t)I.c0 * 16u : dump;
+      I.cseg = (int)(I.g - I.img * (uint32_t)G.SPI);
+      I.iy = (int)(I.s - I.gl * (uint32_t)G.SRS) - G.PH;
+    } else if constexpr (c == 5) {
+      I.iy += I.cseg * (G.RS * G.SH);
+      I.inside = I.on && (uint32_t)I.iy < (uint32_t)G.H && I.img < (uint32_t)G.B;
+    } else if constexpr (c == 6) {
+      I.slot = I.s - fastdiv_nb(I.s, G.div_r) * (uint32_t)G.R;
+    } else if constexpr (c == 7) {
+      I.t = (I.slot * (uint32_t)G.Wp + (uint32_t)G.PW + I.x) * (uint32_t)PS;
+    } else if constexpr (c == 8) {
+      dst = I.on ? I.t + (uint32_t)I.c0 * 16u : dump;
       meta = I.c0 | (I.inside ? 0x100 : 0);
+    } else if constexpr (c == 9) {
+      I.t = (uint32_t)((int)I.img * G.H + I.iy) * (uint32_t)G.W;
+    } else if constexpr (c == 10) {
+      I.t = (I.t + I.x) * (uint32_t)G.Cw * 4u + (uint32_t)I.c0 * 4u;
     } else {
-      const uint32_t off = (uint32_t)(((int)I.img * G.H + I.iy) * G.W + (int)I.x) * (uint32_t)G.Cw * 4u + (uint32_t)I.c0 * 4u;
+      const uint32_t off = I.t;
       if constexpr (FAST && KCH == 1) {
         const u32x2 v2 = buf_load(rin, I.inside ? off : kOobOffset, (u32x2*)nullptr);
         wv[0] = v2[0]; wv[1] = v2[1]; wv[2] = 0u; wv[3] = 0u;
@@ -159,6 +169,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     issue_chunk(IntC<0>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<1>{}, I, e, e_end, wv, dst, meta);
     issue_chunk(IntC<2>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<3>{}, I, e, e_end, wv, dst, meta);
     issue_chunk(IntC<4>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<5>{}, I, e, e_end, wv, dst, meta);
+    issue_chunk(IntC<6>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<7>{}, I, e, e_end, wv, dst, meta);
+    issue_chunk(IntC<8>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<9>{}, I, e, e_end, wv, dst, meta);
+    issue_chunk(IntC<10>{}, I, e, e_end, wv, dst, meta); issue_chunk(IntC<11>{}, I, e, e_end, wv, dst, meta);
+    static_assert(kIssueChunks == 12, "calls above");
   };
   // word q of an item -> 16 bytes of FP4 in the ring
   auto item_write_word = [&](auto qc, const u32x4& wv, uint32_t dst, int meta) LCE_LAMBDA_INLINE {
@@ -557,7 +571,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         if constexpr (ks == SA) load_ctx(u + 1, nxt);
 #ifndef LCE_ST_NOPROD   // timing ablation (results are wrong): no production between the MFMAs
-        // production: block step 0 expands item A (16 chunks), block step 1 issues the next one (6 chunks; its load
+        // production: block step 0 expands item A (16 chunks), block step 1 issues the next one (12 chunks; its load
         // has three block steps to arrive)
         if constexpr (ks > SA) {
           if constexpr (k == 0) {
@@ -568,10 +582,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
             if constexpr (lo + 3 < hi) write_chunk(IntC<lo + 3>{}, pwa, pda, pma);
             static_assert(hi - lo <= 4, "chunks per gap");
           } else if constexpr (k == 1) {
-            constexpr int lo = stream_unit_lo(6, ks - SA - 1, NPG), hi = stream_unit_lo(6, ks - SA, NPG);
+            constexpr int lo = stream_unit_lo(kIssueChunks, ks - SA - 1, NPG), hi = stream_unit_lo(kIssueChunks, ks - SA, NPG);
             if constexpr (lo + 0 < hi) issue_chunk(IntC<lo + 0>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
             if constexpr (lo + 1 < hi) issue_chunk(IntC<lo + 1>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
-            static_assert(hi - lo <= 2, "chunks per gap");
+            if constexpr (lo + 2 < hi) issue_chunk(IntC<lo + 2>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
+            static_assert(hi - lo <= 3, "chunks per gap");
           }
         }
 #endif

@@ -292,7 +292,8 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   P.noclamp = (p.clamp_min <= 0 && (int64_t)p.clamp_max >= 2 * (int64_t)p.backtransform_add) ? 1 : 0;
   P.in_bytes = (uint32_t)(m * p.cw * 4);
   const int64_t row = d.dst_type == LCE_HIP_BITPACKED ? (int64_t)p.wout * 4 : (int64_t)d.channels_out * (d.dst_type == LCE_HIP_I8 ? 1 : 4);
-  P.out_bytes = (uint32_t)(m * row);
+  // (max_batch_per_launch keeps a launch's output below 2 GiB: the kernel's offsets are 32-bit)
+  P.out_bytes = (uint32_t)std::min<int64_t>(m * row, (1ll << 31) - 1);
   P.a_bt = (float)p.backtransform_add;
   P.cmin = (float)p.clamp_min;
   P.cmax = (float)p.clamp_max;
@@ -724,10 +725,20 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   return G;
 }
 
-// Auto rule for the streaming kernel: see DESIGN.md 4.6 (set from the measurements of profiles/r03/).
-static bool stream_preferred(const HostPlan& p, int64_t pixels) {
-  (void)p; (void)pixels;
-  return false;
+// Auto rule for the streaming kernel (profiles/r03/stream_vs_block_gemm.txt, batch 256): with a 3x3x256 filter bank
+// (36 K-steps per pixel block) it beats the block GEMM on every output type -- 56x56: float 0.188 vs 0.239 ms, int8
+// 0.175 vs 0.215, bitpacked 0.148 vs 0.162; 14x14: float 20.8 vs 23.6 us -- with 128 or 64 input channels a pixel
+// block has too few MFMAs to carry its epilogue and it loses (28x28x128 float 29.1 vs 27.5 us, 56x56x64 47.8 vs 40.7).
+// A launch must also fill the chip: at least three quarters of the CUs get a block, a block runs long enough
+// (>= 6 block steps) to pay for loading its filter bank, and segments are not slivers.
+static bool stream_candidate(const HostPlan& p) {
+  return stream_supported(p) && ceil_div(p.d.channels_in, 64) == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
+}
+static bool stream_worthwhile(const HostPlan& p) {
+  const int cus = std::max(1, p.num_cus / p.st_ny);
+  const int64_t steps = ((int64_t)p.st_spb * p.st_pbs + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
+  // (segments of fewer than 4 rows re-expand their halo rows more than 1.5 times: left to the block GEMM)
+  return p.st_gx * 4 >= cus * 3 && steps >= 6 && (p.st_rs >= 4 || p.st_rs == p.out_h);
 }
 
 std::string select_kernel(HostPlan& p, int64_t pixels) {
@@ -744,11 +755,11 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   p.use_stream = false;
-  if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_preferred(p, pixels))) {
+  if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_candidate(p))) {
     // weight-stationary streaming kernel: the planner's FP4 weight image with 64-channel granularity
     const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
     const std::string err = plan_stream(p, batch_chunk);
-    if (err.empty()) {
+    if (err.empty() && (p.engine_pref == 5 || stream_worthwhile(p))) {
       const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
       const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
       p.mfma = want;
@@ -790,8 +801,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
         // forced: take any tile whose halo fits, whatever the padding waste
         for (int bm : {128, 256}) {
           const MfmaCfg* c = mfma_cfg_by_tile(bm, d.channels_out > 64 && (d.groups == 1 || p.npg % 128 == 0) ? 128 : 64);
-          int a, b, c2, e, f;
-          if (c && direct_geometry(p, *c, &a, &b, &c2, &e, &f, kDirectLdsMax)) { want = *c; direct = true; break; }
+          int a, b, c2, e, f, ttx, hw;   // (with the 2-D tile outputs: a wide image's strip may not fit where its 2-D tile does)
+          if (c && direct_geometry(p, *c, &a, &b, &c2, &e, &f, kDirectLdsMax, &ttx, &hw)) { want = *c; direct = true; break; }
         }
         if (!direct) direct = true;  // reported below by direct_geometry
       }
@@ -897,6 +908,11 @@ int max_batch_per_launch(const HostPlan& p) {
     const int64_t wp = std::max<int64_t>(p.pad_w + p.d.in_width,
                                          (int64_t)(p.out_w - 1) * p.d.stride_width + (p.d.filter_width - 1) * p.d.dilation_width + 1);
     b = std::min<int64_t>(b, (int64_t)(((1ll << 31) - 1) / (hp * wp * (cpad / 2))));
+    // the pointwise and the streaming kernel address a whole launch's output through ONE buffer resource with 32-bit
+    // byte offsets (an out-of-range marker is offset 2^31): a launch's output stays below 2 GiB
+    const int64_t out_row = p.d.dst_type == LCE_HIP_BITPACKED ? (int64_t)p.wout * 4
+                                                               : (int64_t)p.d.channels_out * (p.d.dst_type == LCE_HIP_I8 ? 1 : 4);
+    b = std::min<int64_t>(b, ((1ll << 31) - 1) / std::max<int64_t>(1, per_image_pixels * out_row));
   }
   b = std::max<int64_t>(1, std::min<int64_t>(b, p.d.batch));
   return (int)b;

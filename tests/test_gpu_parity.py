@@ -557,6 +557,77 @@ def test_l0_batch256_properties(dst, engine):
     assert np.array_equal(permuted.view(np.uint8), got[perm].view(np.uint8))
 
 
+@pytest.mark.parametrize("dst", [amd.F32, amd.I8, amd.BITPACKED])
+def test_l0_batch256_streaming_kernel(dst):
+    """BASELINE config 2 on the weight-stationary streaming kernel (the auto choice for this layer):
+    (a) a seeded 4-image subset is bit-exact vs the CPU oracle; (b) all 256 images equal the block GEMM's (engine=direct);
+    (c) batch independence; (d) a batch that does not fill whole blocks (201 images) and forced 14-row segments."""
+    B = 256
+    spec = O.ConvSpec(batch=B, **L0)
+    x, w, mul, bias = synth.conv_inputs(spec, 256)
+    thr = O.thresholds_converter(spec, mul, bias)
+    scale, zp = synth.int8_quant_params(256)
+    kw = dict(mul=mul, bias=bias) if dst != amd.BITPACKED else dict(thr=thr)
+    if dst == amd.I8:
+        kw.update(scale=scale, zp=zp)
+    got, name = _gpu_conv(spec, dst, x, w, engine="auto", **kw)
+    assert name.startswith("bconv2d_stream<"), name
+    subset = [0, 97, 200, 255]
+    odst = {amd.F32: O.DST_F32, amd.I8: O.DST_I8, amd.BITPACKED: O.DST_BITPACKED}[dst]
+    want = O.bconv2d(O.ConvSpec(batch=len(subset), **L0), odst, x[subset], w, mul, bias, thresholds=thr,
+                     out_scale=float(scale), out_zero_point=zp, threads=8)
+    assert np.array_equal(got[subset].view(np.uint8), want.view(np.uint8))
+    ref, rname = _gpu_conv(spec, dst, x, w, engine="direct", **kw)
+    assert rname.startswith("bconv2d_mfma_direct<") and np.array_equal(ref.view(np.uint8), got.view(np.uint8))
+    alone, _ = _gpu_conv(O.ConvSpec(batch=1, **L0), dst, x[97:98], w, engine="stream", **kw)
+    assert np.array_equal(alone[0].view(np.uint8), got[97].view(np.uint8))
+    part, pname = _gpu_conv(O.ConvSpec(batch=201, **L0), dst, x[:201], w, engine="stream", opts=(("stream_rows", "14"),), **kw)
+    assert ",rows14>" in pname and np.array_equal(part.view(np.uint8), got[:201].view(np.uint8)), pname
+
+
+STREAM_GPU_SHAPES = [(3, 19, 23, 64, 64, (1, 1), "ONE"), (2, 14, 14, 256, 256, (1, 1), "ONE"), (5, 7, 7, 96, 320, (1, 1), "SAME"),
+                     (2, 30, 9, 40, 96, (1, 1), "VALID"), (4, 28, 28, 128, 128, (1, 1), "ONE"), (3, 21, 17, 200, 304, (2, 2), "ONE"),
+                     (2, 16, 40, 256, 192, (1, 2), "ONE"), (300, 7, 7, 256, 256, (1, 1), "ONE"), (2, 56, 56, 200, 64, (2, 1), "VALID")]
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+@pytest.mark.parametrize("shape", STREAM_GPU_SHAPES, ids=lambda s: "%dx%dx%d_%d-%d" % s[:5])
+def test_streaming_kernel_shapes(shape, rows):
+    """engine=stream against the oracle on all three output types: pixel phases (64 / 128 output channels), channel groups
+    (> 256), partial pixel blocks, strides, exact SAME-zero and VALID padding, partial word planes, many small images
+    per block; rows = 1: one-row segments (every halo row expanded three times, short streams)."""
+    b, h, w_, cin, cout, st, pad = shape
+    padding, pad_values = {"ONE": (O.PADDING_SAME, 1), "SAME": (O.PADDING_SAME, 0), "VALID": (O.PADDING_VALID, 0)}[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, O.ACT_RELU if b & 1 else O.ACT_NONE,
+                      O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, cin + cout + b, negative_mul_fraction=0.2)
+    opts = (("stream_rows", "1"),) if rows else ()
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=8)
+    got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine="stream", opts=opts)
+    assert n.startswith("bconv2d_stream<") and np.array_equal(got.view(np.int32), want.view(np.int32)), n
+    scale, zp = synth.int8_quant_params(cin + cout)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=8)
+    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, engine="stream", opts=opts)
+    assert np.array_equal(got, want), n
+    thr = O.thresholds_converter(spec, mul, bias)
+    thr[::5] = np.iinfo(np.int32).max
+    thr[1::7] = np.iinfo(np.int32).min
+    want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, threads=8)
+    got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, engine="stream", opts=opts)
+    assert np.array_equal(got, want), n
+
+
+def test_streaming_kernel_with_a_forced_compute_unit_count():
+    """The planner sizes the streaming kernel's grid by the device's CU count; `compute_units` overrides it (tests: several
+    segments per block, the last block short)."""
+    spec = O.ConvSpec(37, 14, 14, 256, 3, 3, 256, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 77)
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=8)
+    for cus in ("5", "16", "256"):
+        got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine="stream", opts=(("compute_units", cus),))
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), (n, cus)
+
+
 QUICKNET_LAYERS = [(56, 64), (28, 128), (14, 256), (7, 512)]
 
 
@@ -929,7 +1000,7 @@ def test_birealnet_stack_batch256():
     assert all(chain.fed[1:])
     chain.run_chain()
     names = _check_chain(chain, [0, 131, 255], O.DST_I8)
-    assert all(n.startswith(("bconv2d_mfma", "bconv2d_pointwise")) for n in names), names
+    assert all(n.startswith(("bconv2d_mfma", "bconv2d_pointwise", "bconv2d_stream")) for n in names), names
     assert sum(n.startswith("bconv2d_pointwise") for n in names) >= 2, names     # the 1x1 layers stream
 
 
@@ -951,4 +1022,4 @@ def test_quicknet_large_per_gpu_shard_batch256():
     for k, (y, b) in enumerate(unfused):
         assert torch.equal(y, chain.y[k]) and torch.equal(b, chain.bits[k]), k
     names = _check_chain(chain, [0, 255], O.DST_F32)
-    assert all(n.startswith("bconv2d_mfma_direct") for n in names), names
+    assert all(n.startswith(("bconv2d_mfma_direct", "bconv2d_stream")) for n in names), names

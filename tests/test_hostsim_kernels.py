@@ -496,3 +496,75 @@ def test_mfma_engine_refuses_grouped():
     x, w, mul, bias = synth.conv_inputs(spec, 1)
     with pytest.raises(RuntimeError, match="matrix-core engine cannot run"):
         H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="mfma")
+
+
+# ------------------------------------------------------------------------------------ streaming kernel (engine=stream)
+STREAM_SHAPES = [
+    # batch, h, w, cin, cout, stride, pad, act, compute units, rows per segment (0 = auto)
+    (2, 8, 9, 128, 64, (1, 1), "ONE", O.ACT_NONE, 2, 0),        # two pixel phases (64 channels: four pixel blocks per step)
+    (3, 12, 10, 256, 256, (1, 1), "ONE", O.ACT_NONE, 2, 0),     # the BASELINE filter bank; two segments per block
+    (3, 12, 10, 256, 256, (1, 1), "ONE", O.ACT_RELU, 3, 4),     # forced 4-row segments: halos re-expanded, ragged blocks
+    (2, 7, 7, 64, 128, (1, 1), "ONE", O.ACT_NONE, 1, 0),        # one block walks the whole batch; 49 pixels: partial blocks
+    (5, 8, 8, 128, 128, (1, 1), "ONE", O.ACT_RELU6, 2, 0),
+    (2, 9, 11, 96, 80, (1, 1), "SAME", O.ACT_NONE, 2, 0),       # exact SAME-zero, 96 channels (a partial last word plane)
+    (2, 9, 11, 40, 48, (1, 1), "VALID", O.ACT_RELU, 1, 0),
+    (2, 11, 9, 200, 304, (2, 2), "ONE", O.ACT_NONE, 2, 0),      # strides; 304 channels: two channel groups (grid.y)
+    (3, 10, 12, 256, 192, (1, 2), "ONE", O.ACT_NONE, 2, 5),
+    (2, 13, 37, 64, 64, (2, 1), "VALID", O.ACT_RELU6, 3, 0),
+]
+
+
+@pytest.mark.parametrize("shape", STREAM_SHAPES, ids=lambda s: "%dx%dx%d_%d-%d_cu%d" % (s[0], s[1], s[2], s[3], s[4], s[8]))
+def test_stream_kernel(shape):
+    """The weight-stationary streaming kernel (lce_kernels_stream.h) with the planner's tables, against the oracle:
+    all three output types, segments / blocks / pixel phases / channel groups, ragged last pixel blocks, strides,
+    both padding semantics it supports, the general (partial word) expansion path."""
+    b, h, w_, cin, cout, st, pad, act, cus, rows = shape
+    padding, pad_values = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, act, O.SEM_REFERENCE)
+    H.set_stream(cus, rows)
+    try:
+        for mb in (0, 2):
+            names = _run_all_dst_mfma(spec, seed=cin + 7 * cout + b, max_batch=mb, engine="stream")
+            assert all(n.startswith("bconv2d_stream<") for n in names), names
+            if rows:
+                assert all(",rows%d>" % rows in n for n in names), names
+    finally:
+        H.set_stream(256, 0)
+
+
+def test_stream_kernel_refuses_what_it_cannot_run():
+    x, w, mul, bias = synth.conv_inputs(O.ConvSpec(1, 6, 6, 64, 3, 3, 64), 1)
+    for spec, why in [
+        (O.ConvSpec(1, 6, 6, 64, 3, 3, 70, padding=O.PADDING_SAME, pad_values=1), "16-byte groups"),      # float: Cout % 4
+        (O.ConvSpec(1, 6, 6, 64, 1, 1, 64), "3x3"),
+        (O.ConvSpec(1, 6, 6, 320, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "256 input"),
+        (O.ConvSpec(1, 8, 8, 64, 3, 3, 64, 1, 1, 1, 2, 2, O.PADDING_SAME, 1), "dilation"),
+        (O.ConvSpec(1, 6, 6, 128, 3, 3, 128, 2, padding=O.PADDING_SAME, pad_values=1), "ungrouped"),
+    ]:
+        x, w, mul, bias = synth.conv_inputs(spec, 2)
+        with pytest.raises(RuntimeError, match="streaming kernel"):
+            H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="stream")
+    # stream_rows must divide the output height
+    spec = O.ConvSpec(2, 9, 9, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 3)
+    H.set_stream(2, 4)
+    try:
+        with pytest.raises(RuntimeError, match="divide the output height"):
+            H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="stream")
+    finally:
+        H.set_stream(256, 0)
+
+
+def test_stream_kernel_is_the_auto_choice_for_a_256_channel_3x3_layer_that_fills_the_chip():
+    spec = O.ConvSpec(6, 12, 16, 256, 3, 3, 256, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 5)
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+    H.set_stream(4, 0)          # a 4-CU "device": 6 images fill it, 12 block steps per block
+    try:
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="auto")
+    finally:
+        H.set_stream(256, 0)
+    assert name.startswith("bconv2d_stream<") and np.array_equal(got.view(np.int32), want.view(np.int32)), name
+    got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="auto")     # 256 CUs: 6 images do not -> block GEMM
+    assert name.startswith("bconv2d_mfma") and np.array_equal(got.view(np.int32), want.view(np.int32)), name
