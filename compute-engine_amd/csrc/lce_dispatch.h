@@ -118,26 +118,31 @@ inline pointwise_fn find_pointwise(int dst, int nc, int nj) {
 
 
 typedef void (*stream_fn)(const StreamArgs, const uint8_t*, const uint8_t*, const float*, const float*, const float*,
-                          const uint32_t*, void*);
+                          const uint32_t*, void*, uint32_t*);
 
 // 3x3 filters over 64 / 128 / 256 (padded) input channels; FAST = every padded word exists and padding is +1;
-// CLAMP = the float transform's clamp is not the identity
-template <int DST, bool FAST, bool CLAMP>
+// CLAMP = the float transform's clamp is not the identity; SIGN = the epilogue also writes the output's LceQuantize
+template <int DST, bool FAST, bool CLAMP, bool SIGN>
 stream_fn stream_by_kch(int kch) {
   switch (kch) {
-    case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP>;
-    case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP>;
-    case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP>;
+    case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN>;
+    case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP, SIGN>;
+    case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP, SIGN>;
     default: return nullptr;
   }
 }
-inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp) {
+template <int DST, bool CLAMP, bool SIGN>
+stream_fn stream_by_fast(int kch, bool fast) {
+  return fast ? stream_by_kch<DST, true, CLAMP, SIGN>(kch) : stream_by_kch<DST, false, CLAMP, SIGN>(kch);
+}
+inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign) {
   switch (dst) {
     case LCE_HIP_F32:
-      if (clamp) return fast ? stream_by_kch<kDstFloat, true, true>(kch) : stream_by_kch<kDstFloat, false, true>(kch);
-      return fast ? stream_by_kch<kDstFloat, true, false>(kch) : stream_by_kch<kDstFloat, false, false>(kch);
-    case LCE_HIP_I8: return fast ? stream_by_kch<kDstInt8, true, false>(kch) : stream_by_kch<kDstInt8, false, false>(kch);
-    default: return fast ? stream_by_kch<kDstBitpacked, true, false>(kch) : stream_by_kch<kDstBitpacked, false, false>(kch);
+      if (clamp) return sign ? stream_by_fast<kDstFloat, true, true>(kch, fast) : stream_by_fast<kDstFloat, true, false>(kch, fast);
+      return sign ? stream_by_fast<kDstFloat, false, true>(kch, fast) : stream_by_fast<kDstFloat, false, false>(kch, fast);
+    case LCE_HIP_I8:
+      return sign ? stream_by_fast<kDstInt8, false, true>(kch, fast) : stream_by_fast<kDstInt8, false, false>(kch, fast);
+    default: return stream_by_fast<kDstBitpacked, false, false>(kch, fast);
   }
 }
 // the FAST variant's precondition (lce_kernels_stream.h)

@@ -570,7 +570,8 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     } else if (h.use_mfma && h.use_stream) {
       // weight-stationary streaming kernel: one persistent block per CU walks its run of segments
       const lce::StreamArgs G = lce::make_stream_args(h, nb);
-      lce::stream_fn fn = lce::find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G));
+      const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
+      lce::stream_fn fn = lce::find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::stream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
@@ -579,8 +580,9 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       }
       const dim3 grid((unsigned)((G.S + G.SPB - 1) / G.SPB), (unsigned)h.st_ny);
       hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, G, (const uint8_t*)in, plan->d_wq.ptr, plan->d_mul.ptr,
-                         plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_sched.ptr, out);
+                         plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_sched.ptr, out, with_sign ? sgn : nullptr);
       LCE_HIP_TRY(hipGetLastError());
+      sign_fused = true;   // (also when there is none to write)
     } else if (h.use_mfma) {
       mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct, h.use_direct && h.tile_tx > 0);

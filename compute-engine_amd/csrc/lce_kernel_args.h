@@ -148,8 +148,10 @@ struct StreamArgs {
   uint32_t in_bytes, w_bytes, out_bytes;   // bytes bound to the input / weight / output buffer resources (< 2^31)
   // the planner's tables (one buffer): sched at byte 0, one dword per tile step; lim: one dword per pixel block (its
   // last real row); ctx: 16 bytes per (pixel block, lane) = {tap-row LDS addresses 0..2, output byte offset}
-  uint32_t tab_bytes, tab_lim, tab_ctx;
-  float a_bt, cmin, cmax;
+  // sgn (float / int8 plans): one dword per (pixel block, lane): the pixel row's byte offset in the sign-word tensor
+  uint32_t tab_bytes, tab_lim, tab_ctx, tab_sgn;
+  uint32_t sign_bytes;                     // bytes of the second output of this launch (B * OH * OW * Wout * 4)
+  float a_bt, cmin, cmax, bit_thr;
   FastDiv div_ipr, div_qg, div_srs, div_spi, div_r;
 };
 

@@ -71,11 +71,15 @@ constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 // FAST (compile-time): every padded input word exists in full and padding is +1 (Cin == 64 * KCH, no exact
 // SAME-zero border) -- the BASELINE layers -- so neither the loads nor the expansion carry per-word conditions.
 // CLAMP (float output): the transform's clamp is not the identity (a fused activation).
-template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP>
+// SIGN (float / int8 output): the epilogue also writes the LceQuantize of the values it produces (the second output of
+// lce_hip_bconv2d_run_dual: bit = value < bit_thr, as the block GEMM's epilogues do) -- the next binary layer of a
+// chain reads 1/32 of the bytes and no separate quantize launch runs.
+template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN>
 LCE_KERNEL void __launch_bounds__(256, 1)
 bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
                const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
-               const uint32_t* __restrict__ tabs, void* __restrict__ out) {
+               const uint32_t* __restrict__ tabs, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
+  static_assert(!SIGN || DST != kDstBitpacked, "a bitpacked-output plan already writes bits");
   constexpr int KS = KH * KW * KCH;            // K-steps of one pixel block
   constexpr int PS = KCH * 32 + 16;            // LDS bytes per ring pixel (the +16 staggers the banks)
   constexpr int GA = 4;                        // K-steps per fragment group (one counted wait per group)
@@ -305,6 +309,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   //              when the pixel block is the partial last one of its segment (its stores then go out of line)
   struct Ctx {
     u32x4 t;
+    uint32_t s;            // SIGN: byte offset of the lane's pixel row in the sign-word tensor (same marker bit)
   };
   const uint32_t row_bytes = DST == kDstBitpacked ? (uint32_t)G.Wout * 4u : (uint32_t)G.N * (DST == kDstInt8 ? 1u : 4u);
   const rsrc_t rout = make_rsrc(out, G.out_bytes);
@@ -325,7 +330,20 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     int q = (u << G.pph_log) + pp;
     q = q < nq ? q : nq - 1;
     cx.t = buf_load(rtab, (uint32_t)G.tab_ctx + (uint32_t)(q * 64 + lane) * 16u, (u32x4*)nullptr);
+    if constexpr (SIGN) cx.s = buf_load(rtab, (uint32_t)G.tab_sgn + (uint32_t)(q * 64 + lane) * 4u, (uint32_t*)nullptr);
+    else cx.s = 0u;
   };
+  // second output: lane p (< 32) owns pixel row p's two sign words of this wave's 64 channels
+  const rsrc_t rsgn = make_rsrc(sign_words, SIGN ? G.sign_bytes : 0u);
+  const uint32_t sign_chan_off = lane < 32 ? (uint32_t)(n0 >> 5) * 4u + (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * (uint32_t)G.Wout * 4u : kOobOffset;
+  auto sign_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
+    const int q = (u << G.pph_log) + pp;
+    return sat_add_u32(cx.s, q < nblk ? sign_chan_off : kOobOffset);
+  };
+  // per lane: channels past the last one never set a bit (padding bits of the last word are 0, bitpack.h:248-308)
+  float bit_thrv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bit_thrv[j] = n0 + j * 32 + l31 < G.N ? G.bit_thr : -__builtin_inff();
   // the store offset of a context: out of range for pixel blocks past the stream and for partial blocks
   auto out_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
     const int q = (u << G.pph_log) + pp;
@@ -380,6 +398,28 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       }
       scratch[row0 * 64 + j * 32 + l31] = y[0];
       scratch[(row0 + 1) * 64 + j * 32 + l31] = y[1];
+      if constexpr (SIGN) {
+        // the 32 channel bits of the four pixel rows these two registers hold, dropped into the lanes that store them
+        unsigned long long bits[2];
+        bits[0] = wave_ballot(y[0] < bit_thrv[j]);
+        bits[1] = wave_ballot(y[1] < bit_thrv[j]);
+        settle_ballots(bits);
+        constexpr int q0 = (r0 & 3) + 8 * (r0 >> 2);
+        bw[j] = write_lane_settled<q0>((uint32_t)bits[0], bw[j]);
+        bw[j] = write_lane_settled<q0 + 4>((uint32_t)(bits[0] >> 32), bw[j]);
+        bw[j] = write_lane_settled<q0 + 1>((uint32_t)bits[1], bw[j]);
+        bw[j] = write_lane_settled<q0 + 5>((uint32_t)(bits[1] >> 32), bw[j]);
+      }
+    }
+  };
+  // the second output's store: two words per pixel row (one when the last word does not exist)
+  auto sign_store = [&](uint32_t sob) LCE_LAMBDA_INLINE {
+    if ((G.Wout & 1) == 0) {
+      const u32x2 v = {bw[0], bw[1]};
+      buf_store2(rsgn, sob, v);
+    } else {
+      buf_store1(rsgn, sob, bw[0]);
+      buf_store1(rsgn, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(sob, 4u) : kOobOffset, bw[1]);
     }
   };
   auto epi_b = [&](auto kc) LCE_LAMBDA_INLINE {
@@ -444,6 +484,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       buf_store1(rout, o, bw[0]);
       buf_store1(rout, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(o, 4u) : kOobOffset, bw[1]);
     }
+    if constexpr (SIGN) {
+      const uint32_t rowl = (uint32_t)(lane & 31);
+      const uint32_t row = rowl < lim1 ? rowl : lim1;
+      sign_store((cx.s & 0x7fffffffu) + sign_chan_off + (row - rowl) * (uint32_t)G.Wout * 4u);
+    }
   };
   // which units ride in K-step ks: A in the first 4/9 of the steps, B from the middle on, C at the end
   // B's gaps are the K-steps ks >= SB0 with ks % 4 in {2, 3} (SBG of them); C's the last SBN K-steps
@@ -478,7 +523,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   //   gap 0: the next fragment group's four reads (every fourth K-step); phase B reads
   //   gap 1: phase A units, then the next block's context load, then production chunks, with phase C's stores
   constexpr int NPG = KS - SA - 1;                          // gap-1 slots behind phase A and the context load
-  uint32_t next_ob = kOobOffset;
+  uint32_t next_ob = kOobOffset, next_sob = kOobOffset, epi_sob = kOobOffset;
   bool next_part = false;
   Issue isa;
   auto step = [&](auto kc_, int u, uint32_t sch1, uint32_t sch2) LCE_LAMBDA_INLINE {
@@ -538,6 +583,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         if constexpr (ks == 1) {       // what the NEXT step's drain of this block needs
           next_ob = out_base(u, cur);
+          if constexpr (SIGN) next_sob = sign_base(u, cur);
           next_part = (int)(uniform(cur.t[3]) >> 31) != 0;
         }
         sched_fence();
@@ -569,6 +615,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         }
 #endif
+        if constexpr (SIGN && ks == SA) sign_store(epi_sob);      // phase A is complete: the drained block's sign words
         if constexpr (ks == SA) load_ctx(u + 1, nxt);
 #ifndef LCE_ST_NOPROD   // timing ablation (results are wrong): no production between the MFMAs
         // production: block step 0 expands item A (16 chunks), block step 1 issues the next one (12 chunks; its load
@@ -604,6 +651,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     if (epi_part) epi_partial(epi_u, epi_cx);
     // this block becomes the one being drained
     epi_ob = next_ob;
+    epi_sob = next_sob;
     epi_part = next_part;
     epi_u = u;
     epi_cx = cur;
@@ -632,6 +680,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     drain_a(IntC<4>{}); drain_a(IntC<5>{}); drain_a(IntC<6>{}); drain_a(IntC<7>{});
     drain_a(IntC<8>{}); drain_a(IntC<9>{}); drain_a(IntC<10>{}); drain_a(IntC<11>{});
     drain_a(IntC<12>{}); drain_a(IntC<13>{}); drain_a(IntC<14>{}); drain_a(IntC<15>{});
+    if constexpr (SIGN) sign_store(epi_sob);
     wave_lds_fence();
     epi_b(IntC<0>{}); epi_b(IntC<1>{}); epi_b(IntC<2>{}); epi_b(IntC<3>{});
     epi_b(IntC<4>{}); epi_b(IntC<5>{}); epi_b(IntC<6>{}); epi_b(IntC<7>{});

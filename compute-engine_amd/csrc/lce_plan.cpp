@@ -418,9 +418,11 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     p.wp = wp;
     // ---- the tables: [sched | lim | ctx] ----
     const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
+    const size_t n_sgn = d.dst_type == LCE_HIP_BITPACKED ? 0 : (size_t)nq * 64;
     p.st_tab_lim = (uint32_t)(n_sched * 4);
     p.st_tab_ctx = (uint32_t)((n_sched + n_lim) * 4);
-    p.st_tabs.assign(n_sched + n_lim + (size_t)nq * 256, 0u);
+    p.st_tab_sgn = (uint32_t)((n_sched + n_lim + (size_t)nq * 256) * 4);
+    p.st_tabs.assign(n_sched + n_lim + (size_t)nq * 256 + n_sgn, 0u);
     std::copy(sched.begin(), sched.end(), p.st_tabs.begin());
     for (size_t i = sched.size(); i < n_sched; ++i) p.st_tabs[i] = sched.back();
     const int npx = rs * p.out_w, sh = d.stride_height, sw = d.stride_width;
@@ -439,6 +441,11 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
         const int rowl = d.dst_type == LCE_HIP_F32 ? lane >> 4 : d.dst_type == LCE_HIP_I8 ? lane >> 2 : l31;
         e[3] = (uint32_t)((gl * npx + pb * 32 + rowl) * (int64_t)row_bytes);
         if (ragged && pb == pbs - 1) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
+        if (n_sgn) {
+          uint32_t& sg = p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + (size_t)q * 64 + lane];
+          sg = (uint32_t)((gl * npx + pb * 32 + l31) * (int64_t)p.wout * 4);
+          if (ragged && pb == pbs - 1) sg |= 0x80000000u;
+        }
       }
     }
     return "";
@@ -467,6 +474,9 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.tab_bytes = (uint32_t)(p.st_tabs.size() * 4);
   G.tab_lim = p.st_tab_lim;
   G.tab_ctx = p.st_tab_ctx;
+  G.tab_sgn = p.st_tab_sgn;
+  G.sign_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * p.wout * 4);
+  G.bit_thr = p.bit_thr;
   G.a_bt = (float)p.backtransform_add;
   G.cmin = (float)p.clamp_min;
   G.cmax = (float)p.clamp_max;

@@ -93,7 +93,7 @@ struct HostPlan {
   int st_rs = 0, st_spi = 0, st_srs = 0, st_pbs = 0, st_pph_log = 0, st_ny = 1, st_qg = 0, st_ipr = 0;
   int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images
   std::vector<uint32_t> st_tabs;           // [sched | lim | ctx]: the kernel's tables (lce_kernel_args.h, StreamArgs)
-  uint32_t st_tab_lim = 0, st_tab_ctx = 0; // byte offsets of lim and ctx inside st_tabs
+  uint32_t st_tab_lim = 0, st_tab_ctx = 0, st_tab_sgn = 0;   // byte offsets of lim / ctx / sgn inside st_tabs
 
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]

@@ -139,14 +139,15 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
     if (h.use_mfma && h.use_stream) {
       const StreamArgs G = make_stream_args(h, nb);
-      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G));
+      uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
+      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
       std::vector<uint32_t> sched = h.st_tabs;
       sched.resize(sched.size() + 16, 0u);
       launch_block_lockstep((G.S + G.SPB - 1) / G.SPB, h.st_ny, 256, (size_t)stream_lds_bytes(h), [&] {
-        fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out);
+        fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out, sgn);
       });
     } else if (h.use_mfma && h.use_pointwise) {
       pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj);

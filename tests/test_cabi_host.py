@@ -101,7 +101,9 @@ def test_kernel_selection_is_host_side_and_named():
     _, filt, mul, bias = synth.conv_inputs(O.ConvSpec(1, 3, 3, 256, 3, 3, 256), 1)
     plan = amd.Bconv2dPlan(_params(spec, amd.F32))
     plan.set_weights(filt, mul, bias)
-    assert plan.kernel_name() == "bconv2d_mfma_direct<f32,128x256>"   # auto: matrix cores, LDS-halo variant
+    assert plan.kernel_name() == "bconv2d_stream<f32,3x3x256,rows56>"  # auto: matrix cores, weight-stationary streaming kernel
+    plan.set_option("engine", "direct")
+    assert plan.kernel_name() == "bconv2d_mfma_direct<f32,128x256>"   # the block GEMM, LDS-halo variant
     plan.set_option("engine", "valu")
     assert plan.kernel_name().startswith("bconv2d_tiled<f32,TM=")     # xor-popcount engine
     plan.set_option("kernel", "general")
@@ -165,17 +167,17 @@ def test_empty_batch_is_legal_and_a_no_op():
 
 
 @pytest.mark.parametrize("hw,c,dst,want", [
-    (56, 256, "F32", "bconv2d_mfma_direct<f32,128x256>"),          # BASELINE L0: long launch, 256 channels per block
-    (56, 256, "I8", "bconv2d_mfma_direct<i8,128x256>"),           # bytes: 256 channels = whole 128-byte lines
-    (14, 256, "I8", "bconv2d_mfma_direct<i8,256x128>"),           # ... but not on short launches
-    (56, 256, "BITPACKED", "bconv2d_mfma_direct<bitpacked,128x256>"),
+    (56, 256, "F32", "bconv2d_stream<f32,3x3x256,rows56>"),         # BASELINE L0: the weight-stationary streaming kernel,
+    (56, 256, "I8", "bconv2d_stream<i8,3x3x256,rows56>"),           # one image per block (round 3; profiles/r03/)
+    (14, 256, "I8", "bconv2d_stream<i8,3x3x256,rows14>"),
+    (56, 256, "BITPACKED", "bconv2d_stream<bitpacked,3x3x256,rows56>"),
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
     (28, 128, "F32", "bconv2d_mfma_direct<f32,128x128>"),
-    (14, 256, "F32", "bconv2d_mfma_direct<f32,256x128>"),
+    (14, 256, "F32", "bconv2d_stream<f32,3x3x256,rows14>"),
     (7, 512, "F32", "bconv2d_mfma_direct<f32,128x128>"),           # two whole images per tile
 ])
 def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
-    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v8.jsonl); this pins what it
+    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v8.jsonl, profiles/r03/stream_vs_block_gemm.txt); this pins what it
     picks for the BASELINE.json layers at batch 256 so that a planner edit shows up as a diff."""
     p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=getattr(amd, dst))
     assert amd.Bconv2dPlan(p).kernel_name() == want

@@ -585,6 +585,33 @@ def test_l0_batch256_streaming_kernel(dst):
     assert ",rows14>" in pname and np.array_equal(part.view(np.uint8), got[:201].view(np.uint8)), pname
 
 
+@pytest.mark.parametrize("shape", [(3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 144), (300, 14, 14, 256, 256)])
+def test_streaming_kernel_run_dual(shape):
+    """lce_hip_bconv2d_run_dual on the streaming kernel (float and int8 plans): the first output equals lce_hip_bconv2d_run,
+    the second the LceQuantize of it -- written by the same woven epilogue."""
+    b, h, w_, cin, cout = shape
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU if b == 3 else O.ACT_NONE)
+    x, w, mul, bias = synth.conv_inputs(spec, sum(shape), negative_mul_fraction=0.3)
+    xd = torch.from_numpy(x).to(DEV)
+    for dst, zp in ((amd.F32, 0), (amd.I8, 3)):
+        plan = amd.Bconv2dPlan(_params(spec, dst, out_scale=4.0, out_zero_point=zp))
+        plan.set_weights(w, mul, bias)
+        plan.set_option("engine", "stream")
+        y = plan.run(xd)
+        bits_poison = torch.full((b, spec.out_h, spec.out_w, (cout + 31) // 32), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+        y2, bits = plan.run_dual(xd, out_bits=bits_poison)
+        torch.cuda.synchronize()
+        assert plan.kernel_name().startswith("bconv2d_stream<")
+        assert torch.equal(y.view(torch.uint8), y2.view(torch.uint8)), plan.kernel_name()
+        assert torch.equal(bits, amd.bitpack(y, zp)), plan.kernel_name()
+        odst = O.DST_F32 if dst == amd.F32 else O.DST_I8
+        sub = slice(0, min(b, 4))
+        want = O.bconv2d(O.ConvSpec(min(b, 4), h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=spec.activation),
+                         odst, x[sub], w, mul, bias, out_scale=4.0, out_zero_point=zp, threads=4)
+        assert np.array_equal(y[sub].cpu().numpy().view(np.uint8), want.view(np.uint8))
+        assert np.array_equal(bits[sub].cpu().numpy(), O.bitpack(want, zp)), plan.kernel_name()
+
+
 STREAM_GPU_SHAPES = [(3, 19, 23, 64, 64, (1, 1), "ONE"), (2, 14, 14, 256, 256, (1, 1), "ONE"), (5, 7, 7, 96, 320, (1, 1), "SAME"),
                      (2, 30, 9, 40, 96, (1, 1), "VALID"), (4, 28, 28, 128, 128, (1, 1), "ONE"), (3, 21, 17, 200, 304, (2, 2), "ONE"),
                      (2, 16, 40, 256, 192, (1, 2), "ONE"), (300, 7, 7, 256, 256, (1, 1), "ONE"), (2, 56, 56, 200, 64, (2, 1), "VALID")]

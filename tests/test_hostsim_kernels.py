@@ -568,3 +568,44 @@ def test_stream_kernel_is_the_auto_choice_for_a_256_channel_3x3_layer_that_fills
     assert name.startswith("bconv2d_stream<") and np.array_equal(got.view(np.int32), want.view(np.int32)), name
     got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="auto")     # 256 CUs: 6 images do not -> block GEMM
     assert name.startswith("bconv2d_mfma") and np.array_equal(got.view(np.int32), want.view(np.int32)), name
+
+
+@pytest.mark.parametrize("cin,cout,act,cus", [(256, 256, O.ACT_NONE, 2), (128, 136, O.ACT_RELU, 1), (64, 64, O.ACT_NONE, 3)])
+def test_stream_second_output_is_the_lcequantize_of_the_float_output(cin, cout, act, cus):
+    """lce_hip_bconv2d_run_dual on the streaming kernel: the woven epilogue also writes sign(y) bits, word for word what
+    LceQuantize makes of the float tensor -- negative multipliers, a RELU clamp, ragged last pixel blocks (143 pixels),
+    a channel count that leaves padding bits (136), pixel phases (64 channels)."""
+    spec = O.ConvSpec(3, 11, 13, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=act)
+    x, w, mul, bias = synth.conv_inputs(spec, 77 + cout, negative_mul_fraction=0.3)
+    bias = (bias - np.median(O.bconv2d(spec, O.DST_F32, x, w, mul, bias), axis=(0, 1, 2))).astype(np.float32)   # both signs occur
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    H.set_stream(cus, 0)
+    try:
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="stream", sign_words=words)
+    finally:
+        H.set_stream(256, 0)
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+    assert name.startswith("bconv2d_stream<f32"), name
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+    assert np.array_equal(words, O.bitpack(want)), name
+    assert 0.02 < ((words.view(np.uint32)[..., 0] & 1) == 1).mean() < 0.98
+
+
+@pytest.mark.parametrize("zp", [-128, -127, -3, 0, 1, 5, 127])
+def test_stream_second_output_of_an_int8_layer_is_its_lcequantize(zp):
+    cout = 144 if zp == 5 else 128          # 144: half a word of padding bits, which must stay 0
+    spec = O.ConvSpec(2, 9, 11, 64, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_NONE)
+    x, w, mul, bias = synth.conv_inputs(spec, 31 + zp, negative_mul_fraction=0.3)
+    mul = (np.sign(mul) * 0.5).astype(np.float32)
+    bias = np.zeros_like(bias)
+    scale = float(3 * 3 * 4)                        # |y| up to ~ K/scale = 8 around zp; halves occur -> exact ties
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    H.set_stream(2, 0)
+    try:
+        got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp, engine="stream", sign_words=words)
+    finally:
+        H.set_stream(256, 0)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp)
+    assert name.startswith("bconv2d_stream<i8"), name
+    assert np.array_equal(got, want), name
+    assert np.array_equal(words, O.bitpack(want, zp)), name
