@@ -5,7 +5,7 @@
 # 2. --kernel-trace --stats per single layer named in bench.py's `extra` (one process per layer, so the
 #    per-kernel average IS that layer's launch duration)
 # 3. PMC passes (separate runs, counters only + kernel trace) over the L0 float layer
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT/layers $OUT/bench
