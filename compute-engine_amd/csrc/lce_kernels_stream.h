@@ -237,15 +237,6 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         W[ks][j] = buf_load(rw, slice_ok ? (uint32_t)((ks * 2 + half) * G.Npad + n0 + j * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
-    // 256 accumulator registers hold the first 32 K-steps' fragments, the rest stay in VGPRs.  (The hint is a use of
-    // the value: only after ALL loads are in flight -- behind each load it would wait for that load.)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (ks < 32) keep_in_agpr(W[ks][j]);
-        else keep_in_vgpr(W[ks][j]);
-      }
   }
   LCE_SPH(59);
   // per-channel constants of this lane's two channels; multiplier and bias twice each: the transform works on
@@ -269,11 +260,19 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   keep_in_vgpr(cminv);
   keep_in_vgpr(cmaxv);
 
-  // the ring: every slot starts as padding (+1 codes, or zeros for exact SAME-zero)
+  // The ring's padding COLUMNS (pixels left of PW and right of PW + W in every row slot) are +1 codes, or zeros for
+  // exact SAME-zero, for good: production only ever writes pixels PW .. PW + W - 1 of a slot (padding ROWS are
+  // produced like any other row, from out-of-range loads).
   {
     const uint32_t code = G.zero_border ? 0u : 0x22222222u;
     const u32x4 v = {code, code, code, code};
-    for (int o = tid * 16; o < G.ring_bytes; o += 256 * 16) *(u32x4*)(lds0 + o) = v;
+    const int padc = G.Wp - G.W;                               // padding pixels per slot
+    constexpr int CH = KCH * 2;                                // 16-byte chunks per pixel
+    for (int e = tid; e < G.R * padc * CH; e += 256) {
+      const int c16 = e % CH, t = e / CH, pc = t % padc, slot = t / padc;
+      const int px = pc < G.PW ? pc : pc + G.W;
+      *(u32x4*)(lds0 + (size_t)(slot * G.Wp + px) * PS + c16 * 16) = v;
+    }
   }
   block_barrier_keep_vm();
   LCE_SPH(60);
@@ -300,6 +299,17 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     have_b = b - a > 256u;
     if (have_b) item_issue(a + (uint32_t)(256 + tid), b, pwb, pdb, pmb);
   }
+  // The filter bank's home: 256 accumulator registers hold the first 32 K-steps' fragments, the rest stay in VGPRs.
+  // The hint is a USE of the loaded value (a counted wait), placed here so that the first rows' expansion above ran
+  // while the bank was still arriving -- and after all its loads were issued: behind each load it would wait for that
+  // load alone, 72 round trips in a row.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (ks < 32) keep_in_agpr(W[ks][j]);
+      else keep_in_vgpr(W[ks][j]);
+    }
   block_barrier_keep_vm();
   LCE_SPH(1);
 
@@ -437,10 +447,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     if constexpr (DST == kDstFloat) {
       buf_store_streaming_so(rout, ob, (uint32_t)(4 * k) * row_bytes, yb[k]);
     } else if constexpr (DST == kDstInt8) {
-      int q0, q1, q2, q3;
-      round_i8_clamped2(yb[k][0], yb[k][1], q0, q1);
-      round_i8_clamped2(yb[k][2], yb[k][3], q2, q3);
-      pk[k >> 2][k & 3] = pack4_u8(q0, q1, q2, q3);
+      // round half away from zero on values already clamped to [-128, 127] (lce_kernels.h, round_sat_i8); scalar adds:
+      // a packed-f32 add beside the MFMA stream costs a dozen cycles more than its issue slot
+      auto rnd = [](float c) LCE_LAMBDA_INLINE -> int { return (int)(c + __builtin_copysignf(0x1.fffffep-2f, c)); };
+      pk[k >> 2][k & 3] = pack4_u8(rnd(yb[k][0]), rnd(yb[k][1]), rnd(yb[k][2]), rnd(yb[k][3]));
       if constexpr ((k & 3) == 3) buf_store_so(rout, ob, (uint32_t)(16 * (k >> 2)) * row_bytes, pk[k >> 2]);
     } else {
       if constexpr (k == 0) {
@@ -660,10 +670,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 
   for (int T = 0; T < ntile; ++T) {
     const uint32_t sch1 = sched[T + 1], sch2 = sched[T + 2];
+    // (the last tile step may be short: block steps past the stream are skipped, not computed and masked)
     step(IntC<0>{}, 4 * T + 0, sch1, sch2);
-    step(IntC<1>{}, 4 * T + 1, sch1, sch2);
-    step(IntC<2>{}, 4 * T + 2, sch1, sch2);
-    step(IntC<3>{}, 4 * T + 3, sch1, sch2);
+    if (4 * T + 1 < usteps) step(IntC<1>{}, 4 * T + 1, sch1, sch2);
+    if (4 * T + 2 < usteps) step(IntC<2>{}, 4 * T + 2, sch1, sch2);
+    if (4 * T + 3 < usteps) step(IntC<3>{}, 4 * T + 3, sch1, sch2);
     // the rare second item of a tile step's quota
     if (have_b) item_write(pwb, pdb, pmb);
     have_b = sch2 - sch1 > 256u;
@@ -672,10 +683,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     LCE_SPH(2 + T);
   }
 
-  // drain: the last block step's accumulators (set 1: block steps come in fours)
-  {
+  // drain: the last block step's accumulators (its set by the parity of the step count)
+  auto drain = [&](f32x16 (&last)[2]) LCE_LAMBDA_INLINE {
     wave_lds_order();
-    auto drain_a = [&](auto tc) LCE_LAMBDA_INLINE { epi_a(tc, acc[1]); };
+    auto drain_a = [&](auto tc) LCE_LAMBDA_INLINE { epi_a(tc, last); };
     drain_a(IntC<0>{}); drain_a(IntC<1>{}); drain_a(IntC<2>{}); drain_a(IntC<3>{});
     drain_a(IntC<4>{}); drain_a(IntC<5>{}); drain_a(IntC<6>{}); drain_a(IntC<7>{});
     drain_a(IntC<8>{}); drain_a(IntC<9>{}); drain_a(IntC<10>{}); drain_a(IntC<11>{});
@@ -687,7 +698,9 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     epi_c(IntC<0>{}, epi_ob); epi_c(IntC<1>{}, epi_ob); epi_c(IntC<2>{}, epi_ob); epi_c(IntC<3>{}, epi_ob);
     epi_c(IntC<4>{}, epi_ob); epi_c(IntC<5>{}, epi_ob); epi_c(IntC<6>{}, epi_ob); epi_c(IntC<7>{}, epi_ob);
     if (epi_part) epi_partial(epi_u, epi_cx);
-  }
+  };
+  if (usteps & 1) drain(acc[0]);
+  else drain(acc[1]);
   LCE_SPH(63);
 }
 

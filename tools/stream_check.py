@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""engine=stream against the default engine on the same operands: bit equality of the outputs and HIP-event timings.
+"""engine=stream against the block GEMM (engine=direct) on the same operands: bit equality of the outputs and HIP-event timings.
 usage: stream_check.py [layer ...]   layer = HWxCINxCOUT[xBATCH]  (default: L0 and the QuickNet 3x3 layers)
 env: LCE_OPTS=key=val,... (extra plan options for the stream plan), LCE_STEPS (timed launches, default 20)"""
 import importlib
@@ -42,7 +42,7 @@ for spec in layers:
     x = torch.from_numpy(SL.activations(layer, 4)).to("cuda:0")
     for dname, dst in (("f32", amd.F32), ("i8", amd.I8), ("bp", amd.BITPACKED)):
         res = {}
-        for engine in ("auto", "stream"):
+        for engine in ("direct", "stream"):
             plan = amd.Bconv2dPlan(layer.params(amd, dst, 0.125, 3))
             plan.set_weights(w, mul, bias, thr)
             plan.set_option("engine", engine)
@@ -53,11 +53,11 @@ for spec in layers:
             torch.cuda.synchronize()
             ms = timed(plan, x, out)
             res[engine] = (plan.kernel_name(), ms, out.clone())
-        same = torch.equal(res["auto"][2].view(torch.uint8), res["stream"][2].view(torch.uint8))
+        same = torch.equal(res["direct"][2].view(torch.uint8), res["stream"][2].view(torch.uint8))
         print("%-14s %-3s %-38s %.4f ms | %-40s %.4f ms | %s x%.2f" % (
-            spec, dname, res["auto"][0], res["auto"][1], res["stream"][0], res["stream"][1],
-            "EQUAL" if same else "MISMATCH", res["auto"][1] / res["stream"][1]), flush=True)
+            spec, dname, res["direct"][0], res["direct"][1], res["stream"][0], res["stream"][1],
+            "EQUAL" if same else "MISMATCH", res["direct"][1] / res["stream"][1]), flush=True)
         if not same:
-            a, b = res["auto"][2].view(torch.uint8), res["stream"][2].view(torch.uint8)
+            a, b = res["direct"][2].view(torch.uint8), res["stream"][2].view(torch.uint8)
             bad = (a != b).nonzero()
             print("   first mismatches at", bad[:5].tolist(), "count", int((a != b).sum()))
