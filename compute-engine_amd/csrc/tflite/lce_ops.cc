@@ -5,13 +5,20 @@
 // (paths relative to /root/reference/larq_compute_engine/): C++ functions in namespace
 // compute_engine::tflite returning a function-local static TfLiteRegistration with
 // {init, free, prepare, invoke}.  Underneath, instead of the CPU kernels, every op calls
-// the C ABI in include/lce_hip.h.  Interpreter tensors are host memory, so invoke stages
-// them through HBM (lce_hip_*_run_host / memcpy); device-resident chaining is available
-// through the C ABI directly.
+// the C ABI in include/lce_hip.h.  Interpreter tensors are host memory; a tensor that is PRODUCED by one
+// of these ops and READ only by these ops stays in HBM between them (namespace `resident` below): in the
+// reference consecutive LCE ops hand tensors over in the arena at no cost (tflite/kernels/bconv2d.cc:550-564,
+// quantization.cc:76-114, bmaxpool.cc:79-91), here a chain LceQuantize -> LceBconv2d -> LceBMaxPool2d ->
+// LceBconv2d crosses PCIe once in each direction instead of twice per op.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 
 #include "../../../include/lce_hip.h"
 #include "flexbuffer_map.h"
@@ -64,27 +71,146 @@ inline int BitpackedSize(int n) { return (n + 31) / 32; }  // core/bitpacking/bi
     }                                                                                  \
   } while (0)
 
-// RAII device scratch used by the ops that stage host tensors themselves
-struct DeviceBuffer {
-  void* ptr = nullptr;
-  size_t bytes = 0;
-  ~DeviceBuffer() { if (ptr) lce_hip_free(ptr); }
-  lce_hip_status ensure(size_t n) {
-    if (n <= bytes) return LCE_HIP_OK;
-    if (ptr) lce_hip_free(ptr);
-    ptr = nullptr;
-    bytes = 0;
-    lce_hip_status s = lce_hip_malloc(&ptr, n);
-    if (s == LCE_HIP_OK) bytes = n;
-    return s;
-  }
-};
-
 size_t NumElements(const TfLiteTensor* t) {
   size_t n = 1;
   for (int i = 0; i < t->dims->size; ++i) n *= (size_t)t->dims->data[i];
   return n;
 }
+
+// =====================================================================================
+// Device residency between LCE ops.
+//
+// Every op's output lives in a device buffer keyed by (context, tensor index).  At Prepare time the producing node
+// scans the interpreter's execution plan (TfLiteContext::GetExecutionPlan / GetNodeAndRegistration) for the readers
+// of its output: readers that are LCE ops take the device buffer in their invoke (no upload); if ALL readers are LCE
+// ops -- and there is at least one -- the producer does not copy the tensor back to the arena at all; a tensor with a
+// non-LCE reader, or with no reader (a graph output), is copied back as before.  An interpreter that does not provide
+// the two callbacks (the single-op test driver) gets the old behaviour: every invoke uploads and downloads.
+// Caveat: TfLiteContext does not say which tensors are graph OUTPUTS; a tensor that is a graph output and ALSO feeds
+// an LCE op is indistinguishable from an intermediate and is not copied back.  Converted LCE models never expose a
+// bitpacked / pre-quantize intermediate as an output; set LCE_HIP_TFLITE_RESIDENCY=0 (or call
+// lce_tflite_ops_set_residency(0)) to copy every tensor back regardless.
+// =====================================================================================
+namespace resident {
+
+struct Entry {
+  void* dev = nullptr;
+  size_t bytes = 0;       // allocated
+  bool valid = false;     // holds the tensor's current value (set by the producer's invoke)
+};
+std::mutex g_mu;
+std::map<std::pair<const TfLiteContext*, int>, Entry> g_table;
+std::atomic<uint64_t> g_h2d{0}, g_d2h{0}, g_h2d_bytes{0}, g_d2h_bytes{0};
+std::atomic<int> g_enabled{-1};   // -1: read LCE_HIP_TFLITE_RESIDENCY on first use
+
+bool enabled() {
+  int e = g_enabled.load();
+  if (e < 0) {
+    const char* v = getenv("LCE_HIP_TFLITE_RESIDENCY");
+    e = (v && (v[0] == '0' || v[0] == 'n' || v[0] == 'N' || v[0] == 'f' || v[0] == 'F')) ? 0 : 1;
+    g_enabled.store(e);
+  }
+  return e != 0;
+}
+
+// the device buffer of (context, tensor): created / grown on demand; nullptr on allocation failure
+Entry* ensure(const TfLiteContext* c, int tensor, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  Entry& e = g_table[std::make_pair(c, tensor)];
+  if (e.bytes < bytes) {
+    if (e.dev) lce_hip_free(e.dev);
+    e.dev = nullptr;
+    e.bytes = 0;
+    e.valid = false;
+    if (lce_hip_malloc(&e.dev, bytes ? bytes : 1) != LCE_HIP_OK) return nullptr;
+    e.bytes = bytes;
+  }
+  return &e;   // (std::map nodes are stable)
+}
+// the current device copy of (context, tensor), if a producer left one
+void* current(const TfLiteContext* c, int tensor, size_t bytes) {
+  if (!enabled()) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_table.find(std::make_pair(c, tensor));
+  return it != g_table.end() && it->second.valid && it->second.bytes >= bytes ? it->second.dev : nullptr;
+}
+void invalidate(const TfLiteContext* c, int tensor) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_table.find(std::make_pair(c, tensor));
+  if (it != g_table.end()) it->second.valid = false;
+}
+void drop(const TfLiteContext* c, int tensor) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_table.find(std::make_pair(c, tensor));
+  if (it == g_table.end()) return;
+  if (it->second.dev) lce_hip_free(it->second.dev);
+  g_table.erase(it);
+}
+
+bool is_lce_invoke(TfLiteStatus (*fn)(TfLiteContext*, TfLiteNode*));   // defined at the end of this file
+
+// Who reads `tensor`?  known = the interpreter answered; then lce / other count its readers.
+struct Readers {
+  bool known = false;
+  int lce = 0, other = 0;
+  bool keep_on_device() const { return known && lce > 0; }                     // an LCE reader will pick it up
+  bool needs_host() const { return !known || other > 0 || lce == 0; }          // someone reads the arena (or nobody we know of)
+};
+Readers readers_of(TfLiteContext* c, const TfLiteNode* self, int tensor) {
+  Readers r;
+  if (!enabled() || !c->GetExecutionPlan || !c->GetNodeAndRegistration) return r;
+  TfLiteIntArray* plan = nullptr;
+  if (c->GetExecutionPlan(c, &plan) != kTfLiteOk || !plan) return r;
+  for (int i = 0; i < plan->size; ++i) {
+    TfLiteNode* node = nullptr;
+    void* reg = nullptr;
+    if (c->GetNodeAndRegistration(c, plan->data[i], &node, &reg) != kTfLiteOk || !node || !reg) return Readers{};
+    if (node == self || !node->inputs) continue;
+    bool reads = false;
+    for (int k = 0; k < node->inputs->size; ++k) reads = reads || node->inputs->data[k] == tensor;
+    if (!reads) continue;
+    if (is_lce_invoke(static_cast<const TfLiteRegistration*>(reg)->invoke)) ++r.lce;
+    else ++r.other;
+  }
+  r.known = true;
+  return r;
+}
+
+// ---- what an op's invoke does with its tensors ----
+// input: the producer's device copy when there is one, else an upload into a per-tensor staging buffer
+lce_hip_status input(TfLiteContext* c, int tensor, const void* host, size_t bytes, const void** dev) {
+  if (void* cur = current(c, tensor, bytes)) { *dev = cur; return LCE_HIP_OK; }
+  Entry* e = ensure(c, tensor, bytes);
+  if (!e) return LCE_HIP_ERR_RUNTIME;
+  ++g_h2d;
+  g_h2d_bytes += bytes;
+  *dev = e->dev;
+  return lce_hip_memcpy_h2d(e->dev, host, bytes, nullptr);   // (not marked valid: the arena may change before the next invoke)
+}
+// output: the device buffer the kernel writes ...
+lce_hip_status output(TfLiteContext* c, int tensor, size_t bytes, void** dev) {
+  Entry* e = ensure(c, tensor, bytes);
+  if (!e) return LCE_HIP_ERR_RUNTIME;
+  e->valid = false;
+  *dev = e->dev;
+  return LCE_HIP_OK;
+}
+// ... and what happens to it behind the kernel
+lce_hip_status publish(TfLiteContext* c, int tensor, const Readers& r, void* host, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_table.find(std::make_pair(static_cast<const TfLiteContext*>(c), tensor));
+    if (it != g_table.end()) it->second.valid = r.keep_on_device();
+    if (r.needs_host() && it != g_table.end()) {
+      ++g_d2h;
+      g_d2h_bytes += bytes;
+      if (lce_hip_status s = lce_hip_memcpy_d2h(host, it->second.dev, bytes, nullptr)) return s;
+    }
+  }
+  return r.needs_host() ? lce_hip_stream_synchronize(nullptr) : LCE_HIP_OK;
+}
+
+}  // namespace resident
 
 }  // namespace
 
@@ -108,7 +234,14 @@ struct OpData {  // bconv2d.cc:44-74
   lce_hip_bconv2d_plan* plan = nullptr;
   bool successfully_initialized = false;
   bool one_time_setup_complete = false;
-  ~OpData() { if (plan) lce_hip_bconv2d_plan_destroy(plan); }
+  // device residency of the output (namespace resident)
+  const TfLiteContext* out_context = nullptr;
+  int out_tensor = -1;
+  resident::Readers readers;
+  ~OpData() {
+    if (plan) lce_hip_bconv2d_plan_destroy(plan);
+    if (out_context) resident::drop(out_context, out_tensor);
+  }
 };
 
 void* Init(TfLiteContext* context, const char* buffer, size_t length) {  // bconv2d.cc:85-131
@@ -257,6 +390,11 @@ TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bconv2d.cc:
   // [B,OH,OW,KH*KW*Cw] here, :250-293).
   // Prepare may run again after a resize: redo the one-time setup (:295-297).
   op->one_time_setup_complete = false;
+  // who reads the output decides whether it has to travel back to the arena
+  if (op->out_context) resident::invalidate(op->out_context, op->out_tensor);
+  op->out_context = context;
+  op->out_tensor = node->outputs->data[0];
+  op->readers = resident::readers_of(context, node, op->out_tensor);
   return kTfLiteOk;
 }
 
@@ -284,7 +422,19 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // :550-564
   TfLiteTensor* output = GetOutput(context, node, 0);
   if (output->type != kTfLiteFloat32 && output->type != kTfLiteInt8 && output->type != kTfLiteInt32)
     return kTfLiteError;
-  LCE_ENSURE_HIP(context, lce_hip_bconv2d_run_host(op->plan, input->data.i32, output->data.data));
+  const int in_idx = node->inputs->data[0];
+  const bool in_resident = resident::current(context, in_idx, input->bytes) != nullptr;
+  if (!in_resident && !op->readers.keep_on_device()) {
+    // host in, host out: the pipelined path (batch slices on three streams)
+    LCE_ENSURE_HIP(context, lce_hip_bconv2d_run_host(op->plan, input->data.i32, output->data.data));
+    return kTfLiteOk;
+  }
+  const void* in_dev = nullptr;
+  void* out_dev = nullptr;
+  LCE_ENSURE_HIP(context, resident::input(context, in_idx, input->data.data, input->bytes, &in_dev));
+  LCE_ENSURE_HIP(context, resident::output(context, op->out_tensor, output->bytes, &out_dev));
+  LCE_ENSURE_HIP(context, lce_hip_bconv2d_run(op->plan, (const int32_t*)in_dev, out_dev, nullptr));
+  LCE_ENSURE_HIP(context, resident::publish(context, op->out_tensor, op->readers, output->data.data, output->bytes));
   return kTfLiteOk;
 }
 
@@ -317,12 +467,24 @@ TfLiteRegistration* Register_BCONV_2D() { return Register_BCONV_2D_OPT_BGEMM(); 
 // =====================================================================================
 namespace {
 
-struct StagePair {
-  DeviceBuffer in, out;
+// The reference's LceQuantize / LceDequantize have no per-node state (init = free = nullptr, quantization.cc:149-159);
+// here a node remembers which tensor it produces so that the tensor's device buffer is released with the node.
+struct OutputRef {
+  const TfLiteContext* context = nullptr;
+  int tensor = -1;
 };
-StagePair& stage() {
-  static thread_local StagePair s;
-  return s;
+void* OutputRefInit(TfLiteContext*, const char*, size_t) { return new (std::nothrow) OutputRef{}; }
+void OutputRefFree(TfLiteContext*, void* buffer) {
+  auto* r = reinterpret_cast<OutputRef*>(buffer);
+  if (r && r->context) resident::drop(r->context, r->tensor);
+  delete r;
+}
+void RememberOutput(TfLiteContext* context, TfLiteNode* node) {
+  auto* r = reinterpret_cast<OutputRef*>(node->user_data);
+  if (!r) return;
+  if (r->context) resident::invalidate(r->context, r->tensor);
+  r->context = context;
+  r->tensor = node->outputs->data[0];
 }
 
 TfLiteStatus QuantizePrepare(TfLiteContext* context, TfLiteNode* node) {  // quantization.cc:19-41
@@ -336,6 +498,7 @@ TfLiteStatus QuantizePrepare(TfLiteContext* context, TfLiteNode* node) {  // qua
   LCE_ENSURE_EQ(context, num_dims, NumDimensions(output));
   TfLiteIntArray* output_dims = TfLiteIntArrayCopy(input->dims);
   output_dims->data[num_dims - 1] = BitpackedSize(SizeOfDimension(input, num_dims - 1));
+  RememberOutput(context, node);
   return context->ResizeTensor(context, output, output_dims);
 }
 
@@ -355,13 +518,14 @@ TfLiteStatus QuantizeEval(TfLiteContext* context, TfLiteNode* node) {  // quanti
   if (total == 0) return kTfLiteOk;
   const size_t rows = total / cols;
   const size_t out_bytes = rows * (size_t)BitpackedSize((int)cols) * 4;
-  StagePair& s = stage();
-  LCE_ENSURE_HIP(context, s.in.ensure(total * esz));
-  LCE_ENSURE_HIP(context, s.out.ensure(out_bytes));
-  LCE_ENSURE_HIP(context, lce_hip_memcpy_h2d(s.in.ptr, input->data.data, total * esz, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_bitpack(t, s.in.ptr, rows, cols, zp, (int32_t*)s.out.ptr, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_memcpy_d2h(output->data.data, s.out.ptr, out_bytes, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_stream_synchronize(nullptr));
+  const int out_idx = node->outputs->data[0];
+  const resident::Readers readers = resident::readers_of(context, node, out_idx);
+  const void* in_dev = nullptr;
+  void* out_dev = nullptr;
+  LCE_ENSURE_HIP(context, resident::input(context, node->inputs->data[0], input->data.data, total * esz, &in_dev));
+  LCE_ENSURE_HIP(context, resident::output(context, out_idx, out_bytes, &out_dev));
+  LCE_ENSURE_HIP(context, lce_hip_bitpack(t, in_dev, rows, cols, zp, (int32_t*)out_dev, nullptr));
+  LCE_ENSURE_HIP(context, resident::publish(context, out_idx, readers, output->data.data, out_bytes));
   return kTfLiteOk;
 }
 
@@ -376,6 +540,7 @@ TfLiteStatus DequantizePrepare(TfLiteContext* context, TfLiteNode* node) {  // q
   LCE_ENSURE_EQ(context, num_dims, NumDimensions(output));
   for (int i = 0; i < num_dims - 1; ++i) LCE_ENSURE_EQ(context, SizeOfDimension(output, i), SizeOfDimension(input, i));
   LCE_ENSURE_EQ(context, SizeOfDimension(input, num_dims - 1), BitpackedSize(SizeOfDimension(output, num_dims - 1)));
+  RememberOutput(context, node);
   return kTfLiteOk;  // no resize: the unpacked channel count cannot be inferred (:69-71)
 }
 
@@ -394,25 +559,26 @@ TfLiteStatus DequantizeEval(TfLiteContext* context, TfLiteNode* node) {  // quan
   if (total == 0) return kTfLiteOk;
   const size_t rows = total / cols;
   const size_t in_bytes = rows * (size_t)BitpackedSize((int)cols) * 4;
-  StagePair& s = stage();
-  LCE_ENSURE_HIP(context, s.in.ensure(in_bytes));
-  LCE_ENSURE_HIP(context, s.out.ensure(total * esz));
-  LCE_ENSURE_HIP(context, lce_hip_memcpy_h2d(s.in.ptr, input->data.data, in_bytes, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_unpack(t, (const int32_t*)s.in.ptr, rows, cols, output->params.scale,
-                                         output->params.zero_point, s.out.ptr, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_memcpy_d2h(output->data.data, s.out.ptr, total * esz, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_stream_synchronize(nullptr));
+  const int out_idx = node->outputs->data[0];
+  const resident::Readers readers = resident::readers_of(context, node, out_idx);
+  const void* in_dev = nullptr;
+  void* out_dev = nullptr;
+  LCE_ENSURE_HIP(context, resident::input(context, node->inputs->data[0], input->data.data, in_bytes, &in_dev));
+  LCE_ENSURE_HIP(context, resident::output(context, out_idx, total * esz, &out_dev));
+  LCE_ENSURE_HIP(context, lce_hip_unpack(t, (const int32_t*)in_dev, rows, cols, output->params.scale,
+                                         output->params.zero_point, out_dev, nullptr));
+  LCE_ENSURE_HIP(context, resident::publish(context, out_idx, readers, output->data.data, total * esz));
   return kTfLiteOk;
 }
 
 }  // namespace
 
 TfLiteRegistration* Register_QUANTIZE() {  // quantization.cc:149-153
-  static TfLiteRegistration r = {nullptr, nullptr, QuantizePrepare, QuantizeEval};
+  static TfLiteRegistration r = {OutputRefInit, OutputRefFree, QuantizePrepare, QuantizeEval};
   return &r;
 }
 TfLiteRegistration* Register_DEQUANTIZE() {  // quantization.cc:155-159
-  static TfLiteRegistration r = {nullptr, nullptr, DequantizePrepare, DequantizeEval};
+  static TfLiteRegistration r = {OutputRefInit, OutputRefFree, DequantizePrepare, DequantizeEval};
   return &r;
 }
 
@@ -423,6 +589,9 @@ namespace bmaxpool {
 
 struct PoolParams {  // core/bmaxpool.h:15-22
   int32_t filter_height = 0, filter_width = 0, stride_height = 0, stride_width = 0, padding = 0;
+  const TfLiteContext* out_context = nullptr;   // device residency of the output (namespace resident)
+  int out_tensor = -1;
+  ~PoolParams() { if (out_context) resident::drop(out_context, out_tensor); }
 };
 
 void* Init(TfLiteContext*, const char* buffer, size_t length) {  // bmaxpool.cc:20-35
@@ -461,6 +630,9 @@ TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bmaxpool.cc
   out->data[1] = oh;
   out->data[2] = ow;
   out->data[3] = SizeOfDimension(input, 3);
+  if (p->out_context) resident::invalidate(p->out_context, p->out_tensor);
+  p->out_context = context;
+  p->out_tensor = node->outputs->data[0];
   return context->ResizeTensor(context, output, out);
 }
 
@@ -470,16 +642,17 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // bmaxpool.cc:79
   TfLiteTensor* output = GetOutput(context, node, 0);
   const size_t in_bytes = NumElements(input) * 4, out_bytes = NumElements(output) * 4;
   if (in_bytes == 0 || out_bytes == 0) return kTfLiteOk;
-  StagePair& s = stage();
-  LCE_ENSURE_HIP(context, s.in.ensure(in_bytes));
-  LCE_ENSURE_HIP(context, s.out.ensure(out_bytes));
-  LCE_ENSURE_HIP(context, lce_hip_memcpy_h2d(s.in.ptr, input->data.data, in_bytes, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_bmaxpool((const int32_t*)s.in.ptr, SizeOfDimension(input, 0), SizeOfDimension(input, 1),
+  const int out_idx = node->outputs->data[0];
+  const resident::Readers readers = resident::readers_of(context, node, out_idx);
+  const void* in_dev = nullptr;
+  void* out_dev = nullptr;
+  LCE_ENSURE_HIP(context, resident::input(context, node->inputs->data[0], input->data.data, in_bytes, &in_dev));
+  LCE_ENSURE_HIP(context, resident::output(context, out_idx, out_bytes, &out_dev));
+  LCE_ENSURE_HIP(context, lce_hip_bmaxpool((const int32_t*)in_dev, SizeOfDimension(input, 0), SizeOfDimension(input, 1),
                                            SizeOfDimension(input, 2), SizeOfDimension(input, 3), p->filter_height,
                                            p->filter_width, p->stride_height, p->stride_width, p->padding,
-                                           (int32_t*)s.out.ptr, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_memcpy_d2h(output->data.data, s.out.ptr, out_bytes, nullptr));
-  LCE_ENSURE_HIP(context, lce_hip_stream_synchronize(nullptr));
+                                           (int32_t*)out_dev, nullptr));
+  LCE_ENSURE_HIP(context, resident::publish(context, out_idx, readers, output->data.data, out_bytes));
   return kTfLiteOk;
 }
 
@@ -490,5 +663,30 @@ TfLiteRegistration* Register_BMAXPOOL_2D() {  // bmaxpool.cc:95-99
   return &r;
 }
 
+namespace {
+namespace resident {
+bool is_lce_invoke(TfLiteStatus (*fn)(TfLiteContext*, TfLiteNode*)) {
+  return fn == Register_BCONV_2D_REF()->invoke || fn == Register_BCONV_2D_OPT_BGEMM()->invoke ||
+         fn == Register_BCONV_2D_OPT_INDIRECT_BGEMM()->invoke || fn == Register_QUANTIZE()->invoke ||
+         fn == Register_DEQUANTIZE()->invoke || fn == Register_BMAXPOOL_2D()->invoke;
+}
+}  // namespace resident
+}  // namespace
+
 }  // namespace tflite
 }  // namespace compute_engine
+
+// Test / tuning hooks of the residency layer (plain C, not part of the reference's interface).
+extern "C" {
+// 1 / 0: keep LCE-only intermediates on the device / copy every tensor back (also: LCE_HIP_TFLITE_RESIDENCY=0)
+void lce_tflite_ops_set_residency(int on) { compute_engine::tflite::resident::g_enabled.store(on ? 1 : 0); }
+// host -> device and device -> host tensor copies made by the ops' invokes since the last reset
+void lce_tflite_ops_transfer_counts(uint64_t* h2d, uint64_t* d2h, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset) {
+  using namespace compute_engine::tflite::resident;
+  if (h2d) *h2d = g_h2d.load();
+  if (d2h) *d2h = g_d2h.load();
+  if (h2d_bytes) *h2d_bytes = g_h2d_bytes.load();
+  if (d2h_bytes) *d2h_bytes = g_d2h_bytes.load();
+  if (reset) { g_h2d = 0; g_d2h = 0; g_h2d_bytes = 0; g_d2h_bytes = 0; }
+}
+}

@@ -1,4 +1,5 @@
-// A tiny stand-in for the part of the TFLite interpreter that drives ONE custom-op node:
+// A tiny stand-in for the part of the TFLite interpreter that drives custom-op nodes (one, as TFLite's SingleOpModel
+// does in the reference's op tests, or a short chain of them with an execution plan the ops can inspect):
 // resolver lookup -> init(options) -> prepare -> invoke -> free, with a tensor arena,
 // ResizeTensor / AddTensors / ReportError callbacks and the TfLiteIntArray helpers.  It
 // plays the role TFLite's SingleOpModel plays in the reference's op tests
@@ -56,10 +57,18 @@ struct Model {
   std::vector<TfLiteTensor> tensors;
   std::vector<std::vector<char>> storage;
   std::vector<TfLiteAffineQuantization> quant;
-  TfLiteNode node{};
+  TfLiteNode node{};                       // node 0 (the single-op interface)
   const TfLiteRegistration* reg = nullptr;
   std::string log;
   bool inited = false;
+  // further nodes of a chain (lce_driver_add_node): node i + 1 of the execution plan
+  struct Extra {
+    TfLiteNode node{};
+    const TfLiteRegistration* reg = nullptr;
+    std::string options;
+  };
+  std::vector<Extra*> extra;
+  TfLiteIntArray* plan = nullptr;
 
   static Model* self(TfLiteContext* c) { return (Model*)c->impl_; }
 
@@ -92,6 +101,25 @@ struct Model {
     return kTfLiteOk;
   }
 
+  static TfLiteStatus ExecutionPlan(TfLiteContext* c, TfLiteIntArray** out) {
+    Model* m = self(c);
+    const int n = (m->reg ? 1 : 0) + (int)m->extra.size();
+    TfLiteIntArrayFree(m->plan);
+    m->plan = TfLiteIntArrayCreate(n);
+    for (int i = 0; i < n; ++i) m->plan->data[i] = i;
+    *out = m->plan;
+    return kTfLiteOk;
+  }
+  static TfLiteStatus NodeAndRegistration(TfLiteContext* c, int idx, TfLiteNode** node, void** reg) {
+    Model* m = self(c);
+    if (idx == 0 && m->reg) { *node = &m->node; *reg = (void*)m->reg; return kTfLiteOk; }
+    const int k = idx - (m->reg ? 1 : 0);
+    if (k < 0 || k >= (int)m->extra.size()) return kTfLiteError;
+    *node = &m->extra[k]->node;
+    *reg = (void*)m->extra[k]->reg;
+    return kTfLiteOk;
+  }
+
   Model() {
     tensors.reserve(64);
     storage.reserve(64);
@@ -102,8 +130,20 @@ struct Model {
     ctx.AddTensors = AddTensors;
     ctx.recommended_num_threads = 1;
   }
+  void enable_plan() {          // chains only: the single-op tests keep an interpreter that answers no questions
+    ctx.GetExecutionPlan = ExecutionPlan;
+    ctx.GetNodeAndRegistration = NodeAndRegistration;
+  }
   ~Model() {
     if (reg && reg->free && inited) reg->free(&ctx, node.user_data);
+    for (Extra* e : extra) {
+      if (e->reg && e->reg->free) e->reg->free(&ctx, e->node.user_data);
+      TfLiteIntArrayFree(e->node.inputs);
+      TfLiteIntArrayFree(e->node.outputs);
+      TfLiteIntArrayFree(e->node.temporaries);
+      delete e;
+    }
+    TfLiteIntArrayFree(plan);
     for (auto& t : tensors) TfLiteIntArrayFree(t.dims);
     TfLiteIntArrayFree(node.inputs);
     TfLiteIntArrayFree(node.outputs);
@@ -138,7 +178,77 @@ TfLiteIntArray* make_array(const int* v, int n) {
 
 }  // namespace
 
+// A stand-in for a builtin CPU kernel in chain tests: copies its input tensor to its output tensor in the arena, i.e.
+// a reader of host memory that knows nothing about the LCE ops' device buffers.
+TfLiteStatus HostCopyPrepare(TfLiteContext* c, TfLiteNode* n) {
+  const TfLiteTensor* in = &c->tensors[n->inputs->data[0]];
+  return c->ResizeTensor(c, &c->tensors[n->outputs->data[0]], TfLiteIntArrayCopy(in->dims));
+}
+TfLiteStatus HostCopyInvoke(TfLiteContext* c, TfLiteNode* n) {
+  const TfLiteTensor* in = &c->tensors[n->inputs->data[0]];
+  TfLiteTensor* out = &c->tensors[n->outputs->data[0]];
+  memcpy(out->data.raw, in->data.raw, in->bytes < out->bytes ? in->bytes : out->bytes);
+  return kTfLiteOk;
+}
+const TfLiteRegistration* find_registration(const char* op_name, int variant, int use_resolver) {
+  using namespace compute_engine::tflite;
+  if (!strcmp(op_name, "HostCopy")) {
+    static TfLiteRegistration r = {nullptr, nullptr, HostCopyPrepare, HostCopyInvoke};
+    return &r;
+  }
+  if (use_resolver) {
+    Resolver r;
+    RegisterLCECustomOps(&r, (variant & 1) != 0, (variant & 2) != 0);
+    auto it = r.ops.find(op_name);
+    return it == r.ops.end() ? nullptr : it->second;
+  }
+  if (!strcmp(op_name, "LceBconv2d"))
+    return variant == 1 ? Register_BCONV_2D_REF() : variant == 2 ? Register_BCONV_2D_OPT_BGEMM()
+           : variant == 3 ? Register_BCONV_2D_OPT_INDIRECT_BGEMM() : Register_BCONV_2D();
+  if (!strcmp(op_name, "LceQuantize")) return Register_QUANTIZE();
+  if (!strcmp(op_name, "LceDequantize")) return Register_DEQUANTIZE();
+  if (!strcmp(op_name, "LceBMaxPool2d")) return Register_BMAXPOOL_2D();
+  return nullptr;
+}
+
 extern "C" {
+
+// ---- chains: an empty model, nodes added in execution order, an execution plan the ops may inspect ----
+void* lce_driver_create_chain(void) {
+  Model* m = new Model();
+  m->enable_plan();
+  return m;
+}
+// returns the node's index in the execution plan, or -1
+int lce_driver_add_node(void* h, const char* op_name, int variant, int use_resolver, const int* inputs, int n_in,
+                        const int* outputs, int n_out, const char* options, size_t options_len) {
+  Model* m = (Model*)h;
+  const TfLiteRegistration* reg = find_registration(op_name, variant, use_resolver);
+  if (!reg) return -1;
+  Model::Extra* e = new Model::Extra();
+  e->reg = reg;
+  e->options.assign(options ? options : "", options ? options_len : 0);
+  e->node.inputs = make_array(inputs, n_in);
+  e->node.outputs = make_array(outputs, n_out);
+  e->node.temporaries = TfLiteIntArrayCreate(0);
+  e->node.custom_initial_data = e->options.data();
+  e->node.custom_initial_data_size = (int)e->options.size();
+  e->node.user_data = reg->init ? reg->init(&m->ctx, e->options.data(), e->options.size()) : nullptr;
+  m->extra.push_back(e);
+  return (int)m->extra.size() - 1 + (m->reg ? 1 : 0);
+}
+int lce_driver_prepare_all(void* h) {
+  Model* m = (Model*)h;
+  if (m->reg) { const int rc = (int)m->reg->prepare(&m->ctx, &m->node); if (rc) return rc; }
+  for (Model::Extra* e : m->extra) { const int rc = (int)e->reg->prepare(&m->ctx, &e->node); if (rc) return rc; }
+  return 0;
+}
+int lce_driver_invoke_all(void* h) {
+  Model* m = (Model*)h;
+  if (m->reg) { const int rc = (int)m->reg->invoke(&m->ctx, &m->node); if (rc) return rc; }
+  for (Model::Extra* e : m->extra) { const int rc = (int)e->reg->invoke(&m->ctx, &e->node); if (rc) return rc; }
+  return 0;
+}
 
 // variant: for "LceBconv2d" 0 = Register_BCONV_2D (default), 1 = _REF, 2 = _OPT_BGEMM,
 // 3 = _OPT_INDIRECT_BGEMM; otherwise ignored.  With use_resolver != 0 the registration is

@@ -101,3 +101,98 @@ def test_prepare_again_after_resize_redoes_setup():
         m.set_data(xi, x)
         assert m.invoke() == 0, m.log
         assert np.array_equal(m.get(oi), O.bconv2d(spec, O.DST_F32, x, w, mul, bias))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device residency between LCE ops (csrc/tflite/lce_ops.cc, namespace resident)
+def _binary_section(m, b=3, h=12, w_=10, c0=64, c1=96, c2=64, host_reader=False, seed=5):
+    """LceQuantize -> LceBconv2d (bitpacked out) -> LceBMaxPool2d 2x2 -> LceBconv2d (float out), as nodes of `m`.
+    Returns (input index, output index, index of the first conv's output, reference fn)."""
+    g = synth.rng(seed)
+    s1 = O.ConvSpec(b, h, w_, c0, 3, 3, c1, padding=O.PADDING_SAME, pad_values=1)
+    s2 = O.ConvSpec(b, h // 2, w_ // 2, c1, 3, 3, c2, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    _, w1, mul1, bias1 = synth.conv_inputs(s1, seed + 1)
+    _, w2, mul2, bias2 = synth.conv_inputs(s2, seed + 2)
+    thr1 = O.thresholds_converter(s1, mul1, bias1)
+    x = g.standard_normal((b, h, w_, c0)).astype(np.float32)
+    t_x = m.add_tensor(T.FLOAT32, x.shape, x)
+    t_q = m.add_tensor(T.INT32, (0,) * 4)
+    t_w1 = m.add_tensor(T.INT32, s1.filter_shape(), w1, allocation=T.MMAP_RO)
+    t_thr = m.add_tensor(T.INT32, (c1,), thr1, allocation=T.MMAP_RO)
+    t_c1 = m.add_tensor(T.INT32, (0,) * 4)
+    t_p = m.add_tensor(T.INT32, (0,) * 4)
+    t_w2 = m.add_tensor(T.INT32, s2.filter_shape(), w2, allocation=T.MMAP_RO)
+    t_m2 = m.add_tensor(T.FLOAT32, (c2,), mul2, allocation=T.MMAP_RO)
+    t_b2 = m.add_tensor(T.FLOAT32, (c2,), bias2, allocation=T.MMAP_RO)
+    t_y = m.add_tensor(T.FLOAT32, (0,) * 4)
+    m.add_node("LceQuantize", [t_x], [t_q])
+    m.add_node("LceBconv2d", [t_q, t_w1, -1, -1, t_thr], [t_c1], flexbuf.bconv2d_options(c0, 1, 1, 1, 1, s1.padding, 1, O.ACT_NONE))
+    t_copy = None
+    if host_reader:                                   # a CPU kernel that reads the first conv's output from the arena
+        t_copy = m.add_tensor(T.INT32, (0,) * 4)
+        m.add_node("HostCopy", [t_c1], [t_copy])
+    m.add_node("LceBMaxPool2d", [t_c1], [t_p], flexbuf.bmaxpool_options(2, 2, 2, 2, 1))
+    m.add_node("LceBconv2d", [t_p, t_w2, t_m2, t_b2, -1], [t_y], flexbuf.bconv2d_options(c1, 1, 1, 1, 1, s2.padding, 1, O.ACT_RELU))
+
+    def reference(xin):
+        q = O.bitpack(xin)
+        c = O.bconv2d(s1, O.DST_BITPACKED, q, w1, thresholds=thr1)
+        p = O.bmaxpool(c, 2, 2, 2, 2, 1)
+        return c, O.bconv2d(s2, O.DST_F32, p, w2, mul2, bias2)
+    return t_x, t_y, t_c1, t_copy, x, reference
+
+
+def test_a_binary_section_crosses_pcie_once_in_each_direction():
+    """LceQuantize -> LceBconv2d -> LceBMaxPool2d -> LceBconv2d through RegisterLCECustomOps: tensors that only LCE ops read
+    stay in HBM (the reference hands them over in the arena, bconv2d.cc:550-564, quantization.cc:76-114, bmaxpool.cc:79-91),
+    so one invoke makes exactly ONE upload (the float input) and ONE download (the float output), bit-equal to the oracle --
+    also for a second invoke with new input data."""
+    m = T.ChainModel()
+    t_x, t_y, t_c1, _, x, reference = _binary_section(m)
+    T.set_residency(True)
+    assert m.prepare() == 0, m.log
+    for k in range(2):
+        xin = x if k == 0 else (x[::-1] * -1.0).copy()
+        m.set_data(t_x, xin)
+        T.transfer_counts(reset=True)
+        assert m.invoke() == 0, m.log
+        up, down, up_bytes, down_bytes = T.transfer_counts()
+        _, want = reference(xin)
+        got = m.get(t_y)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        assert (up, down) == (1, 1), (up, down)
+        assert up_bytes == xin.nbytes and down_bytes == want.nbytes
+
+
+def test_a_tensor_with_a_host_reader_is_still_copied_back():
+    m = T.ChainModel()
+    t_x, t_y, t_c1, t_copy, x, reference = _binary_section(m, host_reader=True)
+    T.set_residency(True)
+    assert m.prepare() == 0, m.log
+    m.set_data(t_x, x)
+    T.transfer_counts(reset=True)
+    assert m.invoke() == 0, m.log
+    up, down, _, _ = T.transfer_counts()
+    c1, want = reference(x)
+    assert np.array_equal(m.get(t_copy), c1) and np.array_equal(m.get(t_c1), c1)       # the arena copy is current
+    assert np.array_equal(m.get(t_y).view(np.int32), want.view(np.int32))
+    assert (up, down) == (1, 2), (up, down)                                             # ... and it cost one more download
+
+
+def test_residency_can_be_switched_off():
+    m = T.ChainModel()
+    t_x, t_y, t_c1, _, x, reference = _binary_section(m)
+    T.set_residency(False)
+    try:
+        assert m.prepare() == 0, m.log
+        m.set_data(t_x, x)
+        T.transfer_counts(reset=True)
+        assert m.invoke() == 0, m.log
+        up, down, _, _ = T.transfer_counts()
+        c1, want = reference(x)
+        assert np.array_equal(m.get(t_y).view(np.int32), want.view(np.int32)) and np.array_equal(m.get(t_c1), c1)
+        # every op stages its own tensors again: LceQuantize and LceBMaxPool2d through the counted copies, the two
+        # convolutions inside lce_hip_bconv2d_run_host (pipelined slices, not counted here)
+        assert (up, down) == (2, 2), (up, down)
+    finally:
+        T.set_residency(True)

@@ -208,3 +208,25 @@ def test_invoke_without_gpu_reports_error_instead_of_falling_back():
     assert m.prepare() == 0
     m.set_data(xi, x)
     assert m.invoke() == 1 and "no CPU fallback" in m.log
+
+
+def test_a_chain_of_ops_prepares_through_one_context_with_an_execution_plan():
+    """The chain driver: four LCE nodes behind one context that answers GetExecutionPlan / GetNodeAndRegistration (what the
+    ops' residency layer asks); shape inference runs node by node; without a GPU invoke fails loudly at the first op."""
+    m = T.ChainModel()
+    x = m.add_tensor(T.FLOAT32, (2, 12, 10, 64))
+    q = m.add_tensor(T.INT32, (0,) * 4)
+    _, w1, mul1, bias1 = synth.conv_inputs(O.ConvSpec(2, 12, 10, 64, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1), 1)
+    f1 = m.add_tensor(T.INT32, w1.shape, w1, allocation=T.MMAP_RO)
+    th = m.add_tensor(T.INT32, (96,), np.zeros(96, np.int32), allocation=T.MMAP_RO)
+    c1 = m.add_tensor(T.INT32, (0,) * 4)
+    p = m.add_tensor(T.INT32, (0,) * 4)
+    m.add_node("LceQuantize", [x], [q])
+    m.add_node("LceBconv2d", [q, f1, -1, -1, th], [c1], flexbuf.bconv2d_options(64, 1, 1, 1, 1, O.PADDING_SAME, 1, O.ACT_NONE))
+    m.add_node("LceBMaxPool2d", [c1], [p], flexbuf.bmaxpool_options(2, 2, 2, 2, 1))
+    assert m.prepare() == 0, m.log
+    assert m.shape(q) == (2, 12, 10, 2) and m.shape(c1) == (2, 12, 10, 3) and m.shape(p) == (2, 6, 5, 3)
+    if amd.device_count() == 0:
+        assert m.invoke() == 1 and "no CPU fallback" in m.log
+    with pytest.raises(ValueError):
+        m.add_node("NoSuchOp", [x], [q])

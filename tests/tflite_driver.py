@@ -46,6 +46,13 @@ def lib():
         l.lce_driver_log.argtypes = [C.c_void_p]
         l.lce_driver_log.restype = C.c_char_p
         l.lce_driver_flex_lookup.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.lce_driver_create_chain.restype = C.c_void_p
+        l.lce_driver_add_node.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                          C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_size_t]
+        l.lce_driver_prepare_all.argtypes = [C.c_void_p]
+        l.lce_driver_invoke_all.argtypes = [C.c_void_p]
+        l.lce_tflite_ops_set_residency.argtypes = [C.c_int]
+        l.lce_tflite_ops_transfer_counts.argtypes = [C.POINTER(C.c_uint64)] * 4 + [C.c_int]
         _lib = l
     return _lib
 
@@ -113,6 +120,43 @@ class SingleOpModel:
     @property
     def num_temporaries(self) -> int:
         return lib().lce_driver_num_temporaries(self._h)
+
+
+class ChainModel(SingleOpModel):
+    """Several nodes in execution order behind ONE context that answers GetExecutionPlan / GetNodeAndRegistration --
+    what the LCE ops need to keep tensors that only they read on the device.  "HostCopy" is a stand-in for a builtin CPU
+    kernel (copies its input to its output in the arena)."""
+
+    def __init__(self):
+        self._keep = []
+        self._h = lib().lce_driver_create_chain()
+        self._dtype = {}
+
+    def add_node(self, op_name, inputs, outputs, options: bytes = b"", variant: int = 0, use_resolver: bool = True) -> int:
+        i = (C.c_int * len(inputs))(*inputs)
+        o = (C.c_int * len(outputs))(*outputs)
+        idx = lib().lce_driver_add_node(self._h, op_name.encode(), variant, int(use_resolver), i, len(inputs), o, len(outputs),
+                                        options, len(options))
+        if idx < 0:
+            raise ValueError(f"unknown op {op_name}")
+        return idx
+
+    def prepare(self) -> int:
+        return lib().lce_driver_prepare_all(self._h)
+
+    def invoke(self) -> int:
+        return lib().lce_driver_invoke_all(self._h)
+
+
+def transfer_counts(reset: bool = False):
+    """(host->device copies, device->host copies, bytes up, bytes down) made by the ops' invokes since the last reset."""
+    v = [C.c_uint64() for _ in range(4)]
+    lib().lce_tflite_ops_transfer_counts(*[C.byref(x) for x in v], int(reset))
+    return tuple(int(x.value) for x in v)
+
+
+def set_residency(on: bool):
+    lib().lce_tflite_ops_set_residency(int(on))
 
 
 def build_bconv2d(spec, dst, filt, post_mul, post_bias, thresholds, variant=BCONV_DEFAULT,
