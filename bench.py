@@ -485,7 +485,66 @@ def extra_measurements(amd, torch, spec, args, dev):
                                                 "timed_from": timed_from,
                                                 "note": "26 MB input, just written: largely served by the 256 MB Infinity Cache"}
     del fx, ow, fo, po
+    try:
+        extra["tflite_ops_chain_host_tensors"] = tflite_chain_timing()
+    except Exception as exc:   # the op glue is optional for the headline
+        extra["tflite_ops_chain_host_tensors"] = {"error": repr(exc)}
     return extra
+
+
+def tflite_chain_timing(batch=64):
+    """PCIe-INCLUSIVE (never part of `value`): LceQuantize -> LceBconv2d -> LceBMaxPool2d -> LceBconv2d through the registered
+    TFLite ops with HOST tensors (the interpreter's arena), as a converted model's binary section runs them, with and without
+    the ops' device residency (csrc/tflite/lce_ops.cc: tensors that only LCE ops read stay in HBM).  Synthetic operands; the
+    chain driver stands in for the interpreter (csrc/tflite/single_op_driver.cc)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import flexbuf               # flexbuffer writer for the ops' custom options (test tooling, not the oracle)
+    import tflite_driver as T    # ctypes front-end of the chain driver
+    g = np.random.default_rng(11)
+    h = w_ = 56
+    c = 64
+    x = g.standard_normal((batch, h, w_, c)).astype(np.float32)
+    w1 = g.integers(-2**31, 2**31, (c, 3, 3, c // 32), dtype=np.int64).astype(np.int32)
+    w2 = g.integers(-2**31, 2**31, (c, 3, 3, c // 32), dtype=np.int64).astype(np.int32)
+    thr = np.full(c, 9 * c // 2, np.int32)
+    mul, bias = np.ones(c, np.float32), np.zeros(c, np.float32)
+    out = {}
+    for label, on in (("resident", True), ("every_op_stages_its_tensors", False)):
+        m = T.ChainModel()
+        t_x = m.add_tensor(T.FLOAT32, x.shape, x)
+        t_q = m.add_tensor(T.INT32, (0,) * 4)
+        t_w1 = m.add_tensor(T.INT32, w1.shape, w1, allocation=T.MMAP_RO)
+        t_t = m.add_tensor(T.INT32, (c,), thr, allocation=T.MMAP_RO)
+        t_c = m.add_tensor(T.INT32, (0,) * 4)
+        t_p = m.add_tensor(T.INT32, (0,) * 4)
+        t_w2 = m.add_tensor(T.INT32, w2.shape, w2, allocation=T.MMAP_RO)
+        t_m = m.add_tensor(T.FLOAT32, (c,), mul, allocation=T.MMAP_RO)
+        t_b = m.add_tensor(T.FLOAT32, (c,), bias, allocation=T.MMAP_RO)
+        t_y = m.add_tensor(T.FLOAT32, (0,) * 4)
+        m.add_node("LceQuantize", [t_x], [t_q])
+        m.add_node("LceBconv2d", [t_q, t_w1, -1, -1, t_t], [t_c], flexbuf.bconv2d_options(c, 1, 1, 1, 1, 0, 1, 0))
+        m.add_node("LceBMaxPool2d", [t_c], [t_p], flexbuf.bmaxpool_options(2, 2, 2, 2, 1))
+        m.add_node("LceBconv2d", [t_p, t_w2, t_m, t_b, -1], [t_y], flexbuf.bconv2d_options(c, 1, 1, 1, 1, 0, 1, 0))
+        T.set_residency(on)
+        try:
+            if m.prepare() != 0 or m.invoke() != 0:
+                raise RuntimeError(m.log)
+            T.transfer_counts(reset=True)
+            t = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                if m.invoke() != 0:
+                    raise RuntimeError(m.log)
+            dt = (time.perf_counter() - t) / n
+            up, down, upb, downb = T.transfer_counts()
+            out[label] = {"ms_per_invoke": dt * 1e3, "uploads_per_invoke": up / n, "downloads_per_invoke": down / n,
+                          "bytes_up_per_invoke": upb / n, "bytes_down_per_invoke": downb / n}
+        finally:
+            T.set_residency(True)
+            m.close()
+    out["workload"] = (f"{batch} x {h}x{w_}x{c} float -> LceQuantize -> LceBconv2d 3x3 {c}->{c} (bitpacked) -> LceBMaxPool2d 2x2 -> "
+                       f"LceBconv2d 3x3 {c}->{c} (float): {x.nbytes / 1e6:.1f} MB up, {batch * 28 * 28 * c * 4 / 1e6:.1f} MB down, host wall time")
+    return out
 
 
 if __name__ == "__main__":

@@ -5,15 +5,87 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "flexbuffer_map.h"
 #include "tflite_flatbuffer_reader.h"
 
+struct lce_tflite_section {
+  std::vector<int32_t> ops, inputs, outputs;
+};
 struct lce_tflite_model {
   lce_tfl::Model m;
+  std::vector<lce_tflite_section> sections;   // built by Partition() right after parsing
+  void Partition();
 };
+
+namespace {
+bool IsLceOp(const lce_tfl::Operator& o) {
+  return o.builtin_code == 32 && (o.custom_code == "LceBconv2d" || o.custom_code == "LceQuantize" ||
+                                  o.custom_code == "LceDequantize" || o.custom_code == "LceBMaxPool2d");
+}
+}  // namespace
+
+// The partition a delegate would get (tensorflow/lite/graph_info.cc, PartitionGraphIntoIndependentNodeSubsets, restated from
+// its published description): alternate between epochs of LCE operators and epochs of the others; in an epoch every
+// operator of the epoch's kind whose inputs are all ready joins, repeatedly, until nothing more can; the LCE operators
+// of one epoch are one section.
+void lce_tflite_model::Partition() {
+  const int n_ops = (int)m.operators.size(), n_t = (int)m.tensors.size();
+  std::vector<char> ready(n_t, 1), done(n_ops, 0);
+  for (const lce_tfl::Operator& o : m.operators)
+    for (int32_t t : o.outputs)
+      if (t >= 0 && t < n_t) ready[t] = 0;                   // produced by an operator: not ready until it has run
+  int remaining = n_ops;
+  bool lce_epoch = true;
+  int idle_epochs = 0;
+  while (remaining > 0 && idle_epochs < 2) {
+    lce_tflite_section sec;
+    bool progress = true, any = false;
+    while (progress) {
+      progress = false;
+      for (int i = 0; i < n_ops; ++i) {
+        const lce_tfl::Operator& o = m.operators[i];
+        if (done[i] || IsLceOp(o) != lce_epoch) continue;
+        bool ok = true;
+        for (int32_t t : o.inputs) ok = ok && (t < 0 || t >= n_t || ready[t]);
+        if (!ok) continue;
+        done[i] = 1;
+        --remaining;
+        progress = any = true;
+        for (int32_t t : o.outputs)
+          if (t >= 0 && t < n_t) ready[t] = 1;
+        if (lce_epoch) sec.ops.push_back(i);
+      }
+    }
+    if (lce_epoch && !sec.ops.empty()) {
+      std::sort(sec.ops.begin(), sec.ops.end());
+      std::vector<char> inside(n_t, 0), in_sec(n_ops, 0);
+      for (int32_t i : sec.ops) {
+        in_sec[i] = 1;
+        for (int32_t t : m.operators[i].outputs)
+          if (t >= 0 && t < n_t) inside[t] = 1;
+      }
+      for (int32_t i : sec.ops)
+        for (int32_t t : m.operators[i].inputs)
+          if (t >= 0 && t < n_t && !inside[t] && !m.tensors[t].data &&
+              std::find(sec.inputs.begin(), sec.inputs.end(), t) == sec.inputs.end())
+            sec.inputs.push_back(t);
+      for (int32_t t = 0; t < n_t; ++t) {
+        if (!inside[t]) continue;
+        bool outside_reader = std::find(m.outputs.begin(), m.outputs.end(), t) != m.outputs.end();
+        for (int i = 0; i < n_ops && !outside_reader; ++i)
+          if (!in_sec[i]) outside_reader = std::find(m.operators[i].inputs.begin(), m.operators[i].inputs.end(), t) != m.operators[i].inputs.end();
+        if (outside_reader) sec.outputs.push_back(t);
+      }
+      sections.push_back(sec);
+    }
+    idle_epochs = any ? 0 : idle_epochs + 1;                 // (a graph with a cycle or a dangling input would never finish)
+    lce_epoch = !lce_epoch;
+  }
+}
 
 namespace {
 thread_local std::string g_model_error;
@@ -28,7 +100,10 @@ extern "C" {
 lce_tflite_model* lce_tflite_model_open(const void* data, size_t size, char* err, size_t err_len) {
   auto* model = new (std::nothrow) lce_tflite_model{};
   std::string e = "out of memory";
-  if (model && data && model->m.Parse(data, size, &e)) return model;
+  if (model && data && model->m.Parse(data, size, &e)) {
+    model->Partition();
+    return model;
+  }
   if (!data) e = "null buffer";
   if (err && err_len) snprintf(err, err_len, "%s", e.c_str());
   delete model;
@@ -81,6 +156,20 @@ lce_hip_status lce_tflite_model_operator(const lce_tflite_model* model, int32_t 
   info->num_outputs = (int32_t)o.outputs.size();
   info->custom_options = o.custom_options;
   info->custom_options_size = o.custom_options_size;
+  return LCE_HIP_OK;
+}
+
+int32_t lce_tflite_model_num_sections(const lce_tflite_model* model) { return model ? (int32_t)model->sections.size() : 0; }
+lce_hip_status lce_tflite_model_section(const lce_tflite_model* model, int32_t index, lce_tflite_section_info* info) {
+  if (!model || !info || index < 0 || index >= (int32_t)model->sections.size())
+    return Fail(LCE_HIP_ERR_INVALID, "lce_tflite_model_section: bad argument");
+  const lce_tflite_section& s = model->sections[index];
+  info->ops = s.ops.data();
+  info->num_ops = (int32_t)s.ops.size();
+  info->inputs = s.inputs.data();
+  info->num_inputs = (int32_t)s.inputs.size();
+  info->outputs = s.outputs.data();
+  info->num_outputs = (int32_t)s.outputs.size();
   return LCE_HIP_OK;
 }
 

@@ -176,6 +176,14 @@ Readers readers_of(TfLiteContext* c, const TfLiteNode* self, int tensor) {
   return r;
 }
 
+// a host-in / host-out call that stages its tensors inside the library (lce_hip_bconv2d_run_host)
+void count_host_pass(size_t up_bytes, size_t down_bytes) {
+  ++g_h2d;
+  g_h2d_bytes += up_bytes;
+  ++g_d2h;
+  g_d2h_bytes += down_bytes;
+}
+
 // ---- what an op's invoke does with its tensors ----
 // input: the producer's device copy when there is one, else an upload into a per-tensor staging buffer
 lce_hip_status input(TfLiteContext* c, int tensor, const void* host, size_t bytes, const void** dev) {
@@ -425,7 +433,8 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // :550-564
   const int in_idx = node->inputs->data[0];
   const bool in_resident = resident::current(context, in_idx, input->bytes) != nullptr;
   if (!in_resident && !op->readers.keep_on_device()) {
-    // host in, host out: the pipelined path (batch slices on three streams)
+    // host in, host out: the pipelined path (batch slices on three streams); counted as one pass in each direction
+    resident::count_host_pass(input->bytes, output->bytes);
     LCE_ENSURE_HIP(context, lce_hip_bconv2d_run_host(op->plan, input->data.i32, output->data.data));
     return kTfLiteOk;
   }

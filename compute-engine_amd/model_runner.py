@@ -8,8 +8,12 @@ reference feeds samples one at a time through a batch-1 interpreter (the convert
 to 1, mlir/tf_tfl_passes.cc:141-144) while this runner re-plans every LceBconv2d for
 ``batch_size`` images and keeps all intermediate tensors in HBM.
 
-Only graphs made of LCE custom ops (LceQuantize, LceBconv2d, LceBMaxPool2d, LceDequantize) can
-run: anything else raises ``NotImplementedError`` -- float stems / heads stay with TensorFlow Lite.
+Graphs made of LCE custom ops only (LceQuantize, LceBconv2d, LceBMaxPool2d, LceDequantize) run end to end
+(``predict``).  A MIXED graph -- a real converted model: float stem, batch norms / adds between binary
+convolutions, float head -- is cut into its binary SECTIONS (``Interpreter.sections``: the maximal groups of LCE ops
+with no builtin operator between them, include/lce_tflite_model.h); ``run_section(k, inputs)`` runs one of them on
+its boundary tensors, the float operators stay with TensorFlow Lite (``predict`` on such a graph raises
+``NotImplementedError`` naming the first builtin operator).
 The model file is read by the bounds-checked reader in csrc/tflite (include/lce_tflite_model.h).
 """
 from __future__ import annotations
@@ -17,8 +21,7 @@ from __future__ import annotations
 import ctypes as C
 import importlib
 import os
-import subprocess
-from typing import List, Optional, Union
+from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -43,12 +46,31 @@ class _OperatorInfo(C.Structure):
                 ("custom_options", C.POINTER(C.c_uint8)), ("custom_options_size", C.c_size_t)]
 
 
+class _SectionInfo(C.Structure):
+    _fields_ = [("ops", C.POINTER(C.c_int32)), ("num_ops", C.c_int32), ("inputs", C.POINTER(C.c_int32)), ("num_inputs", C.c_int32),
+                ("outputs", C.POINTER(C.c_int32)), ("num_outputs", C.c_int32)]
+
+
+class Section:
+    """A maximal group of LCE ops with no builtin operator between them: operator indices in execution order, the
+    non-constant tensors it reads from outside, the tensors it must deliver (read outside it, or graph outputs)."""
+
+    def __init__(self, info: _SectionInfo):
+        self.ops = [info.ops[i] for i in range(info.num_ops)]
+        self.inputs = [info.inputs[i] for i in range(info.num_inputs)]
+        self.outputs = [info.outputs[i] for i in range(info.num_outputs)]
+
+    def __repr__(self):
+        return f"Section(ops={self.ops}, inputs={self.inputs}, outputs={self.outputs})"
+
+
 def tflite_lib() -> C.CDLL:
     global _tfl
     if _tfl is None:
         path = os.path.join(_TFL_DIR, "liblce_tflite_ops.so")
-        if not os.path.exists(path):
-            subprocess.run(["make", "-C", _TFL_DIR], check=True, capture_output=True)
+        if not os.path.exists(path):     # a build step belongs to the build, not to an import
+            raise FileNotFoundError(f"{path} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    f"(or `make -C {_TFL_DIR}`)")
         l = C.CDLL(path)
         l.lce_tflite_model_open.restype = C.c_void_p
         l.lce_tflite_model_open.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
@@ -62,6 +84,8 @@ def tflite_lib() -> C.CDLL:
         l.lce_tflite_model_bconv2d_plan.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         l.lce_tflite_option_int.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_int32)]
         l.lce_tflite_model_last_error.restype = C.c_char_p
+        l.lce_tflite_model_num_sections.argtypes = [C.c_void_p]
+        l.lce_tflite_model_section.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_SectionInfo)]
         _tfl = l
     return _tfl
 
@@ -116,6 +140,11 @@ class LceModel:
         buf = (C.c_int32 * 64)()
         self.inputs = [buf[i] for i in range(l.lce_tflite_model_inputs(self._h, buf, 64))]
         self.outputs = [buf[i] for i in range(l.lce_tflite_model_outputs(self._h, buf, 64))]
+        self.sections: List[Section] = []
+        for i in range(l.lce_tflite_model_num_sections(self._h)):
+            info = _SectionInfo()
+            _amd.check(l.lce_tflite_model_section(self._h, i, C.byref(info)))
+            self.sections.append(Section(info))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -146,13 +175,27 @@ class Interpreter:
         self.batch_size = int(batch_size)
         self.device = device
         self._sem = _amd.SEM_REFERENCE if use_reference_bconv else _amd.SEM_OPTIMIZED
-        for op in self.model.operators:
-            if op.builtin_code != 32 or op.custom_code not in LCE_OPS:
-                raise NotImplementedError(
-                    "only LCE custom ops run here; the model contains builtin operator %d %r"
-                    % (op.builtin_code, op.custom_code))
+        self._foreign = [(i, op) for i, op in enumerate(self.model.operators)
+                         if op.builtin_code != 32 or op.custom_code not in LCE_OPS]
         self._plans = {}   # (operator index, batch) -> Bconv2dPlan
         self._fused = None  # LceBconv2d operator index -> LceQuantize consumers of its output (see _quantize_consumers)
+
+    @property
+    def sections(self) -> List[Section]:
+        """The binary sections of the graph (one covering everything for an LCE-only graph)."""
+        return self.model.sections
+
+    @property
+    def lce_only(self) -> bool:
+        return not self._foreign
+
+    def _require_lce_only(self):
+        if self._foreign:
+            i, op = self._foreign[0]
+            raise NotImplementedError(
+                "only LCE custom ops run here; the model contains builtin operator %d %r (operator %d): run its %d binary "
+                "section(s) with run_section() and keep the float operators in TensorFlow Lite"
+                % (op.builtin_code, op.custom_code, i, len(self.model.sections)))
 
     # ---- the reference Interpreter's properties (interpreter_base.py:34-72) -------------------
     def _props(self, ids):
@@ -199,25 +242,29 @@ class Interpreter:
         return self._plans[key]
 
     def _quantize_consumers(self):
-        """op index of an LceBconv2d with a float / int8 output -> the LceQuantize ops that read that output: the
-        convolution's epilogue writes their result as its second output (lce_hip_bconv2d_run_dual)."""
+        """op index of an LceBconv2d with a float / int8 output -> the LceQuantize ops OF THE SAME SECTION that read that
+        output: the convolution's epilogue writes their result as its second output (lce_hip_bconv2d_run_dual)."""
         if self._fused is None:
             ops = self.model.operators
             self._fused = {}
-            for i, op in enumerate(ops):
-                if op.custom_code != "LceBconv2d" or self.model.tensors[op.outputs[0]].type not in (FLOAT32, INT8):
-                    continue
-                js = [j for j in range(i + 1, len(ops))
-                      if ops[j].custom_code == "LceQuantize" and ops[j].inputs[0] == op.outputs[0]]
-                if js:
-                    self._fused[i] = js
+            for sec in self.model.sections:
+                for i in sec.ops:
+                    op = ops[i]
+                    if op.custom_code != "LceBconv2d" or self.model.tensors[op.outputs[0]].type not in (FLOAT32, INT8):
+                        continue
+                    js = [j for j in sec.ops if j > i and ops[j].custom_code == "LceQuantize" and ops[j].inputs[0] == op.outputs[0]]
+                    if js:
+                        self._fused[i] = js
         return self._fused
 
-    def _run_ops(self, live, batch):
-        """Runs the graph on device tensors; `live` maps tensor index -> CUDA tensor."""
+    def _run_ops(self, live, batch, op_indices=None, wanted=None):
+        """Runs operators `op_indices` (default: the whole graph) on device tensors; `live` maps tensor index -> CUDA
+        tensor and must hold every non-constant tensor they read from outside; returns the tensors `wanted`
+        (default: the graph outputs)."""
         import torch
         fused, done = self._quantize_consumers(), set()
-        for i, op in enumerate(self.model.operators):
+        for i in (range(len(self.model.operators)) if op_indices is None else op_indices):
+            op = self.model.operators[i]
             if i in done:
                 continue
             x = live[op.inputs[0]]
@@ -239,11 +286,37 @@ class Interpreter:
             else:
                 y = self._plan(i, batch).run(x)
             live[op.outputs[0]] = y
-        return [live[o] for o in self.model.outputs]
+        return [live[o] for o in (self.model.outputs if wanted is None else wanted)]
+
+    def run_section(self, index: int, inputs: Union[Sequence[np.ndarray], Dict[int, np.ndarray]]):
+        """Runs binary section `index` of a (mixed) graph on its boundary tensors: `inputs` = one array per entry of
+        ``sections[index].inputs`` in that order (or a dict tensor index -> array), each with a leading batch axis of any
+        size (the plans are re-made for it); returns one NumPy array per entry of ``sections[index].outputs``.  Everything in
+        between stays in HBM.  The float operators around the section are TensorFlow Lite's job."""
+        import torch
+        sec = self.model.sections[index]
+        if isinstance(inputs, dict):
+            arrs = [inputs[t] for t in sec.inputs]
+        else:
+            arrs = list(inputs)
+        if len(arrs) != len(sec.inputs):
+            raise ValueError("section %d reads %d tensor(s) %r, got %d array(s)" % (index, len(sec.inputs), sec.inputs, len(arrs)))
+        live = {}
+        for t, a in zip(sec.inputs, arrs):
+            info = self.model.tensors[t]
+            a = np.ascontiguousarray(a, dtype=_NP[info.type])
+            if tuple(a.shape[1:]) != tuple(info.shape[1:]):
+                raise ValueError("tensor %d (%s) has shape [batch, %s], got %r" % (t, info.name, ", ".join(map(str, info.shape[1:])), a.shape))
+            live[t] = torch.from_numpy(a).to(self.device)
+        batch = arrs[0].shape[0]
+        if any(a.shape[0] != batch for a in arrs):
+            raise ValueError("all inputs of a section share the batch dimension")
+        return [y.cpu().numpy() for y in self._run_ops(live, batch, sec.ops, sec.outputs)]
 
     def _run_batch(self, inputs):
         """One batch, synchronously (kept for callers that drive batches themselves)."""
         import torch
+        self._require_lce_only()
         live = {idx: torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
                 for idx, arr in zip(self.model.inputs, inputs)}
         return [y.cpu().numpy() for y in self._run_ops(live, inputs[0].shape[0])]
@@ -285,6 +358,7 @@ class Interpreter:
         batch k-1 -- so the PCIe copies (40x the kernel time for a float 56x56x256 map) overlap the compute
         and each other's direction."""
         import torch
+        self._require_lce_only()
         dev = torch.device(self.device)
         n_in = len(self.model.inputs)
         in_dt = [self.input_types[k] for k in range(n_in)]

@@ -61,6 +61,28 @@ typedef struct lce_tflite_operator_info {
 } lce_tflite_operator_info;
 lce_hip_status lce_tflite_model_operator(const lce_tflite_model* model, int32_t index, lce_tflite_operator_info* info);
 
+/* Binary SECTIONS of a mixed graph.  A converted model interleaves builtin float operators (the stem, batch norms, adds,
+ * the head) with LCE custom ops; what this library runs are the maximal groups of LCE ops that can execute without a
+ * builtin operator in between -- the partition a TFLite delegate would be handed (the operators are walked in the file's
+ * execution order; an LCE op joins the current section when every tensor it reads is a constant, a graph input, or was
+ * produced before or inside this section; the first op that is not LCE and cannot wait closes it).  The reference runs whole
+ * graphs through one interpreter (tflite/python/interpreter_base.py:74-95, examples/lce_minimal.cc:28-62); a host that
+ * keeps TensorFlow Lite for the float operators calls a section between them: feed `inputs`, collect `outputs`.
+ *   ops     : operator indices of the section, in execution order
+ *   inputs  : non-constant tensors the section reads but does not produce
+ *   outputs : tensors it produces that an operator outside the section, or the graph's output list, reads
+ * The arrays are owned by the model. */
+typedef struct lce_tflite_section_info {
+  const int32_t* ops;
+  int32_t num_ops;
+  const int32_t* inputs;
+  int32_t num_inputs;
+  const int32_t* outputs;
+  int32_t num_outputs;
+} lce_tflite_section_info;
+int32_t lce_tflite_model_num_sections(const lce_tflite_model* model);
+lce_hip_status lce_tflite_model_section(const lce_tflite_model* model, int32_t index, lce_tflite_section_info* info);
+
 /* Builds a ready-to-run plan for operator `index`, which must be an LceBconv2d: descriptor
  * from the op's option map + tensor shapes / types / output quantization exactly as
  * bconv2d::Init + Prepare collect them (tflite/kernels/bconv2d.cc:85-131,137-300), weights

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import synth
-from test_model_reader_host import oracle_forward, small_model
+import oracle_lib as O
+from test_model_reader_host import mixed_model, oracle_forward, small_model
 
 amd = importlib.import_module("compute-engine_amd")
 mr = importlib.import_module("compute-engine_amd.model_runner")
@@ -63,3 +64,33 @@ def test_predict_accepts_the_reference_iterator_forms_and_pipelines_many_batches
         it.predict("not samples")
     with pytest.raises(ValueError):
         it.predict(iter(()))
+
+
+def test_binary_sections_of_a_mixed_graph_run_on_their_boundary_tensors():
+    """A QuickNet-shaped mixed graph (builtin CONV_2D stem, ADDs between LceBconv2ds, builtin pooling head): every binary
+    section runs on the GPU from its boundary tensors, in true batches, and equals the oracle run op by op; the float
+    operators in between are done here in NumPy (TensorFlow Lite's job in a deployment)."""
+    data, t, p = mixed_model(31)
+    it = mr.Interpreter(data, batch_size=8)
+    n = 5
+    g = synth.rng(9)
+    stem = g.standard_normal((n, 10, 10, 64)).astype(np.float32)          # what the float stem would hand over
+    s_a, _, s_c, s_d = (s.with_batch(n) for s in p["specs"])
+    # section 0: LceQuantize + LceBconv2d (one pass through run_dual would need a reader of the bits; here: two ops)
+    (y0,) = it.run_section(0, [stem])
+    want_y0 = O.bconv2d(s_a, O.DST_F32, O.bitpack(stem), p["w"][0], p["m"][0], p["b"][0])
+    assert np.array_equal(y0.view(np.int32), want_y0.view(np.int32))
+    r0 = y0 + stem                                                           # builtin ADD
+    (y1,) = it.run_section(1, {t["r0"]: r0})
+    want_y1 = O.bconv2d(s_a, O.DST_F32, O.bitpack(r0), p["w"][1], p["m"][1], p["b"][1])
+    assert np.array_equal(y1.view(np.int32), want_y1.view(np.int32))
+    r1 = y1 + r0
+    outs = dict(zip(it.sections[2].outputs, it.run_section(2, [r1])))
+    b2 = O.bconv2d(s_c, O.DST_BITPACKED, O.bitpack(r1), p["w"][2], thresholds=p["thr2"])
+    want_y3 = O.bconv2d(s_d, O.DST_F32, O.bmaxpool(b2, 2, 2, 2, 2, O.PADDING_VALID), p["w"][3], p["m"][3], p["b"][3])
+    assert np.array_equal(outs[t["y3"]].view(np.int32), want_y3.view(np.int32))
+    assert np.array_equal(outs[t["d2"]], O.unpack(b2, 96, np.float32))
+    with pytest.raises(ValueError, match="reads 1 tensor"):
+        it.run_section(2, [r1, r1])
+    with pytest.raises(ValueError, match="has shape"):
+        it.run_section(2, [r1[:, :5]])

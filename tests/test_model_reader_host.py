@@ -184,14 +184,92 @@ def test_malformed_buffers_are_refused_not_crashed_on():
                     pass
 
 
-def test_interpreter_refuses_graphs_with_builtin_ops():
+def test_interpreter_refuses_to_predict_graphs_with_builtin_ops():
     b = ModelBuilder()
     t0 = b.tensor([1, 4, 4, 32], np.float32, "x")
     t1 = b.tensor([1, 4, 4, 32], np.float32, "y")
     b.inputs, b.outputs = [t0], [t1]
     b.builtin_op(19, [t0], [t1])      # RELU
+    it = mr.Interpreter(b.finish())
+    assert not it.lce_only and it.sections == []
     with pytest.raises(NotImplementedError, match="only LCE custom ops"):
-        mr.Interpreter(b.finish())
+        it.predict(np.zeros((1, 4, 4, 32), np.float32))
+
+
+CONV_2D, ADD, MAX_POOL_2D = 3, 0, 17      # schema.fbs BuiltinOperator values
+
+
+def mixed_model(seed=0):
+    """A QuickNet-shaped mixed graph (float stem, residual ADDs between binary convolutions, float pooling head):
+
+        x --CONV_2D(builtin stem)--> s --LceQuantize--> q0 --LceBconv2d(float)--> y0 --ADD(s)--> r0
+          r0 --LceQuantize--> q1 --LceBconv2d(float)--> y1 --ADD(r0)--> r1
+          r1 --LceQuantize--> q2 --LceBconv2d(bitpacked)--> b2 --LceBMaxPool2d--> p2 --LceBconv2d(float)--> y3 --MAX_POOL_2D--> out
+          b2 --LceDequantize--> d2 (second graph output)
+
+    Binary sections: {Quantize, Bconv} (s -> y0), {Quantize, Bconv} (r0 -> y1), {Quantize, Bconv, BMaxPool, Bconv, Dequantize}
+    (r1 -> y3, d2)."""
+    H, C = 10, 64
+    s_a = O.ConvSpec(1, H, H, C, 3, 3, C, padding=O.PADDING_SAME, pad_values=1)
+    s_c = O.ConvSpec(1, H, H, C, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    s_d = O.ConvSpec(1, H // 2, H // 2, 96, 3, 3, 32, padding=O.PADDING_SAME, pad_values=1)
+    _, w0, m0, b0 = synth.conv_inputs(s_a, seed + 1)
+    _, w1, m1, b1 = synth.conv_inputs(s_a, seed + 2)
+    _, w2, m2, b2 = synth.conv_inputs(s_c, seed + 3)
+    _, w3, m3, b3 = synth.conv_inputs(s_d, seed + 4)
+    thr2 = O.thresholds_converter(s_c, m2, b2)
+    b = ModelBuilder()
+    f32 = lambda shape, name, data=None: b.tensor(shape, np.float32, name, data)
+    i32 = lambda shape, name, data=None: b.tensor(shape, np.int32, name, data)
+    x = f32([1, H, H, 3], "image")
+    k = f32([C, 3, 3, 3], "stem_filter", synth.rng(seed).standard_normal((C, 3, 3, 3)).astype(np.float32))
+    kb = f32([C], "stem_bias", np.zeros(C, np.float32))
+    s = f32([1, H, H, C], "stem")
+    q0, y0, r0 = i32([1, H, H, 2], "q0"), f32([1, H, H, C], "y0"), f32([1, H, H, C], "r0")
+    q1, y1, r1 = i32([1, H, H, 2], "q1"), f32([1, H, H, C], "y1"), f32([1, H, H, C], "r1")
+    q2, bb2, p2 = i32([1, H, H, 2], "q2"), i32([1, H, H, 3], "b2"), i32([1, H // 2, H // 2, 3], "p2")
+    y3, out, d2 = f32([1, H // 2, H // 2, 32], "y3"), f32([1, 2, 2, 32], "pooled"), f32([1, H, H, 96], "d2")
+    tw = [i32(w.shape, "w%d" % i, w) for i, w in enumerate((w0, w1, w2, w3))]
+    tm = [f32([len(m)], "m%d" % i, m) for i, m in enumerate((m0, m1, m2, m3))]
+    tb = [f32([len(v)], "b%d" % i, v) for i, v in enumerate((b0, b1, b2, b3))]
+    tthr = i32([96], "thr2", thr2)
+    b.inputs, b.outputs = [x], [out, d2]
+    b.builtin_op(CONV_2D, [x, k, kb], [s])                                             # 0
+    b.custom_op("LceQuantize", [s], [q0], b"")                                         # 1
+    b.custom_op("LceBconv2d", [q0, tw[0], tm[0], tb[0], -1], [y0], bconv_options(s_a))  # 2
+    b.builtin_op(ADD, [y0, s], [r0])                                                   # 3
+    b.custom_op("LceQuantize", [r0], [q1], b"")                                        # 4
+    b.custom_op("LceBconv2d", [q1, tw[1], tm[1], tb[1], -1], [y1], bconv_options(s_a))  # 5
+    b.builtin_op(ADD, [y1, r0], [r1])                                                  # 6
+    b.custom_op("LceQuantize", [r1], [q2], b"")                                        # 7
+    b.custom_op("LceBconv2d", [q2, tw[2], -1, -1, tthr], [bb2], bconv_options(s_c))     # 8
+    b.custom_op("LceBMaxPool2d", [bb2], [p2], flexbuf.bmaxpool_options(2, 2, 2, 2, O.PADDING_VALID))   # 9
+    b.custom_op("LceBconv2d", [p2, tw[3], tm[3], tb[3], -1], [y3], bconv_options(s_d))  # 10
+    b.builtin_op(MAX_POOL_2D, [y3], [out])                                             # 11
+    b.custom_op("LceDequantize", [bb2], [d2], b"")                                     # 12
+    ids = dict(s=s, y0=y0, r0=r0, y1=y1, r1=r1, y3=y3, d2=d2, b2=bb2)
+    params = dict(specs=(s_a, s_a, s_c, s_d), w=(w0, w1, w2, w3), m=(m0, m1, m2, m3), b=(b0, b1, b2, b3), thr2=thr2)
+    return b.finish(), ids, params
+
+
+def test_binary_sections_of_a_mixed_graph():
+    """The partition of include/lce_tflite_model.h on a QuickNet-shaped graph: three sections, their boundary tensors, and --
+    the LceDequantize that comes LAST in the file belongs to the third section (it can run as soon as b2 exists)."""
+    data, t, _ = mixed_model()
+    it = mr.Interpreter(data)
+    assert not it.lce_only
+    secs = it.sections
+    assert [s.ops for s in secs] == [[1, 2], [4, 5], [7, 8, 9, 10, 12]]
+    assert [s.inputs for s in secs] == [[t["s"]], [t["r0"]], [t["r1"]]]
+    assert [s.outputs for s in secs] == [[t["y0"]], [t["y1"]], sorted([t["y3"], t["d2"]])]
+    with pytest.raises(NotImplementedError, match="run_section"):
+        it.predict(np.zeros((1, 10, 10, 3), np.float32))
+    # an LCE-only graph is ONE section that reads the graph inputs and delivers the graph outputs
+    data, _ = small_model(3)
+    one = mr.Interpreter(data)
+    assert one.lce_only and len(one.sections) == 1
+    assert one.sections[0].ops == list(range(7)) and one.sections[0].inputs == one.model.inputs
+    assert sorted(one.sections[0].outputs) == sorted(one.model.outputs)
 
 
 def test_model_abi_exports_every_declared_symbol():
