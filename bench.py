@@ -434,6 +434,9 @@ def extra_measurements(amd, torch, spec, args, dev):
                 ch.run_chain()
             graph.replay()
             torch.cuda.synchronize(dev)
+            # (the first replays after instantiation are slow; profiles/r03/graph_gaps.txt: inside a replay the kernels run
+            # back to back exactly as eager launches do, between two replays the GPU idles ~9 us)
+            spin_up(torch, dev, graph.replay)
             entry["device_resident_chain_hip_graph_ms"] = _event_time(torch, dev, graph.replay, st) * 1e3
             entry["kernels"] = sorted(set(ch.kernel_names()))
             extra[name] = entry

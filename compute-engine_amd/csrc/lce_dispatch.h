@@ -90,29 +90,37 @@ inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = fal
 
 typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, const float*, const float*, const float*, void*, uint32_t*);
 
-template <int DST, int NC>
+template <int DST, int NC, bool STRIDED>
 pointwise_fn pointwise_by_nj(int nj) {
   switch (nj) {
-    case 4: return bconv2d_pointwise<DST, NC, 4>;
-    case 2: return bconv2d_pointwise<DST, NC, 2>;
-    case 1: return bconv2d_pointwise<DST, NC, 1>;
+    case 4:
+      // (8 K-steps x 4 tiles, or a float tile's 16 row stores x 4 tiles, would not fit 256 VGPRs)
+      if constexpr (NC <= 4 && DST != kDstFloat) return bconv2d_pointwise<DST, NC, 4, STRIDED>;
+      else return nullptr;
+    case 2: return bconv2d_pointwise<DST, NC, 2, STRIDED>;
+    case 1: return bconv2d_pointwise<DST, NC, 1, STRIDED>;
+    default: return nullptr;
+  }
+}
+template <int DST, bool STRIDED>
+pointwise_fn pointwise_by_nc(int nc, int nj) {
+  switch (nc) {
+    case 8: return pointwise_by_nj<DST, 8, STRIDED>(nj);
+    case 4: return pointwise_by_nj<DST, 4, STRIDED>(nj);
+    case 2: return pointwise_by_nj<DST, 2, STRIDED>(nj);
+    case 1: return pointwise_by_nj<DST, 1, STRIDED>(nj);
     default: return nullptr;
   }
 }
 template <int DST>
-pointwise_fn pointwise_by_nc(int nc, int nj) {
-  switch (nc) {
-    case 4: return pointwise_by_nj<DST, 4>(nj);
-    case 2: return pointwise_by_nj<DST, 2>(nj);
-    case 1: return pointwise_by_nj<DST, 1>(nj);
-    default: return nullptr;
-  }
+pointwise_fn pointwise_by_stride(int nc, int nj, bool strided) {
+  return strided ? pointwise_by_nc<DST, true>(nc, nj) : pointwise_by_nc<DST, false>(nc, nj);
 }
-inline pointwise_fn find_pointwise(int dst, int nc, int nj) {
+inline pointwise_fn find_pointwise(int dst, int nc, int nj, bool strided) {
   switch (dst) {
-    case LCE_HIP_F32: return pointwise_by_nc<kDstFloat>(nc, nj);
-    case LCE_HIP_I8: return pointwise_by_nc<kDstInt8>(nc, nj);
-    default: return pointwise_by_nc<kDstBitpacked>(nc, nj);
+    case LCE_HIP_F32: return pointwise_by_stride<kDstFloat>(nc, nj, strided);
+    case LCE_HIP_I8: return pointwise_by_stride<kDstInt8>(nc, nj, strided);
+    default: return pointwise_by_stride<kDstBitpacked>(nc, nj, strided);
   }
 }
 

@@ -457,6 +457,14 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     h.pw_tiles_pref = v;
     return LCE_HIP_OK;
   }
+  if (!strcmp(key, "pointwise_channels")) {   // tuning aid for the 1x1 streaming kernel: output channels per block
+    const int v = atoi(value);
+    if (!(v == 32 || v == 64 || v == 128 || (v == 0 && !strcmp(value, "0"))))
+      return fail(LCE_HIP_ERR_INVALID, "plan_set_option: pointwise_channels must be 0 (auto), 32, 64 or 128");
+    h.pw_nj_pref = v / 32;
+    plan->selected_for_pixels = -1;
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "stream_rows")) {       // tuning aid for the streaming kernel: output rows per segment (0 = auto)
     const int v = atoi(value);
     if (v < 0 || (v == 0 && strcmp(value, "0")))
@@ -555,7 +563,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     bool sign_fused = false;
     if (h.use_mfma && h.use_pointwise && ((uintptr_t)out & 15) == 0) {
       // 1x1 streaming kernel: waves walk 32-pixel tiles of the launch's pixel matrix
-      lce::pointwise_fn fn = lce::find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj);
+      lce::pointwise_fn fn = lce::find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::PwArgs P = lce::make_pw_args(h, nb);
       // k tiles per wave: enough blocks (>= 12 per CU when the launch has them) for the dispatcher to even
@@ -875,6 +883,19 @@ int lce_hip_debug_read_timeline(void* host, size_t bytes) {
 int lce_hip_debug_read_stream_tl(void* host, size_t bytes) {
   if (bytes > sizeof(lce::lce_stream_tl)) bytes = sizeof(lce::lce_stream_tl);
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lce::lce_stream_tl), bytes);
+}
+#endif
+
+#ifdef LCE_PW_PHASES
+// profiling aid (tools/pw_phases.py), not part of the ABI: the per-block stamps of the last pointwise launch
+int lce_hip_debug_read_pw_tl(void* host, size_t bytes) {
+  if (bytes > sizeof(lce::lce_pw_tl)) bytes = sizeof(lce::lce_pw_tl);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lce::lce_pw_tl), bytes);
+}
+int lce_hip_debug_clear_pw_tl(void) {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(lce::lce_pw_tl)) != hipSuccess) return 1;
+  return (int)hipMemset(p, 0, sizeof(lce::lce_pw_tl));
 }
 #endif
 

@@ -114,6 +114,11 @@ struct PwArgs {
   float a_bt;           // K_bt = Cin as float
   float cmin, cmax;     // clamps as floats (exact integers)
   float bit_thr;        // second output: bit = value < bit_thr (as MfmaArgs::bit_thr)
+  // strided 1x1 only: output pixel (b, oy, ox) reads input pixel (b, oy * SH, ox * SW); M counts OUTPUT pixels
+  int32_t OW, OHW;      // output width, output pixels per image
+  int32_t IW, IHW;      // input width, input pixels per image
+  int32_t SH, SW;
+  FastDiv div_ow, div_ohw;
 };
 
 

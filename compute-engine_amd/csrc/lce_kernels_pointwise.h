@@ -1,8 +1,9 @@
-// Pointwise (1x1, stride 1) LceBconv2d on the matrix cores: a streaming kernel.
+// Pointwise (1x1) LceBconv2d on the matrix cores: a streaming kernel.
 //
 // A 1x1 binary convolution has no spatial structure: every output pixel is the +-1 dot product of
 // its own Cin bits with each of the Cout filters (reference.h:62-126 with filter extent 1; no
-// padding can occur), so the batch is ONE matrix of M = B*H*W pixel rows.  The general kernel
+// padding can occur), so the batch is ONE matrix of M = B*OH*OW pixel rows (a STRIDED 1x1 layer -- the shortcut
+// convolutions of ResNet-style binary nets -- only changes which input pixel a row reads).  The general kernel
 // (lce_kernels_mfma.h) pays a per-block prologue -- halo rows into LDS, weight ring, barriers --
 // that a layer with one or two K-steps cannot amortise: its 1x1 int8 layers sit at 8-24 % of the HBM
 // roofline (profiles/r02/layer_kernel_stats.txt).  Here instead:
@@ -24,18 +25,33 @@
 
 namespace lce {
 
-// DST: kDstFloat / kDstInt8 / kDstBitpacked.  NC = K-steps (64 input channels each), NJ = 32-channel
-// tiles per block (grid.y covers N / (32*NJ) of them; requires N % 32 == 0).
+#ifdef LCE_PW_PHASES
+// Profiling aid (never defined in the product build; tools/pw_phases.py): wave 0 of every block stamps the cycle counter
+// at entry (0), filter bank + first words resident (1), first tile's stores issued (2), exit (3).
+__device__ unsigned long long lce_pw_tl[8192 * 4];
+#define LCE_PWPH(slot)                                                                                            \
+  do {                                                                                                            \
+    const unsigned bid_ = block_idx_y() * grid_dim_x() + block_idx_x();                                           \
+    if (thread_idx_x() == 0 && bid_ < 8192) lce_pw_tl[bid_ * 4 + (slot)] = __builtin_readcyclecounter();          \
+  } while (0)
+#else
+#define LCE_PWPH(slot) do {} while (0)
+#endif
+
+// DST: kDstFloat / kDstInt8 / kDstBitpacked.  NC = K-steps (64 input channels each; 1, 2, 4 or 8 -- the last with
+// NJ <= 2 so that the filter bank stays within 64 registers), NJ = 32-channel tiles per block (grid.y covers
+// N / (32*NJ) of them; requires N % 32 == 0).  STRIDED: stride > 1 in either direction.
 // <= 256 registers, so the accumulators stay in VGPRs, which the epilogue reads directly (AGPR accumulators cost a
 // v_accvgpr_read per value); no tighter cap: a spill reload in the tile loop is a VMEM operation, and waiting for it
 // waits for the tile's stores as well
 constexpr int pw_min_blocks(int, int) { return 2; }
 
-template <int DST, int NC, int NJ>
+template <int DST, int NC, int NJ, bool STRIDED>
 LCE_KERNEL void __launch_bounds__(256, pw_min_blocks(NC, NJ))
 bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t* __restrict__ wq,
                   const float* __restrict__ mul, const float* __restrict__ bias,
                   const float* __restrict__ thrf, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
+  LCE_PWPH(0);
   const int tid = thread_idx_x();
   const int lane = tid & (kWave - 1), wave = uniform(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -86,7 +102,17 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
   auto load_words = [&](int t, uint32_t (&w)[NC]) LCE_LAMBDA_INLINE {
     // a lane past the last pixel, or a K-half past the last word, reads out of range or a neighbour's word:
     // zeros from the range check, or masked by `valid` below
-    const uint32_t base = t < P.tiles ? (uint32_t)t * tile_in + lane_in : kOobOffset;
+    uint32_t base;
+    if constexpr (STRIDED) {
+      // (a pixel past the launch's last lands in a later image or behind the input: zeros, and nothing stores its row)
+      const uint32_t p = (uint32_t)t * 32u + (uint32_t)l31;
+      const uint32_t b = fastdiv(p, P.div_ohw), r = p - b * (uint32_t)P.OHW;
+      const uint32_t oy = fastdiv(r, P.div_ow), ox = r - oy * (uint32_t)P.OW;
+      const uint32_t pix = b * (uint32_t)P.IHW + oy * (uint32_t)(P.SH * P.IW) + ox * (uint32_t)P.SW;
+      base = t < P.tiles ? pix * (uint32_t)P.Cw * 4u + (uint32_t)half * 4u : kOobOffset;
+    } else {
+      base = t < P.tiles ? (uint32_t)t * tile_in + lane_in : kOobOffset;
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) w[c] = buf_load(rin, base + (uint32_t)c * 8u, (uint32_t*)nullptr);
   };
@@ -271,6 +297,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
   // preheader (where this load is the NEWEST memory operation) with the back edge's (where it is followed by two
   // stores) pessimistically and would otherwise wait with vmcnt(0) at the loop head, i.e. for the previous tile's stores
   wait_vmcnt<0>();
+  LCE_PWPH(1);
   // pairs of tiles in a branch-free body (the compiler's s_waitcnt placement stays exact: with a conditional second
   // tile it falls back to vmcnt(0) at the loop head, which waits for the stores again), then the odd one
   for (; t + wstride < P.tiles; t += 2 * wstride) {
@@ -280,6 +307,11 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
     tile(IntC<1>{}, t + wstride, w1);
   }
   if (t < P.tiles) tile(IntC<0>{}, t, w0);
+  LCE_PWPH(2);
+#ifdef LCE_PW_PHASES
+  wait_vmcnt<0>();      // the stores' acknowledgements
+  LCE_PWPH(3);
+#endif
 }
 
 }  // namespace lce

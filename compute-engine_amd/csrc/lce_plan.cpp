@@ -249,39 +249,52 @@ bool mfma_supported(const HostPlan& p) {
   return true;
 }
 
-// The streaming 1x1 kernel (lce_kernels_pointwise.h): filter extent 1, stride 1 (then no padding exists and
-// dilation is moot), one group, whole 32-channel output tiles, and a filter bank that fits registers
-// (1, 2 or 4 K-steps of 64 input channels).
-bool pointwise_supported(const HostPlan& p, int* nc, int* nj) {
+// The streaming 1x1 kernel (lce_kernels_pointwise.h): filter extent 1 (then no padding exists -- SAME pads
+// (out-1)*stride + 1 - in <= 0 -- and dilation is moot), any stride, one group, whole 32-channel output tiles, and a
+// filter bank that fits registers (1, 2, 4 or 8 K-steps of 64 input channels).
+// nj = 32-channel tiles per block.  More tiles per block = fewer re-reads of the input words (they come from L2) and
+// fewer FP4 conversions per output, but longer waves; measured (profiles/r03/pointwise_widen_*.txt) 64 channels per
+// block win on every launch of fewer than ~16k wave-tiles -- whose time is the length of a wave's load -> MFMA ->
+// transform -> store chain times the rounds of blocks, not throughput -- and 128 on the large ones; 32 never wins.
+bool pointwise_supported(const HostPlan& p, int64_t pixels, int* nc, int* nj) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!mfma_supported(p)) return false;
-  if (d.filter_height != 1 || d.filter_width != 1 || d.stride_height != 1 || d.stride_width != 1) return false;
+  if (d.filter_height != 1 || d.filter_width != 1) return false;
   if (d.groups != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
-  if (p.out_h != d.in_height || p.out_w != d.in_width) return false;
+  if (p.out_h != (d.in_height - 1) / d.stride_height + 1 || p.out_w != (d.in_width - 1) / d.stride_width + 1) return false;
   if (d.channels_out % 32 != 0) return false;
   const int c = ceil_div(d.channels_in, 64);
-  if (c != 1 && c != 2 && c != 4) return false;
+  if (c != 1 && c != 2 && c != 4 && c != 8) return false;
   const int t = d.channels_out / 32;
+  int j = t % 4 == 0 ? 4 : t % 2 == 0 ? 2 : 1;
+  if (c == 8 || d.dst_type == LCE_HIP_F32) j = std::min(j, 2);   // (float: 16 row stores of a 128-channel tile + the bank do not fit 256 VGPRs)
+  if (p.pw_nj_pref > 0) {
+    if (t % p.pw_nj_pref != 0) return false;
+    j = std::min(j, p.pw_nj_pref);          // (a tuning aid: what the instances cannot do is clamped, not refused)
+  } else {
+    const int64_t tiles = (pixels + 31) / 32;
+    if (j == 4 && tiles * (t / 4) < pw_small_launch_tiles) j = 2;
+  }
   *nc = c;
-  *nj = t % 4 == 0 ? 4 : t % 2 == 0 ? 2 : 1;
+  *nj = j;
   return true;
 }
 
-// Auto rule (profiles/r02/pointwise_vs_block_gemm.txt): on every 1x1 layer measured -- 64->64, 64->128, 128->128, 256->256
-// channels on 56x56 / 28x28 / 14x14 maps at batch 256, all three output types -- the streaming kernel is faster than
-// or equal to the block GEMM (int8 -10...-36 %, bitpacked -18...-50 %, float -2...-12 %); launches of less than 32 tiles
-// stay with the previous choice.
-// One exception: float output of a 64 -> 128-channel layer (K1 x N4: 240 VGPRs for the 16 row stores of a tile,
-// two waves per SIMD) is 15 % slower than the block GEMM.
+// Auto rule (profiles/r02/pointwise_vs_block_gemm.txt, profiles/r03/pointwise_widen_*.txt): on every 1x1 layer measured --
+// 64 ... 512 channels on 56x56 ... 7x7 maps at batch 256, strides 1 and 2, all three output types -- the streaming
+// kernel is faster than or equal to the block GEMM (int8 -10...-40 %, bitpacked -5...-55 %, float 0...-25 %) with two
+// exceptions that stay on the block GEMM: launches of less than 32 tiles, and float output of a LARGE launch
+// (56x56x256 -> 256: 151 vs 144 us; the float epilogue's 64-channel blocks re-read the input words four times).
 static bool pointwise_preferred(const HostPlan& p, int64_t pixels) {
-  if (p.d.dst_type == LCE_HIP_F32 && p.pw_nc == 1 && p.pw_nj == 4) return false;
+  const int64_t tiles = (pixels + 31) / 32;
+  if (p.d.dst_type == LCE_HIP_F32 && tiles * (p.d.channels_out / 64) >= 65536) return false;
   return pixels >= 1024;
 }
 
 PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   const lce_hip_bconv2d_desc& d = p.d;
   PwArgs P{};
-  const int64_t m = (int64_t)batch_chunk * d.in_height * d.in_width;
+  const int64_t m = (int64_t)batch_chunk * p.out_h * p.out_w;
   P.M = (int32_t)m;
   P.N = d.channels_out;
   P.Npad = p.npad;
@@ -290,7 +303,7 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   P.Wout = p.wout;
   P.tiles = (int32_t)((m + 31) / 32);
   P.noclamp = (p.clamp_min <= 0 && (int64_t)p.clamp_max >= 2 * (int64_t)p.backtransform_add) ? 1 : 0;
-  P.in_bytes = (uint32_t)(m * p.cw * 4);
+  P.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
   const int64_t row = d.dst_type == LCE_HIP_BITPACKED ? (int64_t)p.wout * 4 : (int64_t)d.channels_out * (d.dst_type == LCE_HIP_I8 ? 1 : 4);
   // (max_batch_per_launch keeps a launch's output below 2 GiB: the kernel's offsets are 32-bit)
   P.out_bytes = (uint32_t)std::min<int64_t>(m * row, (1ll << 31) - 1);
@@ -298,6 +311,14 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   P.cmin = (float)p.clamp_min;
   P.cmax = (float)p.clamp_max;
   P.bit_thr = p.bit_thr;
+  P.OW = p.out_w;
+  P.OHW = p.out_h * p.out_w;
+  P.IW = d.in_width;
+  P.IHW = d.in_height * d.in_width;
+  P.SH = d.stride_height;
+  P.SW = d.stride_width;
+  P.div_ow = make_fastdiv((uint32_t)P.OW);
+  P.div_ohw = make_fastdiv((uint32_t)P.OHW);
   return P;
 }
 
@@ -760,8 +781,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
   p.use_mfma = false;
   p.use_direct = false;
   p.use_pointwise = false;
-  if (p.engine_pref == 4 && !pointwise_supported(p, &p.pw_nc, &p.pw_nj))
-    return "bconv2d: the pointwise kernel runs 1x1 stride-1 ungrouped convolutions with <= 256 input channels (64, 128 or 256 after padding) and a multiple of 32 output channels";
+  if (p.engine_pref == 4 && !pointwise_supported(p, pixels, &p.pw_nc, &p.pw_nj))
+    return "bconv2d: the pointwise kernel runs 1x1 ungrouped convolutions with 64, 128, 256 or 512 input channels (after padding to 64) and a multiple of 32 output channels (pointwise_channels must divide them)";
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   p.use_stream = false;
@@ -840,11 +861,12 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     p.kernel_name = nm;
     // 1x1 stride-1 layers: the streaming kernel on top of the same weight image (the block GEMM stays the
     // fallback for output pointers that are not 16-byte aligned)
-    if ((p.engine_pref == 4 || (p.engine_pref == 0 && p.tile_pref.tm == 0)) && pointwise_supported(p, &p.pw_nc, &p.pw_nj) &&
+    if ((p.engine_pref == 4 || (p.engine_pref == 0 && p.tile_pref.tm == 0)) && pointwise_supported(p, pixels, &p.pw_nc, &p.pw_nj) &&
         (p.engine_pref == 4 || pointwise_preferred(p, pixels))) {
       p.use_pointwise = true;
-      snprintf(nm, sizeof nm, "bconv2d_pointwise<%s,K%dx64,N%dx32>",
-               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", p.pw_nc, p.pw_nj);
+      snprintf(nm, sizeof nm, "bconv2d_pointwise<%s,K%dx64,N%dx32%s>",
+               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", p.pw_nc, p.pw_nj,
+               d.stride_height != 1 || d.stride_width != 1 ? ",strided" : "");
       p.kernel_name = nm;
     }
     return "";

@@ -79,6 +79,7 @@ struct HostPlan {
   bool use_pointwise = false;              // with use_mfma: the 1x1 streaming kernel runs instead of the block GEMM
   int pw_nc = 0, pw_nj = 0;                // its K-steps and 32-channel tiles per block
   int pw_tiles_pref = 0;                   // tuning aid: 32-pixel tiles per wave (0 = auto)
+  int pw_nj_pref = 0;                      // tuning aid: 32-channel tiles per block (0 = auto, 1, 2, 4)
   MfmaCfg mfma{0, 0, 0, 0};                // chosen block shape
   int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count
   int kch = 0;                             // K-steps (64-channel chunks) per filter tap that a block runs: cpad/64,
@@ -132,7 +133,9 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
                      int* ipt, int lds_budget, int* tile_tx = nullptr, int* halo_w = nullptr);
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
 // 1x1 streaming kernel: can it run this convolution (fills nc / nj), and its launch constants.
-bool pointwise_supported(const HostPlan& p, int* nc, int* nj);
+bool pointwise_supported(const HostPlan& p, int64_t pixels, int* nc, int* nj);
+// a 1x1 launch with fewer wave-tiles (32 pixels x 128 channels) than this runs 64 channels per block
+constexpr int64_t pw_small_launch_tiles = 16384;
 PwArgs make_pw_args(const HostPlan& p, int batch_chunk);
 size_t mfma_workspace_bytes(const HostPlan& p, int batch_chunk);
 

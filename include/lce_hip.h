@@ -169,7 +169,8 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *   "engine" = "auto" | "valu" (v_xor + v_bcnt popcount kernels) | "mfma" (FP4 matrix cores, FP4
  *              workspace + GEMM whose tiles span images) | "direct" (FP4 matrix cores, each block
  *              expands its own input halo into LDS; what "auto" picks whenever it fits) | "pointwise" (1x1
- *              stride-1 ungrouped layers, <= 256 input channels, a multiple of 32 output channels: filter bank
+ *              ungrouped layers of any stride, 64 / 128 / 256 / 512 input channels after padding to 64, a multiple
+ *              of 32 output channels: filter bank
  *              in registers, waves stream 32-pixel tiles; what "auto" picks for such layers);
  *   "kernel" = "auto" | "tiled" | "general"                        (valu engine);
  *   "tile"   = "auto" | valu lane tile "4x16"|"2x32"|"2x16"|"1x32"|"1x16"
@@ -178,6 +179,7 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *   "phase"  = "all" | "expand" | "gemm"   (engine = mfma, profiling aid: run one of its two kernels);
  *   "epilogue" = "auto" | "tile" | "wide"   (matrix-core float / int8 epilogue: per-tile or joint transpose);
  *   "pointwise_tiles" = "0" (auto) | "1".."8"   (pointwise kernel: 32-pixel tiles per wave);
+ *   "pointwise_channels" = "0" (auto) | "32" | "64" | "128"   (pointwise kernel: output channels per block);
  *   "tile2d" = "auto" | "on" | "off"   (direct variant: 2-D tiles of BM/32 rows x 32 columns instead of row-major strips;
  *              auto takes them on wide images, where they stage <= 0.7 of the strip's halo at <= 3 % more padding). */
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key,

@@ -90,6 +90,7 @@ std::string g_err;
 void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call (float output, matrix-core engine)
 int g_num_cus = 256;          // what the streaming kernel's planner takes for the device's CU count
 int g_stream_rows = 0;        // its segment size (0 = auto)
+int g_pw_nj = 0;              // the pointwise kernel's 32-channel tiles per block (0 = auto)
 
 }  // namespace
 
@@ -99,6 +100,7 @@ const char* hostsim_last_error() { return g_err.c_str(); }
 float hostsim_int8_below_threshold(int32_t zero_point) { return int8_below_threshold(zero_point); }
 void hostsim_set_sign_output(void* words) { g_sign_out = words; }
 void hostsim_set_stream(int num_cus, int rows) { g_num_cus = num_cus; g_stream_rows = rows; }
+void hostsim_set_pointwise(int channel_tiles) { g_pw_nj = channel_tiles; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
 // engine_pref: 0 auto, 1 valu, 2 mfma
@@ -114,6 +116,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   h.engine_pref = engine_pref;
   h.num_cus = g_num_cus;
   h.stream_rows_pref = g_stream_rows;
+  h.pw_nj_pref = g_pw_nj;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};
   int chunk = max_batch_per_launch(h);
@@ -150,7 +153,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
         fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out, sgn);
       });
     } else if (h.use_mfma && h.use_pointwise) {
-      pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj);
+      pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const PwArgs P = make_pw_args(h, nb);
       std::vector<uint8_t> wq = h.wq;

@@ -49,20 +49,20 @@ def _gpu_conv(spec, dst, x, w, mul=None, bias=None, thr=None, scale=1.0, zp=0, k
     return out.cpu().numpy(), name
 
 
-def _check_all_dst(spec, seed, kernel="auto", tile="auto", engine="valu"):
+def _check_all_dst(spec, seed, kernel="auto", tile="auto", engine="valu", opts=()):
     x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2 if engine != "valu" else 0.0)
     zero_pad = spec.padding == O.PADDING_SAME and spec.pad_values == 0
     names = []
     if not (zero_pad and spec.semantics == O.SEM_OPTIMIZED and spec.activation != O.ACT_NONE):
         want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
-        got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel, tile=tile, engine=engine)
+        got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, kernel=kernel, tile=tile, engine=engine, opts=opts)
         assert np.array_equal(got.view(np.int32), want.view(np.int32)), n
         names.append(n)
     if zero_pad and spec.semantics == O.SEM_OPTIMIZED:
         return names
     scale, zp = synth.int8_quant_params(seed)
     want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp)
-    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel, tile=tile, engine=engine)
+    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, kernel=kernel, tile=tile, engine=engine, opts=opts)
     assert np.array_equal(got, want), n
     names.append(n)
     if tile in ("auto", "2x32", "1x32") or engine != "valu":
@@ -70,7 +70,7 @@ def _check_all_dst(spec, seed, kernel="auto", tile="auto", engine="valu"):
         thr[::5] = np.iinfo(np.int32).max
         thr[1::7] = np.iinfo(np.int32).min
         want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
-        got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, kernel=kernel, tile=tile, engine=engine)
+        got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, kernel=kernel, tile=tile, engine=engine, opts=opts)
         assert np.array_equal(got, want), n
         names.append(n)
     return names
@@ -348,15 +348,21 @@ def test_run_dual_on_an_int8_plan_is_run_followed_by_lcequantize(engine, kernel,
             assert (want < zp).any() and (want >= zp).any()
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32), (128, 512)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32), (128, 512),
+                                      (512, 512), (480, 64), (512, 96)])
 def test_pointwise_streaming_kernel(cin, cout):
-    """lce_kernels_pointwise.h (1x1 stride 1: filter bank in registers, waves walk 32-pixel tiles) against the
-    oracle: all three output types, 1 / 2 / 4 K-steps with partial words, several channel blocks, pixel counts
-    that are not a multiple of 32, more tiles than resident waves."""
+    """lce_kernels_pointwise.h (1x1: filter bank in registers, waves walk 32-pixel tiles) against the
+    oracle: all three output types, 1 / 2 / 4 / 8 K-steps with partial words, several channel blocks, pixel counts
+    that are not a multiple of 32, more tiles than resident waves, every block width the planner can choose."""
     for b, h, w_, act in ((3, 5, 7, O.ACT_NONE), (7, 29, 31, O.ACT_RELU), (64, 28, 28, O.ACT_RELU6)):
         spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, padding=O.PADDING_SAME, pad_values=1, activation=act)
         names = _check_all_dst(spec, cin + 3 * cout + b, engine="pointwise")
         assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+        for ch in (32, 64, 128):
+            if (cout // 32) % (ch // 32) or (cin > 256 and ch == 128):
+                continue
+            names = _check_all_dst(spec, cin + 3 * cout + b + ch, engine="pointwise", opts=(("pointwise_channels", str(ch)),))
+            assert all("N%dx32" % (min(ch // 32, 2) if "<f32" in n else ch // 32) in n for n in names), names
         # ... and the float layer's second output (sign bits) from the same kernel
         x, w, mul, bias = synth.conv_inputs(spec, cin + b, negative_mul_fraction=0.3)
         bias = (bias - 0.4 * cin * np.abs(mul)).astype(np.float32)
@@ -368,6 +374,19 @@ def test_pointwise_streaming_kernel(cin, cout):
         want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
         assert np.array_equal(y.cpu().numpy().view(np.int32), want.view(np.int32))
         assert np.array_equal(bits.cpu().numpy(), O.bitpack(want))
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 256), (256, 512), (200, 96), (512, 64)])
+def test_pointwise_kernel_strided(cin, cout):
+    """Strided 1x1 layers (ResNet-style shortcut convolutions) on the pointwise kernel, and as the planner's own
+    choice at a size where it prefers that kernel."""
+    for b, h, w_, st in ((3, 9, 7, (2, 2)), (16, 28, 28, (2, 2)), (5, 14, 15, (1, 2)), (4, 30, 30, (3, 2))):
+        spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, 1, st[0], st[1], padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+        names = _check_all_dst(spec, cin + cout + b, engine="pointwise")
+        assert all(n.startswith("bconv2d_pointwise<") and n.endswith(",strided>") for n in names), names
+    spec = O.ConvSpec(32, 56, 56, cin, 1, 1, cout, 1, 2, 2, padding=O.PADDING_VALID, activation=O.ACT_NONE)
+    names = _check_all_dst(spec, cin, engine="auto")
+    assert all(n.startswith("bconv2d_pointwise<") for n in names[1:]), names       # (float: see pointwise_preferred)
 
 
 @pytest.mark.parametrize("engine,kernel", [("auto", "auto"), ("direct", "auto"), ("mfma", "auto"), ("valu", "auto"), ("valu", "general")])

@@ -255,26 +255,57 @@ def test_mfma_engine_batch_chunking_and_pointwise():
     _run_all_dst_mfma(spec, 12, max_batch=1)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32),
+                                      (512, 64), (480, 128), (449, 32)])
 @pytest.mark.parametrize("act", [O.ACT_NONE, O.ACT_RELU], ids=["none", "relu"])
 def test_pointwise_streaming_kernel(cin, cout, act):
     """The 1x1 streaming kernel (lce_kernels_pointwise.h; filter bank in registers, waves walking 32-pixel tiles
-    of the batch's pixel matrix) against the oracle: 1 / 2 / 4 K-steps incl. partial last words and an empty
+    of the batch's pixel matrix) against the oracle: 1 / 2 / 4 / 8 K-steps incl. partial last words and an empty
     upper K-half, 1 / 2 / 4 channel tiles per block with several blocks along the channels, a pixel count that is
     not a multiple of 32, more tiles than waves (the tile loop and its prefetch), batch chunking."""
-    for b, h, w_, mb in ((3, 5, 7, 0), (2, 9, 11, 0), (5, 4, 4, 2)):
-        for padding in (O.PADDING_VALID, O.PADDING_SAME):
-            spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, padding=padding, pad_values=1, activation=act)
-            names = _run_all_dst_mfma(spec, seed=cin + 3 * cout + b, max_batch=mb, engine="pointwise")
-            assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+    t = cout // 32
+    widest = 4 if t % 4 == 0 else 2 if t % 2 == 0 else 1
+    if cin > 256:
+        widest = min(widest, 2)
+    try:
+        for k, (b, h, w_, mb) in enumerate(((3, 5, 7, 0), (2, 9, 11, 0), (5, 4, 4, 2))):
+            for padding in (O.PADDING_VALID, O.PADDING_SAME):
+                # the launch-size rule gives these small launches at most 64 channels per block: ask for the widest and for 32 too
+                H.set_pointwise(widest if (k + padding) % 2 == 0 else 1 if k == 1 else 0)
+                spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, padding=padding, pad_values=1, activation=act)
+                names = _run_all_dst_mfma(spec, seed=cin + 3 * cout + b, max_batch=mb, engine="pointwise")
+                assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+                want = widest if (k + padding) % 2 == 0 else 1 if k == 1 else min(widest, 2)
+                for n in names:      # (float output: at most 64 channels per block)
+                    assert "N%dx32" % (min(want, 2) if "<f32" in n else want) in n, (names, want)
+    finally:
+        H.set_pointwise(0)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 256), (200, 96), (512, 128)])
+@pytest.mark.parametrize("stride", [(2, 2), (1, 2), (3, 2)], ids=lambda s: "s%dx%d" % s)
+def test_pointwise_kernel_strided(cin, cout, stride):
+    """Strided 1x1 layers (the shortcut convolutions of ResNet-style binary nets): output pixel (b, oy, ox) reads input
+    pixel (b, oy * sh, ox * sw); odd and even extents, VALID and SAME (neither pads a 1x1 filter), batch chunking."""
+    try:
+        for k, (b, h, w_, mb) in enumerate(((3, 5, 7, 0), (2, 10, 12, 0), (4, 9, 4, 1))):
+            for padding in (O.PADDING_VALID, O.PADDING_SAME):
+                H.set_pointwise(0 if k else (2 if (cout // 32) % 2 == 0 else 1))
+                spec = O.ConvSpec(b, h, w_, cin, 1, 1, cout, 1, stride[0], stride[1], padding=padding, pad_values=1,
+                                  activation=O.ACT_RELU if k == 1 else O.ACT_NONE)
+                names = _run_all_dst_mfma(spec, seed=cin + cout + b + stride[0], max_batch=mb, engine="pointwise")
+                assert all(n.startswith("bconv2d_pointwise<") for n in names), names
+    finally:
+        H.set_pointwise(0)
 
 
 def test_pointwise_kernel_refuses_what_it_cannot_run():
     x, w, mul, bias = synth.conv_inputs(O.ConvSpec(1, 4, 4, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), 1)
     for spec in (O.ConvSpec(1, 4, 4, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1),       # 3x3
-                 O.ConvSpec(1, 4, 4, 64, 1, 1, 64, stride_h=2, stride_w=2),                     # strided
+                 O.ConvSpec(1, 4, 4, 128, 1, 1, 64, groups=2),                                  # grouped
                  O.ConvSpec(1, 4, 4, 64, 1, 1, 48),                                             # channels not a multiple of 32
-                 O.ConvSpec(1, 4, 4, 320, 1, 1, 64)):                                           # filter bank too deep
+                 O.ConvSpec(1, 4, 4, 320, 1, 1, 64),                                            # 5 K-steps: no instance
+                 O.ConvSpec(1, 4, 4, 576, 1, 1, 64)):                                           # filter bank too deep
         x, w, mul, bias = synth.conv_inputs(spec, 1)
         with pytest.raises(RuntimeError, match="pointwise kernel runs 1x1"):
             H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="pointwise")

@@ -20,7 +20,8 @@ steps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 B = int(sys.argv[7]) if len(sys.argv) > 7 else 256
 dst = {"f32": amd.F32, "i8": amd.I8, "bp": amd.BITPACKED}[dname]
 K = int(os.environ.get("LCE_K", "3"))   # filter height = width
-layer = SL.Layer(B, hw, hw, c, K, K, cout, padding=SL.PADDING_SAME, pad_values=1)
+STRIDE = int(os.environ.get("LCE_STRIDE", "1"))
+layer = SL.Layer(B, hw, hw, c, K, K, cout, stride=STRIDE, padding=SL.PADDING_SAME, pad_values=1)
 w, mul, bias, thr = SL.weights(layer, 3)
 x = torch.from_numpy(SL.activations(layer, 4)).to("cuda:0")
 if os.environ.get("LCE_ZERO"):   # constant operands: how much of the time is the power budget?
