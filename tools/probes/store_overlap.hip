@@ -7,6 +7,9 @@
 //                   instruction, four instructions complete a line (the layout an
 //                   A<->B-swapped MFMA would store without a transpose)                  [nt]
 //        tile4    : 4 bytes per lane, 2 full lines per instruction                       [nt]
+//        scatter16_plain / tile16_plain: the same addresses with write-back stores (round 3: does L2 merge the
+//                   four 32-byte pieces of a line that four consecutive instructions of one wave write?),
+//                   one block per tile and 256 persistent blocks
 //   2. what a kernel with L0's matrix work AND L0's stores reaches when the stores are
 //      (a) a burst after the K loop, (b) spread one per K-step through the K loop --
 //      no LDS, no barriers, constant operands: the upper bound of any overlap scheme.
@@ -46,6 +49,21 @@ __global__ __launch_bounds__(256) void fill_tile(float* out, int tiles) {
         const int row = wm * 64 + (s >> 4) * 32 + (lane >> 5) + 2 * (s & 15);
         const int col = wn * 128 + (lane & 31) * 4;
         __builtin_nontemporal_store(v, (v4f*)(base + (size_t)row * kCh + col));
+      }
+    } else if (MODE == 3) {      // tile16 addresses, plain stores
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int row = wm * 64 + (s >> 4) * 32 + (lane >> 5) + 2 * (s & 15);
+        const int col = wn * 128 + (lane & 31) * 4;
+        *(v4f*)(base + (size_t)row * kCh + col) = v;
+      }
+    } else if (MODE == 4) {      // scatter16 addresses, plain stores
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int i = s >> 4, j = (s >> 2) & 3, g = s & 3;
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        const int col = wn * 128 + j * 32 + 8 * g + 4 * (lane >> 5);
+        *(v4f*)(base + (size_t)row * kCh + col) = v;
       }
     } else if (MODE == 1) {
       // lane = pixel (lane & 31) of a 32-pixel row block, half h = lane >> 5; instruction (i, j, g):
@@ -166,6 +184,18 @@ int main() {
     TIME(nm, 0.0, (fill_tile<1><<<tiles, 256, lds>>>(out, tiles)));
     snprintf(nm, sizeof nm, "tile4_lds%dk", lds / 1024);
     TIME(nm, 0.0, (fill_tile<2><<<tiles, 256, lds>>>(out, tiles)));
+    hipFuncSetAttribute((const void*)fill_tile<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)fill_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    snprintf(nm, sizeof nm, "tile16_plain_lds%dk", lds / 1024);
+    TIME(nm, 0.0, (fill_tile<3><<<tiles, 256, lds>>>(out, tiles)));
+    snprintf(nm, sizeof nm, "scatter16_plain_lds%dk", lds / 1024);
+    TIME(nm, 0.0, (fill_tile<4><<<tiles, 256, lds>>>(out, tiles)));
+    snprintf(nm, sizeof nm, "tile16_plain_persistent256_lds%dk", lds / 1024);
+    TIME(nm, 0.0, (fill_tile<3><<<256, 256, lds>>>(out, tiles)));
+    snprintf(nm, sizeof nm, "scatter16_plain_persistent256_lds%dk", lds / 1024);
+    TIME(nm, 0.0, (fill_tile<4><<<256, 256, lds>>>(out, tiles)));
+    snprintf(nm, sizeof nm, "scatter16_nt_persistent256_lds%dk", lds / 1024);
+    TIME(nm, 0.0, (fill_tile<1><<<256, 256, lds>>>(out, tiles)));
   }
   // how fast can ONE CU store when the rest of the chip leaves HBM alone?  G persistent blocks (150 KiB of LDS:
   // one per CU), 24 tiles each, tile16 pattern
