@@ -287,8 +287,18 @@ LCE_DEVICE void store_streaming(u32x4* p, u32x4 v) { __builtin_nontemporal_store
 LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, 0, LCE_STORE_AUX);
 }
+// ... write-through (agent scope: the line goes on to memory instead of waiting dirty in this XCD's L2) for the float rows of
+// the block GEMM, whose blocks store a whole tile in one burst: 56x56x64 40.1 -> 38.4 us, 28x28x128 26.9 -> 25.8 us against
+// nt; the streaming kernel, which stores a little all the time, is 5 % FASTER with nt (profiles/r03/store_cache_policy.txt)
+#ifndef LCE_STORE_THROUGH_AUX
+#define LCE_STORE_THROUGH_AUX 16   /* sc1 */
+#endif
+LCE_DEVICE void buf_store_through(rsrc_t r, uint32_t lane_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, 0, LCE_STORE_THROUGH_AUX);
+}
+// (int8 rows likewise: write-through -4...-5 % on the block GEMM, -13...-15 % on the pointwise kernel, neutral on the streaming kernel)
 #ifndef LCE_STORE8_AUX
-#define LCE_STORE8_AUX 0
+#define LCE_STORE8_AUX 16  /* sc1 */
 #endif
 LCE_DEVICE void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, 0, LCE_STORE8_AUX);

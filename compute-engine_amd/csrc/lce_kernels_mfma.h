@@ -709,7 +709,7 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
 #ifdef LCE_ABL_NOSTORE   // timing ablation (results are wrong): the float epilogue without its global stores
           if (y[k][0] == 1234.5678f)
 #endif
-          buf_store_streaming(ro, lane_off + blk_off + (uint32_t)((k0 + k) * RPI) * row_bytes, y[k]);
+          buf_store_through(ro, lane_off + blk_off + (uint32_t)((k0 + k) * RPI) * row_bytes, y[k]);
           // pace the burst: 128 KiB per block pushed out back to back fills the CU's memory pipeline and
           // the co-resident block's weight DMAs queue behind it (its K loop 18.7k -> 16.4k cycles with the
           // pause, L0 float -2.5 %, tools/phases.py); the sleeping wave also leaves its issue slots to it
