@@ -287,16 +287,43 @@ LCE_DEVICE void store_streaming(u32x4* p, u32x4 v) { __builtin_nontemporal_store
 LCE_DEVICE void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, 0, LCE_STORE_AUX);
 }
-// ... write-through (agent scope: the line goes on to memory instead of waiting dirty in this XCD's L2) for the float rows of
-// the block GEMM, whose blocks store a whole tile in one burst: 56x56x64 40.1 -> 38.4 us, 28x28x128 26.9 -> 25.8 us against
-// nt; the streaming kernel, which stores a little all the time, is 5 % FASTER with nt (profiles/r03/store_cache_policy.txt)
+// ... write-through (agent scope, sc1: the line goes on to memory and is allocated in the Infinity Cache instead of waiting
+// dirty in this XCD's L2).  An A/B aid for float rows, NOT what is built: timed as repeated launches of one layer it looks 4-12 %
+// faster than nt (the launches rewrite ONE buffer, which the 256 MB Infinity Cache then absorbs), timed on QuickNet's chain of
+// 16 layers with their own buffers it is 16 % SLOWER (profiles/r03/store_cache_policy{,_chains}.txt)
 #ifndef LCE_STORE_THROUGH_AUX
-#define LCE_STORE_THROUGH_AUX 16   /* sc1 */
+#define LCE_STORE_THROUGH_AUX 2    /* nt; 16 = sc1 */
 #endif
 LCE_DEVICE void buf_store_through(rsrc_t r, uint32_t lane_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_off, 0, LCE_STORE_THROUGH_AUX);
 }
-// (int8 rows likewise: write-through -4...-5 % on the block GEMM, -13...-15 % on the pointwise kernel, neutral on the streaming kernel)
+// int8 rows: write-through.  On the chain of config 5's twelve int8 layers -4 % against plain write-back stores (isolated
+// layers: -4...-5 % on the block GEMM, -13...-15 % on the pointwise kernel, neutral on the streaming kernel)
+// Bitpacked words (the bitpacked output type, the second output's sign words): a relaxed agent-scope atomic store IS a
+// global_store with sc1 -- write-through; measured no better than ordinary write-back stores (profiles/r03/store_cache_policy.txt),
+// so that is an A/B aid (-DLCE_WORDS_THROUGH) and the default is a plain store
+LCE_DEVICE void store_words(uint32_t* p, uint32_t v) {
+#ifndef LCE_WORDS_THROUGH
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+LCE_DEVICE void store_words(uint32_t* p, u32x2 v) {      // p is 8-byte aligned
+#ifndef LCE_WORDS_THROUGH
+  *(u32x2*)p = v;
+#else
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+LCE_DEVICE void store_words(uint32_t* p, u32x4 v) {      // p is 16-byte aligned
+#ifndef LCE_WORDS_THROUGH
+  *(u32x4*)p = v;
+#else
+  store_words(p, u32x2{v[0], v[1]});
+  store_words(p + 2, u32x2{v[2], v[3]});
+#endif
+}
 #ifndef LCE_STORE8_AUX
 #define LCE_STORE8_AUX 16  /* sc1 */
 #endif
@@ -310,8 +337,11 @@ LCE_DEVICE void buf_store_streaming_so(rsrc_t r, uint32_t lane_off, uint32_t uni
 LCE_DEVICE void buf_store_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, lane_off, uniform_off, LCE_STORE8_AUX);
 }
-LCE_DEVICE void buf_store2(rsrc_t r, uint32_t lane_off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_off, 0, 0); }
-LCE_DEVICE void buf_store1(rsrc_t r, uint32_t lane_off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_off, 0, 0); }
+#ifndef LCE_STOREW_AUX
+#define LCE_STOREW_AUX 0
+#endif
+LCE_DEVICE void buf_store2(rsrc_t r, uint32_t lane_off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, lane_off, 0, LCE_STOREW_AUX); }
+LCE_DEVICE void buf_store1(rsrc_t r, uint32_t lane_off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, lane_off, 0, LCE_STOREW_AUX); }
 // ... and the matching load for inputs that are read exactly once
 LCE_DEVICE f32x4 load_streaming(const f32x4* p) { return __builtin_nontemporal_load(p); }
 LCE_DEVICE u32x4 load_streaming(const u32x4* p) { return __builtin_nontemporal_load(p); }

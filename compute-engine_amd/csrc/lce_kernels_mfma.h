@@ -635,17 +635,17 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
       uint32_t* o = dst_words + (size_t)m * (size_t)A.Wout + (size_t)w0;
       if (WN == 4 && w0 + 4 <= A.Wout && (A.Wout & 3) == 0) {
         u32x4 v = {words[0], words[WN > 1 ? 1 : 0], words[WN > 2 ? 2 : 0], words[WN > 3 ? 3 : 0]};
-        *(u32x4*)o = v;
+        store_words(o, v);
       } else if (WN >= 2 && w0 + WN <= A.Wout && (A.Wout & 1) == 0) {
 #pragma unroll
         for (int j = 0; j < WN; j += 2) {
           u32x2 v = {words[j], words[j + 1 < WN ? j + 1 : j]};
-          *(u32x2*)(o + j) = v;
+          store_words(o + j, v);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          if (w0 + j < A.Wout) o[j] = words[j];
+          if (w0 + j < A.Wout) store_words(o + j, words[j]);
       }
     }
   };

@@ -172,13 +172,13 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
       if (lane < 32 && m < (uint32_t)P.M) {
         uint32_t* o = (uint32_t*)out + (size_t)m * (size_t)P.Wout + (size_t)(n0 >> 5);
         if constexpr (NJ == 4) {
-          if ((P.Wout & 3) == 0) { *(u32x4*)o = hold[S][0]; }
-          else { o[0] = hold[S][0][0]; o[1] = hold[S][0][1]; o[2] = hold[S][0][2]; o[3] = hold[S][0][3]; }
+          if ((P.Wout & 3) == 0) { store_words(o, hold[S][0]); }
+          else { store_words(o, hold[S][0][0]); store_words(o + 1, hold[S][0][1]); store_words(o + 2, hold[S][0][2]); store_words(o + 3, hold[S][0][3]); }
         } else if constexpr (NJ == 2) {
-          if ((P.Wout & 1) == 0) { u32x2 v = {hold[S][0][0], hold[S][0][1]}; *(u32x2*)o = v; }
-          else { o[0] = hold[S][0][0]; o[1] = hold[S][0][1]; }
+          if ((P.Wout & 1) == 0) { u32x2 v = {hold[S][0][0], hold[S][0][1]}; store_words(o, v); }
+          else { store_words(o, hold[S][0][0]); store_words(o + 1, hold[S][0][1]); }
         } else {
-          o[0] = hold[S][0][0];
+          store_words(o, hold[S][0][0]);
         }
       }
     } else {
@@ -242,7 +242,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
         if (lane < 32 && m < (uint32_t)P.M) {
           uint32_t* o = sign_words + (size_t)m * (size_t)P.Wout + (size_t)(n0 >> 5);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) o[j] = words[j];
+          for (int j = 0; j < NJ; ++j) store_words(o + j, words[j]);
         }
       }
 #pragma unroll
@@ -259,11 +259,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
           const uint32_t row = row0 + (uint32_t)(rr + k * RPI);
-#ifdef LCE_PW_STORE_NT   // A/B aid (write-through: 28x28x128 20.3 -> 17.8 us, 56x56x64 32.8 -> 30.8)
           buf_store_streaming(rout, (row * (uint32_t)P.N + (uint32_t)(n0 + g * 4)) * 4u, y[k]);
-#else
-          buf_store_through(rout, (row * (uint32_t)P.N + (uint32_t)(n0 + g * 4)) * 4u, y[k]);
-#endif
         }
       } else {
         // int8: a lane converts 16 consecutive channels of one row into ONE 16-byte store

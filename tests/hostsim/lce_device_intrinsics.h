@@ -188,6 +188,9 @@ inline void buf_store_streaming(rsrc_t r, uint32_t lane_off, f32x4 v) {
   if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 16);
 }
 inline void buf_store_through(rsrc_t r, uint32_t lane_off, f32x4 v) { buf_store_streaming(r, lane_off, v); }
+inline void store_words(uint32_t* p, uint32_t v) { *p = v; }
+inline void store_words(uint32_t* p, u32x2 v) { memcpy(p, &v, 8); }
+inline void store_words(uint32_t* p, u32x4 v) { memcpy(p, &v, 16); }
 inline void buf_store(rsrc_t r, uint32_t lane_off, u32x4 v) {
   if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(const_cast<uint8_t*>(r.base) + lane_off, &v, 16);
 }

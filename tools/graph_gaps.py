@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Where does a HIP-graph replay of a device-resident chain spend its time, next to eager launches of the same chain?
 Two roles:
-  python tools/graph_gaps.py run <eager|graph> [iters]     -- runs QuickNet's 16-layer fused chain (tools/layer_chain.py) that
+  python tools/graph_gaps.py run <eager|graph> [iters] [quicknet|birealnet]
+                                                           -- runs QuickNet's 16-layer fused chain (tools/layer_chain.py) that
                                                               way; meant to be wrapped in `rocprofv3 --kernel-trace`
   python tools/graph_gaps.py report <kernel_trace.csv> <iters> <kernels per iteration>
                                                            -- per iteration of the LAST `iters`: sum of kernel durations, sum of
@@ -15,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(mode, iters):
+def run(mode, iters, stack="quicknet"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import torch
@@ -23,7 +24,10 @@ def run(mode, iters):
     import synthetic_layers as SL
     amd = importlib.import_module("compute-engine_amd")
     dev = torch.device("cuda:0")
-    ch = layer_chain.LayerChain(amd, torch, SL.quicknet_layers(256), dev, dst="f32", seed=4000)
+    if stack == "birealnet":     # BASELINE config 5: int8 outputs, 1x1 + 3x3, strides 1 and 2
+        ch = layer_chain.LayerChain(amd, torch, SL.birealnet_layers(256), dev, dst="i8", seed=4000)
+    else:
+        ch = layer_chain.LayerChain(amd, torch, SL.quicknet_layers(256), dev, dst="f32", seed=4000)
     ch.run_chain()
     torch.cuda.synchronize(dev)
     if mode == "graph":
@@ -48,7 +52,7 @@ def run(mode, iters):
         fn()
     e1.record()
     torch.cuda.synchronize(dev)
-    print("%s: %.4f ms per chain by events (%d iterations, %d kernels each)" % (mode, e0.elapsed_time(e1) / iters, iters, len(ch.plans)))
+    print("%s %s: %.4f ms per chain by events (%d iterations, %d kernels each)" % (stack, mode, e0.elapsed_time(e1) / iters, iters, len(ch.plans)))
 
 
 def report(path, iters, per_iter):
@@ -73,6 +77,6 @@ def report(path, iters, per_iter):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 50)
+        run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 50, sys.argv[4] if len(sys.argv) > 4 else "quicknet")
     else:
         report(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
