@@ -762,6 +762,11 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
 // block has too few MFMAs to carry its epilogue and it loses (28x28x128 float 29.1 vs 27.5 us, 56x56x64 47.8 vs 40.7).
 // A launch must also fill the chip: at least three quarters of the CUs get a block, a block runs long enough
 // (>= 6 block steps) to pay for loading its filter bank, and segments are not slivers.
+// Auto rule: the layers whose K loop (36 K-steps) hides the woven epilogue -- 256 input channels, one 256-channel block per
+// CU (profiles/r03/stream_vs_block_gemm.txt).  Strided 3x3 layers were tried too (the ring expands every input row once, the
+// block GEMM a tile's whole 4x larger input neighbourhood): timed alone they gain 5-25 % (profiles/r03/stream_stride2.txt),
+// inside config 5's chain -- where every layer also writes its sign words -- nothing (0.2529 vs 0.2520 ms,
+// profiles/r03/strided_stream_chain.txt), so they stay where they were.
 static bool stream_candidate(const HostPlan& p) {
   return stream_supported(p) && ceil_div(p.d.channels_in, 64) == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
 }

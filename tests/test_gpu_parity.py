@@ -1047,7 +1047,7 @@ def test_birealnet_stack_batch256():
     chain.run_chain()
     names = _check_chain(chain, [0, 131, 255], O.DST_I8)
     assert all(n.startswith(("bconv2d_mfma", "bconv2d_pointwise", "bconv2d_stream")) for n in names), names
-    assert sum(n.startswith("bconv2d_pointwise") for n in names) >= 2, names     # the 1x1 layers stream
+    assert sum(n.startswith("bconv2d_pointwise") for n in names) == 4, names     # the 1x1 layers stream, 512 channels included
 
 
 def test_quicknet_large_per_gpu_shard_batch256():

@@ -73,6 +73,10 @@ def report(path, iters, per_iter):
     print("  gaps between kernels of a chain   : %8.1f us per chain  (median gap %.2f us, max %.2f us)" % (sum(inner) / iters / 1e3, med(inner) / 1e3, max(inner) / 1e3))
     print("  gap between two chains            : median %.2f us" % (med(outer) / 1e3))
     print("  first start -> last end           : %8.1f us per chain" % (wall / iters / 1e3))
+    print("  per position in the chain (us, mean over the chains):")
+    for k in range(per_iter):
+        d = [rows[i * per_iter + k][1] - rows[i * per_iter + k][0] for i in range(iters)]
+        print("    %2d %-60s %7.2f" % (k, rows[k][2].replace("void lce::", "")[:60], sum(d) / len(d) / 1e3))
 
 
 if __name__ == "__main__":

@@ -34,10 +34,15 @@ def timed(plan, x, out):
 
 
 for spec in layers:
-    f = [int(v) for v in spec.split("x")]
+    stride = 1
+    dims = spec
+    if "s" in spec:                       # HWxCINxCOUT[xBATCH]s<stride>
+        dims, st = spec.split("s")
+        stride = int(st)
+    f = [int(v) for v in dims.split("x")]
     hw, cin, cout = f[:3]
     B = f[3] if len(f) > 3 else 256
-    layer = SL.Layer(B, hw, hw, cin, 3, 3, cout, padding=SL.PADDING_SAME, pad_values=1)
+    layer = SL.Layer(B, hw, hw, cin, 3, 3, cout, stride=stride, padding=SL.PADDING_SAME, pad_values=1)
     w, mul, bias, thr = SL.weights(layer, 3)
     x = torch.from_numpy(SL.activations(layer, 4)).to("cuda:0")
     for dname, dst in (("f32", amd.F32), ("i8", amd.I8), ("bp", amd.BITPACKED)):
@@ -45,7 +50,12 @@ for spec in layers:
         for engine in ("direct", "stream"):
             plan = amd.Bconv2dPlan(layer.params(amd, dst, 0.125, 3))
             plan.set_weights(w, mul, bias, thr)
-            plan.set_option("engine", engine)
+            try:
+                plan.set_option("engine", engine)
+                plan.kernel_name()
+            except Exception as exc:
+                print("%-14s %-3s engine=%s refused: %s" % (spec, dname, engine, str(exc)[:120]), flush=True)
+                break
             if engine == "stream":
                 for kv in filter(None, os.environ.get("LCE_OPTS", "").split(",")):
                     plan.set_option(*kv.split("="))
@@ -53,6 +63,8 @@ for spec in layers:
             torch.cuda.synchronize()
             ms = timed(plan, x, out)
             res[engine] = (plan.kernel_name(), ms, out.clone())
+        if len(res) < 2:
+            continue
         same = torch.equal(res["direct"][2].view(torch.uint8), res["stream"][2].view(torch.uint8))
         print("%-14s %-3s %-38s %.4f ms | %-40s %.4f ms | %s x%.2f" % (
             spec, dname, res["direct"][0], res["direct"][1], res["stream"][0], res["stream"][1],
