@@ -774,7 +774,10 @@ static bool stream_worthwhile(const HostPlan& p) {
   const int cus = std::max(1, p.num_cus / p.st_ny);
   const int64_t steps = ((int64_t)p.st_spb * p.st_pbs + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
   // (segments of fewer than 4 rows re-expand their halo rows more than 1.5 times: left to the block GEMM)
-  return p.st_gx * 4 >= cus * 3 && steps >= 6 && (p.st_rs >= 4 || p.st_rs == p.out_h);
+#ifndef LCE_STREAM_MIN_STEPS
+#define LCE_STREAM_MIN_STEPS 6
+#endif
+  return p.st_gx * 4 >= cus * 3 && steps >= LCE_STREAM_MIN_STEPS && (p.st_rs >= 4 || p.st_rs == p.out_h);
 }
 
 std::string select_kernel(HostPlan& p, int64_t pixels) {
