@@ -281,3 +281,17 @@ def test_model_abi_exports_every_declared_symbol():
     lib = mr.tflite_lib()
     for n in names:
         assert hasattr(lib, n), n
+
+
+def test_section_partition_terminates_on_a_cyclic_graph():
+    """A malformed file whose two LCE ops feed each other: no operator ever becomes ready, the partition gives up after two
+    idle epochs instead of spinning, and there is no section to run."""
+    b = ModelBuilder()
+    t0 = b.tensor([1, 4, 4, 2], np.int32, "a")
+    t1 = b.tensor([1, 4, 4, 2], np.int32, "b")
+    x = b.tensor([1, 4, 4, 64], np.float32, "x")
+    b.inputs, b.outputs = [x], [t1]
+    b.custom_op("LceBMaxPool2d", [t1], [t0], flexbuf.bmaxpool_options(1, 1, 1, 1, O.PADDING_VALID))
+    b.custom_op("LceBMaxPool2d", [t0], [t1], flexbuf.bmaxpool_options(1, 1, 1, 1, O.PADDING_VALID))
+    m = mr.LceModel(b.finish())
+    assert m.sections == []
