@@ -697,6 +697,38 @@ def test_quicknet_layer_shapes_batch256(hw, c):
     assert np.array_equal(got[subset].view(np.int32), want.view(np.int32))
 
 
+@pytest.mark.parametrize("hw,cin,cout,stride", [(56, 64, 128, 2), (28, 128, 256, 2), (14, 256, 512, 2), (7, 512, 512, 1)])
+def test_pointwise_shortcut_layers_batch256(hw, cin, cout, stride):
+    """The 1x1 layers round 3 moved to the pointwise kernel, at batch 256: strided shortcut convolutions of the ResNet-style
+    sections and the 512-channel layer.  All three output types: the planner's choice (pointwise) equals the block GEMM
+    on the WHOLE batch bit for bit, and the oracle on a 3-image subset; float layers also through run_dual."""
+    kwargs = dict(in_h=hw, in_w=hw, channels_in=cin, filter_h=1, filter_w=1, channels_out=cout, stride_h=stride, stride_w=stride,
+                  padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    spec = O.ConvSpec(batch=256, **kwargs)
+    sub = O.ConvSpec(batch=3, **kwargs)
+    x, w, mul, bias = synth.conv_inputs(spec, hw + cin, negative_mul_fraction=0.2)
+    subset = [0, 77, 255]
+    scale, zp = synth.int8_quant_params(hw)
+    thr = O.thresholds_converter(spec, mul, bias)
+    for dst, kw, okw in ((amd.F32, {}, {}), (amd.I8, dict(scale=scale, zp=zp), dict(out_scale=float(scale), out_zero_point=zp)),
+                         (amd.BITPACKED, dict(thr=thr), dict(thresholds=thr))):
+        args = (x, w) if dst == amd.BITPACKED else (x, w, mul, bias)
+        got, name = _gpu_conv(spec, dst, *args, engine="auto", **kw)
+        ref, rname = _gpu_conv(spec, dst, *args, engine="direct", **kw)
+        assert name.startswith("bconv2d_pointwise<") and rname.startswith("bconv2d_mfma"), (name, rname)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), name
+        odst = {amd.F32: O.DST_F32, amd.I8: O.DST_I8, amd.BITPACKED: O.DST_BITPACKED}[dst]
+        oargs = (x[subset], w) if dst == amd.BITPACKED else (x[subset], w, mul, bias)
+        want = O.bconv2d(sub, odst, *oargs, threads=8, **okw)
+        assert np.array_equal(got[subset].view(np.uint8), want.view(np.uint8)), name
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
+    torch.cuda.synchronize()
+    assert plan.kernel_name().startswith("bconv2d_pointwise<")
+    assert torch.equal(bits, amd.bitpack(y))
+
+
 def test_birealnet_style_int8_stack():
     """BASELINE config 5 flavour: 1x1 and strided 3x3 layers with int8 output and a RELU
     clamp, chained through LceQuantize on the device (int8 -> bitpacked -> bconv)."""
