@@ -228,16 +228,31 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   for (int k = 0; k < 4; ++k) item_issue((uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
   LCE_SPH(58);
 
-  // the filter bank of this wave's 64 channels, resident for the life of the block
+  // the filter bank of this wave's 64 channels, resident for the life of the block.  Its 2 * KS 16-byte loads per lane keep the
+  // CU's vector memory path busy for ~5 k cycles (295 KB per CU); a quarter goes out at once, the rest in small pieces between the work that does not
+  // need them in between -- the per-channel constants, the ring's padding columns, the expansion of the first rows (whose
+  // loads are older and return first) -- so that work rides in the shadow of the bank's arrival instead of waiting in
+  // front of it or behind it.  (The wave that issues the loads is the wave that expands: a run is short enough to
+  // queue without stalling the wave.)
   u32x4 W[KS][2];
-  {
-    const rsrc_t rw = make_rsrc(wq, G.w_bytes);
+  const rsrc_t rw = make_rsrc(wq, G.w_bytes);
+  // loads [a, b) of the bank's 2 * KS, numbered ks * 2 + j
+  auto bank_loads = [&](auto ac, auto bc) LCE_LAMBDA_INLINE {
+    constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        W[ks][j] = buf_load(rw, slice_ok ? (uint32_t)((ks * 2 + half) * G.Npad + n0 + j * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
-  }
+    for (int i = a; i < b; ++i)
+      W[i >> 1][i & 1] = buf_load(rw, slice_ok ? (uint32_t)(((i >> 1) * 2 + half) * G.Npad + n0 + (i & 1) * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
+    sched_fence();
+  };
+  constexpr int kBankFirst = KS / 2;                        // the first run: a quarter of the bank
+  constexpr int kBankRest = 2 * KS - kBankFirst;            // the rest: sixteen pieces, one behind each expanded word
+  auto bank_run = [&](auto rc) LCE_LAMBDA_INLINE { bank_loads(IntC<0>{}, IntC<kBankFirst>{}); };
+  auto bank_piece = [&](auto pc) LCE_LAMBDA_INLINE {
+    constexpr int p = decltype(pc)::value;
+    bank_loads(IntC<kBankFirst + kBankRest * p / 16>{}, IntC<kBankFirst + kBankRest * (p + 1) / 16>{});
+  };
+  sched_fence();
+  bank_run(IntC<0>{});
   LCE_SPH(59);
   // per-channel constants of this lane's two channels; multiplier and bias twice each: the transform works on
   // register pairs (v_pk_mul_f32 / v_pk_add_f32, each element rounded twice as output_transform.h:105 does)
@@ -276,9 +291,27 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   }
   block_barrier_keep_vm();
   LCE_SPH(60);
-  // everything tile step 0 needs
-#pragma unroll
-  for (int k = 0; k < 4; ++k) item_write(wv0[k], dv0[k], mv0[k]);
+  // everything tile step 0 needs, with a piece of the bank's remaining loads behind every expanded word
+  sched_fence();
+  auto item_write_with_bank = [&](auto kc, const u32x4& wv, uint32_t dst, int meta) LCE_LAMBDA_INLINE {
+    constexpr int k = decltype(kc)::value;
+    item_write_word(IntC<0>{}, wv, dst, meta);
+    sched_fence();
+    bank_piece(IntC<4 * k + 0>{});
+    item_write_word(IntC<1>{}, wv, dst, meta);
+    sched_fence();
+    bank_piece(IntC<4 * k + 1>{});
+    item_write_word(IntC<2>{}, wv, dst, meta);
+    sched_fence();
+    bank_piece(IntC<4 * k + 2>{});
+    item_write_word(IntC<3>{}, wv, dst, meta);
+    sched_fence();
+    bank_piece(IntC<4 * k + 3>{});
+  };
+  item_write_with_bank(IntC<0>{}, wv0[0], dv0[0], mv0[0]);
+  item_write_with_bank(IntC<1>{}, wv0[1], dv0[1], mv0[1]);
+  item_write_with_bank(IntC<2>{}, wv0[2], dv0[2], mv0[2]);
+  item_write_with_bank(IntC<3>{}, wv0[3], dv0[3], mv0[3]);
   for (uint32_t e0 = 4u * 256u; e0 < need0; e0 += 4u * 256u) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) item_issue(e0 + (uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
