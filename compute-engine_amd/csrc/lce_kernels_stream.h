@@ -218,22 +218,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     }
   };
 
-  // ---- prologue.  The first rows' loads go out FIRST: the memory counter retires in order, so behind the filter
-  // bank's 72 loads per lane they could not be consumed before the whole bank had arrived. ----
-  const uint32_t need0 = sched[0];
-  u32x4 wv0[4];
-  uint32_t dv0[4];
-  int mv0[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) item_issue((uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
-  LCE_SPH(58);
-
-  // the filter bank of this wave's 64 channels, resident for the life of the block.  Its 2 * KS 16-byte loads per lane keep the
-  // CU's vector memory path busy for ~5 k cycles (295 KB per CU); a quarter goes out at once, the rest in small pieces between the work that does not
-  // need them in between -- the per-channel constants, the ring's padding columns, the expansion of the first rows (whose
-  // loads are older and return first) -- so that work rides in the shadow of the bank's arrival instead of waiting in
-  // front of it or behind it.  (The wave that issues the loads is the wave that expands: a run is short enough to
-  // queue without stalling the wave.)
+  // the filter bank of this wave's 64 channels, resident for the life of the block.  Its 2 * KS 16-byte loads per lane keep
+  // the CU's vector memory path busy for ~6 k cycles (295 KB per CU); a quarter goes out at once, the rest in small pieces
+  // between the work that does not need them -- the per-channel constants, the ring's padding columns, the expansion of
+  // the first rows -- so that work rides in the shadow of the bank's arrival instead of waiting in front of it or behind it.
   u32x4 W[KS][2];
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
   // loads [a, b) of the bank's 2 * KS, numbered ks * 2 + j
@@ -253,6 +241,18 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   };
   sched_fence();
   bank_run(IntC<0>{});
+  // ---- prologue.  The bank's first run goes out before anything else (it needs nothing but the kernel arguments, and the
+  // schedule's first entry -- a dependent scalar load -- is still on its way); the first rows' loads follow, AHEAD of the
+  // rest of the bank: the memory counter retires in order, so behind all 72 loads per lane they could not be consumed
+  // before the whole bank had arrived. ----
+  const uint32_t need0 = sched[0];
+  u32x4 wv0[4];
+  uint32_t dv0[4];
+  int mv0[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) item_issue((uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
+  LCE_SPH(58);
+
   LCE_SPH(59);
   // per-channel constants of this lane's two channels; multiplier and bias twice each: the transform works on
   // register pairs (v_pk_mul_f32 / v_pk_add_f32, each element rounded twice as output_transform.h:105 does)
