@@ -56,12 +56,12 @@ print("entry skew (cycles): max %d" % int(t0.max() - t0.min()))
 pro = (live[:, 1].astype(np.int64) - t0)
 print("prologue (filter bank, ring, first rows): mean %d  min %d  max %d" % (pro.mean(), pro.min(), pro.max()))
 if live[:, 58].any():
-    names = ["first rows' loads issued", "filter bank resident", "ring filled + barrier", "first rows expanded", "tile-0 quota issued + barrier"]
+    names = ["bank's first run + first rows' loads issued", "(stamp)", "constants, ring padding + barrier", "first rows expanded between the bank's pieces", "tile-0 quota issued, bank resident + barrier"]
     marks = [58, 59, 60, 61, 1]
     prev = t0
     for nm, mk in zip(names, marks):
         cur_ = live[:, mk].astype(np.int64)
-        print("   %-32s +%d" % (nm, (cur_ - prev).mean()))
+        print("   %-48s +%d" % (nm, (cur_ - prev).mean()))
         prev = cur_
 d = np.diff(live[:, 1:2 + nt].astype(np.int64), axis=1)
 print("tile steps: mean %d cycles  (first %d, median %d, last %d); per block step %d; per MFMA of a wave %.1f" % (
