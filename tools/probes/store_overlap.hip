@@ -87,6 +87,38 @@ __global__ __launch_bounds__(256) void fill_tile(float* out, int tiles) {
   }
 }
 
+// The streaming kernel's store pattern (round 3): 256 persistent blocks, block step s = one 32-pixel block of 256 channels, wave w
+// stores channels [64w, 64w + 64) of 4 rows per instruction (8 instructions per step).  WHICH pixel block a block writes at
+// step s: IMAGE (block b owns image b: its 98 pixel blocks are consecutive, the 256 blocks write at the same offset of
+// images 3,211,264 B = 49 x 64 KiB apart, in lock-step -- what the kernel does) or INTERLEAVED (pixel block s * 256 + b: at any
+// moment the 256 blocks write one contiguous 8 MiB window).  Do the lock-step writers collide on HBM channels?
+// LPR = lanes per row piece of one instruction: 16 (the kernel: a wave owns 64 channels, 4 rows x 256 B per instruction),
+// 32 (2 rows x 512 B: a wave would own 128 channels of 16 rows), 64 (1 row x 1 KiB: a wave would own whole rows -- needs a
+// block-level transpose)
+// SLAB > 0 (with IMAGE): the block's steps come in runs of SLAB consecutive pixel blocks (one segment of the streaming
+// kernel: 14 pixel blocks = 8 rows of a 56-wide image), run k of block b = segment k * 256 + b -- at any moment the 256
+// blocks write 256 consecutive segments (a 117 MB window) instead of 256 different images (822 MB)
+template <bool IMAGE, bool NT, int LPR = 16, int SLAB = 0>
+__global__ __launch_bounds__(256) void fill_stream_pattern(float* out, int steps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const v4f v = {1.f, 2.f, 3.f, (float)lane};
+  constexpr int RPI = 64 / LPR;            // rows per instruction
+  constexpr int WPR = 64 / LPR;            // waves side by side in a row (4, 2, 1)
+  const int wcol = wave % WPR, wrow = wave / WPR;
+  for (int s = 0; s < steps; ++s) {
+    size_t pb = IMAGE ? (size_t)blockIdx.x * steps + s : (size_t)s * gridDim.x + blockIdx.x;
+    if (SLAB > 0) pb = ((size_t)(s / SLAB) * gridDim.x + blockIdx.x) * SLAB + s % SLAB;
+    float* base = out + pb * 32 * kCh + wcol * (LPR * 4) + (lane % LPR) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = wrow * (8 * RPI) + k * RPI + lane / LPR;      // every wave writes 8 KiB per step
+      v4f* p = (v4f*)(base + (size_t)row * kCh);
+      if (NT) __builtin_nontemporal_store(v, p);
+      else *p = v;
+    }
+  }
+}
+
 // L0's work per block: 36 K-steps x 8 MFMAs per wave, 32 16-byte stores per wave.
 // STORES: 0 none, 1 burst after the K loop, 2 one per K-step inside it.  PERSIST: grid-stride over tiles.
 template <int STORES, bool MFMA>
@@ -197,6 +229,18 @@ int main() {
     snprintf(nm, sizeof nm, "scatter16_nt_persistent256_lds%dk", lds / 1024);
     TIME(nm, 0.0, (fill_tile<1><<<256, 256, lds>>>(out, tiles)));
   }
+  TIME("stream_pattern_image_blocked_nt", 0.0, (fill_stream_pattern<true, true><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_interleaved_nt", 0.0, (fill_stream_pattern<false, true><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_slab14_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 14><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_slab7_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 7><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_slab2_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 2><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_slab49_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 49><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_nt_512B_rows", 0.0, (fill_stream_pattern<true, true, 32><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_nt_1KiB_rows", 0.0, (fill_stream_pattern<true, true, 64><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_interleaved_nt_1KiB_rows", 0.0, (fill_stream_pattern<false, true, 64><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_plain_1KiB_rows", 0.0, (fill_stream_pattern<true, false, 64><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_plain", 0.0, (fill_stream_pattern<true, false><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_interleaved_plain", 0.0, (fill_stream_pattern<false, false><<<256, 256>>>(out, 98)));
   // how fast can ONE CU store when the rest of the chip leaves HBM alone?  G persistent blocks (150 KiB of LDS:
   // one per CU), 24 tiles each, tile16 pattern
   for (int g : {8, 32, 64, 128, 256}) {
