@@ -147,7 +147,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     } else if constexpr (c == 6) {
       I.slot = I.s - fastdiv_nb(I.s, G.div_r) * (uint32_t)G.R;
     } else if constexpr (c == 7) {
-      I.t = (I.slot * (uint32_t)G.Wp + (uint32_t)G.PW + I.x) * (uint32_t)PS;
+      I.t = I.slot * (uint32_t)G.pitch + ((uint32_t)G.PW + I.x) * (uint32_t)PS;
     } else if constexpr (c == 8) {
       dst = I.on ? I.t + (uint32_t)I.c0 * 16u : dump;
       meta = I.c0 | (I.inside ? 0x100 : 0);
@@ -286,7 +286,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     for (int e = tid; e < G.R * padc * CH; e += 256) {
       const int c16 = e % CH, t = e / CH, pc = t % padc, slot = t / padc;
       const int px = pc < G.PW ? pc : pc + G.W;
-      *(u32x4*)(lds0 + (size_t)(slot * G.Wp + px) * PS + c16 * 16) = v;
+      *(u32x4*)(lds0 + (size_t)slot * G.pitch + (size_t)px * PS + c16 * 16) = v;
     }
   }
   block_barrier_keep_vm();

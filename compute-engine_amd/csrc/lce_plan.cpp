@@ -406,6 +406,22 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   const int nslb = 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
   const int wp = (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
   const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16;
+  // Ring row pitch.  An A-fragment read is one 16-byte piece per lane, lane = pixel; the LDS serves 16 lanes per pass without
+  // conflicts when their 16-byte units differ mod 16.  Along a row consecutive pixels are ps / 16 (odd) units apart: fine.
+  // Where a 32-pixel block wraps to the next output row the unit jumps by pitch / 16 - (OW - 1) * SW * ps / 16 instead, and
+  // with pitch = wp * ps (two padding columns) two lanes of the pass collide: every wrap costs a second pass (profiles/r03
+  // PMC: 21 % of the LDS pipe's cycles on L0, 39 % on 14x14x256).  A skew of < 256 bytes per row makes the sequence continue
+  // across the wrap: SH * pitch / 16 = OW * SW * ps / 16 (mod 16).  (Solvable when SH is odd; otherwise no skew.)
+  int skew16 = 0;
+  if (d.stride_height % 2 == 1) {
+    const int want = (int)(((int64_t)p.out_w * d.stride_width * (ps / 16)) % 16);
+    for (int k = 0; k < 16; ++k)
+      if (((int64_t)d.stride_height * ((int64_t)wp * (ps / 16) + k)) % 16 == want) { skew16 = k; break; }
+  }
+#ifdef LCE_STREAM_NO_SKEW   // (A/B aid)
+  skew16 = 0;
+#endif
+  const int pitch = wp * ps + skew16 * 16;
   const int cus = std::max(1, p.num_cus / ny);
   // segment size (a divisor of the output height: every segment is whole): the fewest block steps on the busiest
   // block (ties: the longer segment, whose halo is re-expanded less)
@@ -426,7 +442,7 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     int rows = 0;
     std::vector<uint32_t> sched;
     if (!simulate_stream(p, rs, (int)spb, pph_log, &rows, &sched)) continue;
-    const int64_t ring = ((int64_t)rows * wp * ps + 1023) / 1024 * 1024;
+    const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
     if (ring + kStreamLdsExtra > 160 * 1024) continue;
     const int pbs = ceil_div(rs * p.out_w, 32);
     const int64_t nq = spb * pbs;
@@ -437,6 +453,7 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     p.st_spb = (int)spb; p.st_gx = (int)ceil_div((int)s, (int)spb); p.st_rows = rows; p.st_ring_bytes = (int)ring;
     p.st_batch = batch_chunk;
     p.wp = wp;
+    p.st_pitch = pitch;
     // ---- the tables: [sched | lim | ctx] ----
     const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
     const size_t n_sgn = d.dst_type == LCE_HIP_BITPACKED ? 0 : (size_t)nq * 64;
@@ -458,7 +475,7 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
         const int64_t s0 = gl * p.st_srs + r * sh;
         uint32_t* e = &p.st_tabs[n_sched + n_lim + ((size_t)q * 64 + lane) * 4];
         for (int fy = 0; fy < 3; ++fy)
-          e[fy] = (uint32_t)((((s0 + fy) % rows) * wp + ox * sw) * ps + half * 16);
+          e[fy] = (uint32_t)(((s0 + fy) % rows) * pitch + ox * sw * ps + half * 16);
         const int rowl = d.dst_type == LCE_HIP_F32 ? lane >> 4 : d.dst_type == LCE_HIP_I8 ? lane >> 2 : l31;
         e[3] = (uint32_t)((gl * npx + pb * 32 + rowl) * (int64_t)row_bytes);
         if (ragged && pb == pbs - 1) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
@@ -481,7 +498,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.OH = p.out_h; G.OW = p.out_w; G.N = d.channels_out; G.Npad = p.npad; G.Wout = p.wout;
   G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h; G.PW = p.pad_w;
   G.B = batch_chunk;
-  G.Wp = p.wp; G.R = p.st_rows; G.ring_bytes = p.st_ring_bytes;
+  G.Wp = p.wp; G.pitch = p.st_pitch; G.R = p.st_rows; G.ring_bytes = p.st_ring_bytes;
   G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
   G.QG = p.st_qg; G.IPR = p.st_ipr; G.RS = p.st_rs; G.SPI = p.st_spi; G.SRS = p.st_srs; G.PBS = p.st_pbs;
   G.S = batch_chunk * p.st_spi;

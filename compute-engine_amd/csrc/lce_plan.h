@@ -92,6 +92,7 @@ struct HostPlan {
   int num_cus = 256;                       // compute units of the device (the C ABI fills it in; the stream kernel's grid)
   int stream_rows_pref = 0;                // tuning aid: output rows per segment (0 = auto)
   int st_rs = 0, st_spi = 0, st_srs = 0, st_pbs = 0, st_pph_log = 0, st_ny = 1, st_qg = 0, st_ipr = 0;
+  int st_pitch = 0;                          // bytes per ring row slot
   int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images
   std::vector<uint32_t> st_tabs;           // [sched | lim | ctx]: the kernel's tables (lce_kernel_args.h, StreamArgs)
   uint32_t st_tab_lim = 0, st_tab_ctx = 0, st_tab_sgn = 0;   // byte offsets of lim / ctx / sgn inside st_tabs
