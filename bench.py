@@ -435,6 +435,19 @@ def extra_measurements(amd, torch, spec, args, dev):
                                                        **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_), **how}
         del pl_, x_, o_
 
+    # ... and the strided 1x1 shortcut convolutions of ResNet-style binary nets (round 3: on the pointwise kernel)
+    for hw, c in SL.QUICKNET_STAGES[:3]:
+        sps = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1, channels_out=2 * c, stride=2,
+                       activation=SL.ACT_RELU)
+        s_, kn, pl_, x_, o_ = time_layer(amd, torch, sps, amd.I8, st, wu, hw + 2, dev, sc, zp)
+        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st)
+        # (a stride-2 1x1 layer reads only a quarter of its input pixels: count those)
+        pix_out = args.batch * sps.out_h * sps.out_w
+        by = pix_out * sps.in_words * 4 + sps.channels_out * sps.in_words * 4 + sps.channels_out * 8 + pix_out * sps.channels_out
+        extra[f"pointwise_stride2_{hw}x{hw}x{c}_to_{2 * c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sps.binary_macs / s_, "kernel": kn,
+                                                                         **hbm(by, s_), **how}
+        del pl_, x_, o_
+
     # the north star's synthetic 224x224xC feature maps (3x3, C -> C, float output), 16 images = the pixel count of the
     # 56x56 layers at batch 256
     for c in (64, 128, 256):
