@@ -406,6 +406,10 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         bool inv[PRE];
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
+          pixv[k] = -1;
+#ifndef LCE_NO_HALO_SKIP   // (A/B aid)
+          if (e0 + k * NT >= items) continue;      // (block-uniform) a whole round of threads past the halo: 56x56x64 fills 406 of 1024
+#endif
           const int e = e0 + k * NT + tid;
           const int pix = (int)fastdiv((uint32_t)e, G.div_qg);     // (image * halo_rows + slot) * Wp + x
           const int c0 = (e - pix * G.QG) * 4;
