@@ -398,8 +398,13 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
     LCE_PH(8);
     // FAST (compile-time): every item is four full words (Cin % 128 == 0, no zero border) -- the
     // BASELINE layers -- so neither the loads nor the expansion carry per-word conditions.
-    auto halo_pass = [&](auto fast_c) LCE_LAMBDA_INLINE {
-      constexpr bool FAST = decltype(fast_c)::value;
+    // MODE 2 = FAST as above; MODE 1 (round 3) = every EXISTING word is a full word (Cin % 32 == 0, no zero border) but a
+    // pixel has fewer than four of them -- QuickNet's 64-channel layers, two words per pixel: no per-word channel counts,
+    // and the two words come in ONE 8-byte load instead of four conditional 4-byte loads; MODE 0 = the general path.
+    auto halo_pass = [&](auto mode_c) LCE_LAMBDA_INLINE {
+      constexpr int MODE = decltype(mode_c)::value;
+      constexpr bool FAST = MODE == 2;
+      const bool two_words = MODE == 1 && G.Cw == 2;
       for (int e0 = 0; e0 < items; e0 += PRE * NT) {
         u32x4 wv[PRE];
         int pixv[PRE], c0v[PRE];
@@ -422,6 +427,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           const uint32_t off = (uint32_t)li * img_bytes + (uint32_t)((iy * G.W + ix) * G.Cw + c0) * 4u;
           if (FAST || vec) {
             wv[k] = buf_load(rin, inside ? off : kOobOffset, (u32x4*)nullptr);
+          } else if (two_words) {
+            const u32x2 t = buf_load(rin, inside ? off : kOobOffset, (u32x2*)nullptr);
+            wv[k] = u32x4{t[0], t[1], 0u, 0u};
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -446,6 +454,9 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
           for (int q = 0; q < 4; ++q) {
             if constexpr (FAST) {
               *(u32x4*)(dst + q * 16) = fp4_of_full_word(wv[k][q]);
+            } else if constexpr (MODE == 1) {
+              const int cc = c0v[k] + q;       // (a word of the 64-channel padding that no real channel fills: FP4 zeros)
+              if (cc < G.CPW) *(u32x4*)(dst + q * 16) = cc < G.Cw ? fp4_of_full_word(wv[k][q]) : u32x4{0u, 0u, 0u, 0u};
             } else {
               const int cc = c0v[k] + q;
               if (cc < G.CPW) {
@@ -459,8 +470,11 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         }
       }
     };
-    if ((G.Cin & 127) == 0 && !G.zero_border) halo_pass(StepSteady{});
-    else halo_pass(StepTail{});
+    if ((G.Cin & 127) == 0 && !G.zero_border) halo_pass(IntC<2>{});
+#ifndef LCE_NO_HALO_FULLWORDS   // (A/B aid)
+    else if ((G.Cin & 31) == 0 && !G.zero_border) halo_pass(IntC<1>{});
+#endif
+    else halo_pass(IntC<0>{});
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       int p = p0 + (wm * WM + i) * 32 + l31;   // pixel of the tile's first image, or beyond it
