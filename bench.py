@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--launch-selftest", action="store_true", help="CPU-only check of the multi-rank launch path (gloo)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test aid for boxes with ONE GPU: every rank uses cuda:0 and the ranks meet over gloo, so the N > 1 "
+                         "code path (shards, barriers, gathers, the config-4 chain) can run there; not a measurement")
     args = ap.parse_args()
     global SPINUP_MS
     SPINUP_MS = args.spinup_ms
@@ -236,15 +239,19 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 and not args.share_gpu else 1):
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, the node has {torch.cuda.device_count()}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if world > 1 and not args.share_gpu else 0)
+    cdev = None if args.share_gpu else dev          # where the collectives' scalars live
     torch.cuda.set_device(dev)
 
     # weak scaling (default): the global batch grows with N; --global-batch fixes it (strong scaling).  Either way
@@ -259,7 +266,10 @@ def main():
     # the contract's timed region: barrier + sync, exactly K steps, sync + barrier, MAX over ranks
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[dev.index])
+            if args.share_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[dev.index])
         torch.cuda.synchronize(dev)
 
     # Clock spin-up (untimed, before the W warmup steps): the chip's clock governor needs some 10 ms of load to
@@ -283,8 +293,46 @@ def main():
     region_event_sec = evs[0].elapsed_time(evs[-1]) / 1e3 / args.steps
     per_step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     pct = lambda q: per_step_ms[min(len(per_step_ms) - 1, int(q * len(per_step_ms)))]
-    elapsed = shard.max_over_ranks(elapsed_local, dist, dev)
-    per_rank = shard.gather_over_ranks(elapsed_local, dist, dev)
+    elapsed = shard.max_over_ranks(elapsed_local, dist, cdev)
+    per_rank = shard.gather_over_ranks(elapsed_local, dist, cdev)
+
+    # BASELINE config 4 at its size when N > 1 (never part of `value`): every rank runs ITS shard of a QuickNetLarge batch --
+    # the 32 binary convolutions at batch 256 as one device-resident chain -- in the same barrier-bracketed way; the
+    # global batch is 256 x N (2048 on 8 GPUs).  Every rank takes part in the barriers and the gather whatever happens to it.
+    config4 = None
+    if world > 1 and not args.no_extra:
+        chain4, local4 = None, float("nan")
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import layer_chain
+            chain4 = layer_chain.LayerChain(amd, torch, SL.quicknet_layers(args.batch, (6, 8, 12, 6)), dev, dst="f32", seed=4000)
+            chain4.run_chain()
+            torch.cuda.synchronize(dev)
+            spin_up(torch, dev, chain4.run_chain)
+        except Exception:
+            chain4 = None
+        barrier()
+        try:
+            if chain4 is not None:
+                t4 = time.perf_counter()
+                for _ in range(args.steps):
+                    chain4.run_chain()
+                torch.cuda.synchronize(dev)
+                local4 = time.perf_counter() - t4
+        except Exception:
+            local4 = float("nan")
+        barrier()
+        per_rank4 = shard.gather_over_ranks(local4, dist, cdev)
+        if all(v == v for v in per_rank4):
+            worst = max(per_rank4)
+            config4 = {"workload": "BASELINE configs[3]: QuickNetLarge's 32 LceBconv2d layers, float outputs + fused sign words, "
+                                   "device-resident chain, batch %d per GPU" % args.batch,
+                       "global_batch": args.batch * world, "chain_ms": worst / args.steps * 1e3,
+                       "images_per_s": args.batch * world * args.steps / worst,
+                       "per_rank_chain_ms": [v / args.steps * 1e3 for v in per_rank4]}
+        else:
+            config4 = {"error": "a rank could not run the chain", "per_rank_seconds": per_rank4}
+        del chain4
 
     per_image_bmacs = spec.binary_macs // max(1, my_batch)
     total_bmacs = per_image_bmacs * global_batch * args.steps
@@ -311,9 +359,12 @@ def main():
         "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
         "per_gpu_value": value / world,
         "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+        "collective_backend": ("gloo (--share-gpu test aid)" if args.share_gpu else "nccl (RCCL)") if dist is not None else None,
         "per_rank_ms_per_step": [v / args.steps * 1e3 for v in per_rank],
         "kernel": kname + ("+expand_fp4" if mfma and not direct else ""),
     }
+    if config4 is not None:
+        result["config4_quicknet_large_sharded"] = config4
     if rank == 0:
         # dominant kernel alone (the GEMM of the matrix-core engine, or the single VALU kernel)
         if mfma and not direct:

@@ -160,10 +160,11 @@ def test_one_process_drives_one_plan_per_device():
         amd.check(amd.lib().lce_hip_set_device(0))
 
 
-def _bench(*flags, timeout=900):
+def _bench(*flags, timeout=900, no_extra=True):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-extra",
-                          "--no-cpu-baseline", *flags], env=env, capture_output=True, text=True, timeout=timeout)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                          *(["--no-extra"] if no_extra else []), "--no-cpu-baseline", *flags],
+                         env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -197,3 +198,17 @@ def test_bench_on_every_gpu_of_the_node_over_rccl():
     # BASELINE config 4 as stated: 2048 images over the node (on fewer than 8 GPUs: the same per-GPU share)
     r = _bench("--gpus", str(n), "--global-batch", str(256 * n))
     assert r["scaling"] == "strong" and r["config"]["global_batch"] == 256 * n and r["rccl_world_size"] == n
+
+
+def test_bench_multi_rank_path_with_two_ranks_sharing_one_gpu():
+    """The N > 1 code path of bench.py -- self-launch through torch.distributed.run, shard ranges, barriers, max / gather over
+    ranks, the config-4 chain every rank runs -- on a box with ONE GPU: --share-gpu puts both ranks on cuda:0 and lets them meet
+    over gloo (a test aid, not a measurement; the RCCL variant is the test above)."""
+    r = _bench("--gpus", "2", "--share-gpu", no_extra=False, timeout=900)
+    assert r["n_gpus"] == 2 and r["rccl_world_size"] == 2 and len(r["per_rank_ms_per_step"]) == 2
+    assert r["collective_backend"].startswith("gloo") and r["config"]["global_batch"] == 512 and r["scaling"] == "weak"
+    assert abs(r["value"] - 9 * 256 * 256 * 56 * 56 * 512 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    c4 = r["config4_quicknet_large_sharded"]
+    assert c4["global_batch"] == 512 and len(c4["per_rank_chain_ms"]) == 2 and c4["chain_ms"] >= max(c4["per_rank_chain_ms"]) - 1e-9
+    assert abs(c4["images_per_s"] - 512 / (c4["chain_ms"] * 1e-3)) < 1e-6 * c4["images_per_s"]
+    assert "extra" not in r and "cpu_baseline" not in r      # N = 1 only
