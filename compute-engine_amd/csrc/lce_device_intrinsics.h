@@ -172,7 +172,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 LCE_DEVICE f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
   i32x8 va = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
   i32x8 vb = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);   // E8M0 0x7F = 1.0
+}
+// The same product from the UNSCALED instruction: scale operands 0 make the compiler select v_mfma_f32_32x32x64_f8f6f4
+// (cbsz:4 blgp:4, one 8-byte instruction, inputs taken at scale 1) instead of the scaled form above (16 bytes:
+// v_mfma_ld_scale_b32 + v_mfma).  For a wave that is ALONE on its SIMD and fills the gaps behind its MFMAs with other work
+// the scaled form costs ~2 more issue cycles per MFMA and one of the filler slots (tools/probes/mfma_gap.hip: 39.2 vs 37.2
+// cycles per MFMA with four v_mul behind it): the streaming kernel runs L0 1.7 % (float) / 4.7 % (int8) / 3 % (bitpacked)
+// faster with it, the pointwise kernel 2 %.  The block GEMM -- two waves per SIMD, bound by the matrix pipe -- is 4 %
+// SLOWER with it on 7x7x512 and keeps the scaled form (profiles/r03/mfma_scaled_vs_unscaled.txt).  Bit-identical results.
+LCE_DEVICE f32x16 mfma_fp4_32x32x64_unscaled(u32x4 a, u32x4 b, f32x16 c) {
+  i32x8 va = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0};
+  i32x8 vb = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], 0, 0, 0, 0};
+#ifdef LCE_MFMA_SCALED   // (A/B aid)
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#else
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, c, 4, 4, 0, 0, 0, 0);
+#endif
 }
 LCE_DEVICE f32x16 f32x16_fill(float v) {
   f32x16 z;

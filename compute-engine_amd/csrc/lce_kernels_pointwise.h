@@ -139,7 +139,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j)   // K_bt + <a, -w> = K_bt - <a, w> = 2 * accum: the first step adds to the constant tile
-        acc[j] = mfma_fp4_32x32x64(a, bf[c][j], c == 0 ? kbt : acc[j]);
+        acc[j] = mfma_fp4_32x32x64_unscaled(a, bf[c][j], c == 0 ? kbt : acc[j]);
     }
 
     const uint32_t row0 = (uint32_t)t * 32u;                      // first pixel of the tile

@@ -582,8 +582,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         constexpr int g = ks / GA;
         constexpr int fs = (g + k * NG) & 1;     // the fragment set this block's group g lives in (set 0 after a barrier)
         // ---------------- MFMA 0 ----------------
-        if constexpr (ks == 0) acc[PAR][0] = mfma_fp4_32x32x64(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
-        else acc[PAR][0] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
+        if constexpr (ks == 0) acc[PAR][0] = mfma_fp4_32x32x64_unscaled(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
+        else acc[PAR][0] = mfma_fp4_32x32x64_unscaled(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
         pin(acc[PAR][0]);    // (an MFMA has no side effect the sched_fence could hold: the pin keeps it in place)
         sched_fence();       // ... alone in its scheduling region: no filler may slip in FRONT of it
         // ---------------- gap 0 ----------------
@@ -631,8 +631,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         }
         sched_fence();
         // ---------------- MFMA 1 ----------------
-        if constexpr (ks == 0) acc[PAR][1] = mfma_fp4_32x32x64(af[fs][0], W[0][1], kbt);
-        else acc[PAR][1] = mfma_fp4_32x32x64(af[fs][ks % GA], W[ks][1], acc[PAR][1]);
+        if constexpr (ks == 0) acc[PAR][1] = mfma_fp4_32x32x64_unscaled(af[fs][0], W[0][1], kbt);
+        else acc[PAR][1] = mfma_fp4_32x32x64_unscaled(af[fs][ks % GA], W[ks][1], acc[PAR][1]);
         pin(acc[PAR][1]);
         sched_fence();
         // ---------------- gap 1 ----------------

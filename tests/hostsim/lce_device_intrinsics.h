@@ -123,6 +123,8 @@ inline void xor_popc_acc(int& c0, int& c1, int& c2, int& c3, uint32_t w, uint32_
 // ---- matrix-core path (lock-step block mode only) ----------------------------------
 // FP4 E2M1 code -> value for the codes the kernels use (0 -> 0, 0x2 -> +1, 0xA -> -1).
 inline int fp4_pm1(uint32_t nib) { return nib == 0x2 ? 1 : nib == 0xA ? -1 : 0; }
+inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c);
+inline f32x16 mfma_fp4_32x32x64_unscaled(u32x4 a, u32x4 b, f32x16 c) { return mfma_fp4_32x32x64(a, b, c); }
 inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
   const int lane = g_ctx.tid_x & 63;
   uint32_t* x = g_ctx.mfma_xchg;

@@ -5,6 +5,11 @@
 // Build twice:  hipcc -O3 --offload-arch=gfx950 -o mfma_gap_a mfma_gap.hip                                  (AGPR accumulators)
 //               hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -o mfma_gap_v mfma_gap.hip     (VGPR accumulators)
 #include <hip/hip_runtime.h>
+// -DLCE_PROBE_SCALE=0: the compiler then selects the UNSCALED v_mfma_f32_32x32x64_f8f6f4 (8-byte encoding) instead of the
+// v_mfma_scale_... pair (16 bytes: v_mfma_ld_scale + v_mfma)
+#ifndef LCE_PROBE_SCALE
+#define LCE_PROBE_SCALE 0x7F7F7F7F
+#endif
 #include <cstdint>
 #include <cstdio>
 #include <vector>
@@ -74,13 +79,13 @@ __global__ __launch_bounds__(256, 1) void gap(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c0, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c0, 4, 4, 0, LCE_PROBE_SCALE, 0, LCE_PROBE_SCALE);
       asm volatile("" : "+v"(c0));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < N; ++i) filler<KIND>(f, x, lv, lds, lane, r, sacc, idle, s * 16 + i);
       __builtin_amdgcn_sched_barrier(0);
-      c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c1, 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c1, 4, 4, 0, LCE_PROBE_SCALE, 0, LCE_PROBE_SCALE);
       asm volatile("" : "+v"(c1));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
