@@ -20,9 +20,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-enum { F_VALU_MUL, F_VALU_PERM, F_DS_READ128, F_DS_WRITE2, F_STORE16, F_PK_MUL, F_SALU, F_VALU_OTHER_ACC, F_DS_WRITE128, F_KINDS };
+enum { F_VALU_MUL, F_VALU_PERM, F_DS_READ128, F_DS_WRITE2, F_STORE16, F_PK_MUL, F_SALU, F_VALU_OTHER_ACC, F_DS_WRITE128, F_WAIT, F_NOP,
+       F_VALU_LIT, F_KINDS };
 static const char* kNames[] = {"v_mul_f32", "v_perm_b32", "ds_read_b128", "ds_write2_b32", "buffer_store_dwordx4", "v_pk_mul_f32",
-                               "s_add_u32", "v_mul_f32 reading the idle accumulator set", "ds_write_b128"};
+                               "s_add_u32", "v_mul_f32 reading the idle accumulator set", "ds_write_b128",
+                               "s_waitcnt lgkmcnt(0) (nothing pending)", "s_nop 0", "v_and_b32 with a 32-bit literal"};
 
 __device__ unsigned long long g_cycles[1024];
 
@@ -50,6 +52,12 @@ __device__ __forceinline__ void filler(float (&f)[8], unsigned (&x)[8], u4& lv, 
     f[((2 * i) & 6) + 1] = a[1];
   } else if constexpr (KIND == F_SALU) {
     asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+  } else if constexpr (KIND == F_WAIT) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else if constexpr (KIND == F_NOP) {
+    asm volatile("s_nop 0");
+  } else if constexpr (KIND == F_VALU_LIT) {
+    asm volatile("v_and_b32 %0, 0x12345677, %0" : "+v"(x[i & 7]));
   } else if constexpr (KIND == F_VALU_OTHER_ACC) {
     asm volatile("v_mul_f32 %0, %1, %2" : "=v"(f[i & 7]) : "v"(idle[i & 15]), "v"(f[(i + 1) & 7]));
   }
@@ -74,6 +82,9 @@ __global__ __launch_bounds__(256, 1) void gap(float* out, int iters) {
   unsigned sacc = 0;
   float* mine = out + 4096 + ((size_t)blockIdx.x * 4 + wave) * 4096;
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 16384, 0x00020000);
+#ifdef LCE_PROBE_B_AGPR   // the B operand lives in accumulation registers (as the streaming kernel's filter bank does)
+  asm volatile("" : "+a"(b));
+#endif
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -139,6 +150,9 @@ int main() {
   kind<F_VALU_OTHER_ACC>(out, iters);
   kind<F_PK_MUL>(out, iters);
   kind<F_SALU>(out, iters);
+  kind<F_WAIT>(out, iters);
+  kind<F_NOP>(out, iters);
+  kind<F_VALU_LIT>(out, iters);
   kind<F_DS_READ128>(out, iters);
   kind<F_DS_WRITE2>(out, iters);
   kind<F_DS_WRITE128>(out, iters);
