@@ -400,7 +400,8 @@ def main():
             tf = 2.0 * spec.binary_macs / k_sec / 1e12
             result["compute"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": tf / MFMA_FP4_PEAK_TFLOPS,
-                                 "model": "v_mfma_scale_f32_32x32x64_f8f6f4 (fp4 x fp4), 2 FLOP per binary MAC"}
+                                 "model": "v_mfma_f32_32x32x64_f8f6f4 (fp4 x fp4; the unscaled encoding in the streaming / pointwise kernels, "
+                                          "v_mfma_scale_... in the block GEMM), 2 FLOP per binary MAC"}
         else:
             result["compute"] = {"bound": "valu", "achieved": spec.binary_macs / k_sec, "peak": VALU_BMAC_PEAK,
                                  "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
