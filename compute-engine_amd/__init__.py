@@ -31,7 +31,7 @@ SEM_REFERENCE, SEM_OPTIMIZED = 0, 1
 
 # every symbol include/lce_hip.h declares (tests check the library exports them all)
 ABI_SYMBOLS = (
-    "lce_hip_abi_version", "lce_hip_last_error", "lce_hip_device_count", "lce_hip_set_device",
+    "lce_hip_abi_version", "lce_hip_last_error", "lce_hip_build_flavor", "lce_hip_device_count", "lce_hip_set_device",
     "lce_hip_malloc", "lce_hip_free", "lce_hip_memcpy_h2d", "lce_hip_memcpy_d2h", "lce_hip_memset",
     "lce_hip_host_register", "lce_hip_host_unregister",
     "lce_hip_stream_create", "lce_hip_stream_destroy", "lce_hip_stream_synchronize",
@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
                 "(there is no Python or CPU fallback for the HIP kernels)")
         l = C.CDLL(LIB_PATH)
         l.lce_hip_last_error.restype = C.c_char_p
+        l.lce_hip_build_flavor.restype = C.c_char_p
         l.lce_hip_bconv2d_plan_kernel_name.restype = C.c_char_p
         l.lce_hip_bconv2d_plan_kernel_name.argtypes = [C.c_void_p]
         l.lce_hip_bconv2d_plan_destroy.restype = None

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lce_experiments.h"
 
 #define LCE_DEVICE __device__ __forceinline__
 #define LCE_LAMBDA_INLINE __attribute__((always_inline))

@@ -1,0 +1,36 @@
+// Instance table of the weight-stationary streaming kernel (lce_kernels_stream.h) (one translation unit of the product build instantiates it: see lce_kernel_types.h;
+// the host simulation of the CPU tests includes all four tables through lce_dispatch.h).
+#pragma once
+#include "../../include/lce_hip.h"
+#include "lce_kernel_types.h"
+#include "lce_kernels_stream.h"
+
+namespace lce {
+
+// 3x3 filters over 64 / 128 / 256 (padded) input channels; FAST = every padded word exists and padding is +1;
+// CLAMP = the float transform's clamp is not the identity; SIGN = the epilogue also writes the output's LceQuantize
+template <int DST, bool FAST, bool CLAMP, bool SIGN>
+stream_fn stream_by_kch(int kch) {
+  switch (kch) {
+    case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN>;
+    case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP, SIGN>;
+    case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP, SIGN>;
+    default: return nullptr;
+  }
+}
+template <int DST, bool CLAMP, bool SIGN>
+stream_fn stream_by_fast(int kch, bool fast) {
+  return fast ? stream_by_kch<DST, true, CLAMP, SIGN>(kch) : stream_by_kch<DST, false, CLAMP, SIGN>(kch);
+}
+inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign) {
+  switch (dst) {
+    case LCE_HIP_F32:
+      if (clamp) return sign ? stream_by_fast<kDstFloat, true, true>(kch, fast) : stream_by_fast<kDstFloat, true, false>(kch, fast);
+      return sign ? stream_by_fast<kDstFloat, false, true>(kch, fast) : stream_by_fast<kDstFloat, false, false>(kch, fast);
+    case LCE_HIP_I8:
+      return sign ? stream_by_fast<kDstInt8, false, true>(kch, fast) : stream_by_fast<kDstInt8, false, false>(kch, fast);
+    default: return stream_by_fast<kDstBitpacked, false, false>(kch, fast);
+  }
+}
+
+}  // namespace lce

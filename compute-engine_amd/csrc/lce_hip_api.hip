@@ -10,8 +10,17 @@
 #include <vector>
 
 #include "../../include/lce_hip.h"
-#include "lce_kernels.h"
-#include "lce_dispatch.h"
+#include "lce_kernels.h"          // the LceQuantize / LceDequantize / LceBMaxPool2d kernels are launched from here
+#include "lce_kernel_types.h"    // the convolution kernels live in their own translation units (lce_tu_*.hip)
+#ifdef LCE_UNITY
+// single-translation-unit build (tools/build_exp.sh): the time-stamp tools read __device__ arrays that must exist once
+#include "lce_tu_valu.hip"
+#include "lce_tu_mfma_ws.hip"
+#include "lce_tu_mfma_direct.hip"
+#include "lce_tu_mfma_2d.hip"
+#include "lce_tu_pointwise.hip"
+#include "lce_tu_stream.hip"
+#endif
 #include "lce_plan.h"
 #include "lce_prepare.h"
 
@@ -130,9 +139,6 @@ namespace {
 using lce::ConvArgs;
 using lce::tiled_fn;
 using lce::general_fn;
-using lce::find_tiled;
-using lce::find_general;
-using lce::find_mfma;
 using lce::mfma_fn;
 
 size_t out_elem_bytes(int dst) { return dst == LCE_HIP_I8 ? 1 : 4; }
@@ -216,6 +222,7 @@ extern "C" {
 
 int lce_hip_abi_version(void) { return LCE_HIP_ABI_VERSION; }
 const char* lce_hip_last_error(void) { return g_last_error.c_str(); }
+const char* lce_hip_build_flavor(void) { return LCE_BUILD_FLAVOR; }
 
 int lce_hip_device_count(void) {
   int n = 0;
@@ -327,7 +334,7 @@ lce_hip_status lce_hip_bitpack(lce_hip_dtype in_type, const void* in_dev, size_t
   const uint64_t blocks32 = total_words / 32;
   const unsigned grid = grid_for_stream(blocks32, 4);
   if (in_type == LCE_HIP_F32)
-    lce::bitpack_f32_flat<<<grid, 256, 0, st>>>((const float*)in_dev, (uint32_t*)out_dev, blocks32);
+    lce::bitpack_f32_flat<><<<grid, 256, 0, st>>>((const float*)in_dev, (uint32_t*)out_dev, blocks32);
   else if (in_type == LCE_HIP_I8)
     lce::bitpack_b8_flat<false><<<grid, 256, 0, st>>>((const uint8_t*)in_dev, (uint32_t*)out_dev, blocks32, zero_point);
   else
@@ -514,7 +521,7 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     int tm = 0, tn = 0;
     if (!strcmp(value, "auto")) { h.tile_pref = lce::TileShape{0, 0}; }
     else if (sscanf(value, "%dx%d", &tm, &tn) == 2 &&
-             ((tn <= 32 && lce::find_tiled(LCE_HIP_F32, tm, tn, 1)) || lce::mfma_cfg_by_tile(tm, tn))) {
+             ((tn <= 32 && lce::lookup_tiled(LCE_HIP_F32, tm, tn, 1)) || lce::mfma_cfg_by_tile(tm, tn))) {
       h.tile_pref = lce::TileShape{tm, tn};
     } else {
       return fail(LCE_HIP_ERR_INVALID, "plan_set_option: tile must be auto, a xor-popcount tile "
@@ -563,7 +570,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     bool sign_fused = false;
     if (h.use_mfma && h.use_pointwise && ((uintptr_t)out & 15) == 0) {
       // 1x1 streaming kernel: waves walk 32-pixel tiles of the launch's pixel matrix
-      lce::pointwise_fn fn = lce::find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
+      lce::pointwise_fn fn = lce::lookup_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::PwArgs P = lce::make_pw_args(h, nb);
       // k tiles per wave: enough blocks (>= 12 per CU when the launch has them) for the dispatcher to even
@@ -579,7 +586,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       // weight-stationary streaming kernel: one persistent block per CU walks its run of segments
       const lce::StreamArgs G = lce::make_stream_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
-      lce::stream_fn fn = lce::find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign);
+      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::stream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
@@ -592,7 +599,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       LCE_HIP_TRY(hipGetLastError());
       sign_fused = true;   // (also when there is none to write)
     } else if (h.use_mfma) {
-      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
+      mfma_fn fn = lce::lookup_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct, h.use_direct && h.tile_tx > 0);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::MfmaArgs G = lce::make_mfma_args(h, nb);
@@ -633,8 +640,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
         }
         const uint64_t chunks = (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4);  // threads of expand_fp4
         if (h.phase != 2) {
-          lce::expand_fp4<<<grid_for_stream((chunks + 63) / 64, 4), 256, 0, st>>>(in, (lce_dev::u32x4*)plan->workspace, G, chunks);
-          LCE_HIP_TRY(hipGetLastError());
+          LCE_HIP_TRY((hipError_t)lce::launch_expand_fp4(grid_for_stream((chunks + 63) / 64, 4), (void*)st, in, plan->workspace, G, chunks));
         }
         if (h.phase != 1) {
           const dim3 grid((unsigned)((A.M + bm - 1) / bm), (unsigned)(h.npad / bn));
@@ -653,7 +659,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
         }
       }
     } else if (h.use_tiled) {
-      tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
+      tiled_fn fn = lce::lookup_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const int64_t tasks = (int64_t)A.PT * A.NT;
       const int wpb = 4;
@@ -663,7 +669,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
                          plan->d_zpc.ptr, out);
       LCE_HIP_TRY(hipGetLastError());
     } else {
-      general_fn fn = find_general(h.d.dst_type);
+      general_fn fn = lce::lookup_general(h.d.dst_type);
       const unsigned gx = (unsigned)((A.M + 255) / 256);
       const unsigned gy = (unsigned)((h.d.channels_out + 31) / 32);
       hipLaunchKernelGGL(fn, dim3(gx, gy), dim3(256), 0, st, A, in, plan->d_filter.ptr,
@@ -871,6 +877,9 @@ lce_hip_status lce_hip_prepare_bitpack_filter(const float* filter_ohwi, int32_t 
 }
 
 #ifdef LCE_TIMELINE
+#ifndef LCE_UNITY
+#error "the time-stamp builds are single-translation-unit builds (-DLCE_UNITY, tools/build_exp.sh)"
+#endif
 // profiling aid (tools/timeline.py), not part of the ABI: the K-loop time stamps of the last launch
 int lce_hip_debug_read_timeline(void* host, size_t bytes) {
   if (bytes > sizeof(lce::lce_timeline)) bytes = sizeof(lce::lce_timeline);
@@ -879,6 +888,9 @@ int lce_hip_debug_read_timeline(void* host, size_t bytes) {
 #endif
 
 #ifdef LCE_STREAM_PHASES
+#ifndef LCE_UNITY
+#error "the time-stamp builds are single-translation-unit builds (-DLCE_UNITY, tools/build_exp.sh)"
+#endif
 // profiling aid (tools/stream_phases.py), not part of the ABI: the per-block tile-step stamps of the last stream launch
 int lce_hip_debug_read_stream_tl(void* host, size_t bytes) {
   if (bytes > sizeof(lce::lce_stream_tl)) bytes = sizeof(lce::lce_stream_tl);
@@ -887,6 +899,9 @@ int lce_hip_debug_read_stream_tl(void* host, size_t bytes) {
 #endif
 
 #ifdef LCE_PW_PHASES
+#ifndef LCE_UNITY
+#error "the time-stamp builds are single-translation-unit builds (-DLCE_UNITY, tools/build_exp.sh)"
+#endif
 // profiling aid (tools/pw_phases.py), not part of the ABI: the per-block stamps of the last pointwise launch
 int lce_hip_debug_read_pw_tl(void* host, size_t bytes) {
   if (bytes > sizeof(lce::lce_pw_tl)) bytes = sizeof(lce::lce_pw_tl);
@@ -900,6 +915,9 @@ int lce_hip_debug_clear_pw_tl(void) {
 #endif
 
 #ifdef LCE_PHASES
+#ifndef LCE_UNITY
+#error "the time-stamp builds are single-translation-unit builds (-DLCE_UNITY, tools/build_exp.sh)"
+#endif
 // profiling aid (tools/phases.py), not part of the ABI: the per-block phase stamps of the last launch
 int lce_hip_debug_read_phases(void* host, size_t bytes) {
   if (bytes > sizeof(lce::lce_phase_tl)) bytes = sizeof(lce::lce_phase_tl);

@@ -3,6 +3,7 @@
 // plain g++ for the host-side planner tests.
 #pragma once
 #include <stdint.h>
+#include "lce_experiments.h"
 
 namespace lce {
 

@@ -1,0 +1,46 @@
+// Kernel entry-point types and the per-translation-unit lookups of the product build.
+//
+// The product library compiles each kernel family in its own translation unit (csrc/Makefile: parallel builds, and
+// -amdgpu-mfma-vgpr-form only where it is wanted -- the streaming kernel); lce_hip_api.hip sees the kernels only through
+// the lookup_* functions below, which hand out host-side launch stubs.  lce_dispatch.h holds the (inline) instance
+// tables those lookups are made of; the host simulation of the CPU tests includes it directly.
+#pragma once
+#include <stdint.h>
+#include "lce_kernel_args.h"
+
+namespace lce {
+
+typedef void (*tiled_fn)(const ConvArgs, const uint32_t*, const uint32_t*, const float*,
+                         const float*, const int32_t*, const int32_t*, const float*, void*);
+typedef void (*general_fn)(const ConvArgs, const uint32_t*, const uint32_t*, const float*,
+                           const float*, const int32_t*, const float*, void*);
+typedef void (*mfma_fn)(const ConvArgs, const MfmaArgs, const uint8_t*, const uint8_t*, const float*,
+                        const float*, const float*, const float*, void*, uint32_t*);
+typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, const float*, const float*, const float*, void*, uint32_t*);
+typedef void (*stream_fn)(const StreamArgs, const uint8_t*, const uint8_t*, const float*, const float*, const float*,
+                          const uint32_t*, void*, uint32_t*);
+
+// lce_tu_valu.hip
+tiled_fn lookup_tiled(int dst, int tm, int tn, int ch);
+general_fn lookup_general(int dst);
+// lce_tu_mfma_ws.hip / lce_tu_mfma_direct.hip / lce_tu_mfma_2d.hip
+mfma_fn lookup_mfma_workspace(int dst, int bm, int bn, bool zero_pad_correction);
+mfma_fn lookup_mfma_direct(int dst, int bm, int bn, bool zero_pad_correction);
+mfma_fn lookup_mfma_direct_2d(int dst, int bm, int bn, bool zero_pad_correction);
+inline mfma_fn lookup_mfma(int dst, int bm, int bn, bool zero_pad_correction, bool direct, bool tile2d) {
+  if (direct && tile2d) return lookup_mfma_direct_2d(dst, bm, bn, zero_pad_correction);
+  return direct ? lookup_mfma_direct(dst, bm, bn, zero_pad_correction) : lookup_mfma_workspace(dst, bm, bn, zero_pad_correction);
+}
+// the workspace variant's expansion pass (bits -> FP4 word planes); returns the launch's hipError_t as an int
+int launch_expand_fp4(unsigned grid_x, void* stream, const uint32_t* in, void* workspace, const MfmaArgs& G, uint64_t chunks);
+// lce_tu_pointwise.hip
+pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided);
+// lce_tu_stream.hip
+stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign);
+
+// the streaming kernel's FAST variant's precondition (lce_kernels_stream.h)
+inline bool stream_fast(const StreamArgs& G) { return G.Cin % 64 == 0 && !G.zero_border; }
+// its clamp is the identity on [0, 2 * K_bt] (activation NONE)
+inline bool stream_clamps(const StreamArgs& G) { return !(G.cmin <= 0.0f && G.cmax >= 2.0f * G.a_bt); }
+
+}  // namespace lce

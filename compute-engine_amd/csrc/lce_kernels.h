@@ -390,6 +390,7 @@ bitpack_rows(const T* __restrict__ in, uint32_t* __restrict__ out, uint32_t rows
 // cover one 128-B line (one output word) per load, 4 loads in flight per lane; the 8
 // nibbles of a word are OR-reduced across the group with 3 xor-shuffles and lane 0 of
 // each group stores its 4 words as one 16-byte store.
+template <int UNUSED = 0>     // (a template so that only the translation unit that launches it emits it)
 LCE_KERNEL void __launch_bounds__(256)
 bitpack_f32_flat(const float* __restrict__ in, uint32_t* __restrict__ out, uint64_t nblocks32) {
   const int lane = thread_idx_x() & (kWave - 1);

@@ -86,6 +86,7 @@ LCE_DEVICE u32x4 fp4_of_full_word(uint32_t word) {
 // One thread per (workspace pixel, group of 4 input words): a 16-byte read of the pixel's
 // words (when the row allows it) feeds four 16-byte writes into four consecutive word
 // planes; consecutive threads are consecutive pixels, so every plane write is coalesced.
+template <int UNUSED = 0>     // (a template so that only the translation unit that launches it emits it)
 LCE_KERNEL void __launch_bounds__(256)
 expand_fp4(const uint32_t* __restrict__ in, u32x4* __restrict__ out, const MfmaArgs G, uint64_t total) {
   const uint64_t stride = (uint64_t)grid_dim_x() * (uint64_t)block_dim_x();

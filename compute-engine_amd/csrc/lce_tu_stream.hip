@@ -1,0 +1,7 @@
+// One translation unit of the product library (csrc/Makefile): see lce_kernel_types.h.
+#include <hip/hip_runtime.h>
+#include "lce_dispatch_stream.h"
+
+namespace lce {
+stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign) { return find_stream(dst, kch, fast, clamp, sign); }
+}  // namespace lce

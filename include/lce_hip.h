@@ -69,6 +69,10 @@ typedef enum lce_hip_semantics { LCE_HIP_SEM_REFERENCE = 0, LCE_HIP_SEM_OPTIMIZE
  * ---------------------------------------------------------------------------------- */
 int lce_hip_abi_version(void);
 const char* lce_hip_last_error(void);
+/* "product", or "experiment" for a library built with measuring aids compiled in (timing ablations whose results are
+ * wrong by construction, time-stamp builds: csrc/lce_experiments.h).  The library csrc/Makefile builds is "product" and
+ * cannot be anything else (the switches are compile errors there); a host may refuse to load anything else. */
+const char* lce_hip_build_flavor(void);
 /* number of usable HIP devices (0 when there is none; never fails) */
 int lce_hip_device_count(void);
 lce_hip_status lce_hip_set_device(int device);

@@ -179,7 +179,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       }
       const size_t ws = mfma_workspace_bytes(h, nb);
       std::vector<lce_dev::u32x4> work(ws / 16 + 16);
-      launch_sequential(3, 1, 256, [&] { expand_fp4(in, work.data(), G, (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4)); });
+      launch_sequential(3, 1, 256, [&] { expand_fp4<>(in, work.data(), G, (uint64_t)G.NPIX * (uint64_t)((G.CPW + 3) / 4)); });
       launch_block_lockstep((A.M + bm - 1) / bm, h.npad / bn, h.mfma.threads(), (size_t)h.mfma.lds_bytes(), [&] {
         fn(A, G, (const uint8_t*)work.data(), wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out, g_sign_out ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr);
       });

@@ -25,6 +25,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.lce_hip_abi_version() == 2
+    # the in-tree library is the product build: no timing ablation / A-B switch compiled in (csrc/lce_experiments.h)
+    assert lib.lce_hip_build_flavor() == b"product"
 
 
 def _params(spec: O.ConvSpec, dst, **kw):

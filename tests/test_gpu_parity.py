@@ -6,6 +6,7 @@ size-independent properties.
 Bars: int8 and bitpacked outputs bit-exact; float outputs bit-exact too (the north star
 asks for 1e-5; VALID / SAME-one / SAME-zero all reproduce the reference's rounding
 sequence exactly, so the tests ask for equality of the bit patterns)."""
+import os
 import zlib
 
 import numpy as np
@@ -21,6 +22,7 @@ from test_oracle_vs_float_conv import CASES, PADS, _id, legal
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+NTHREADS = os.cpu_count() or 8          # the oracle over ALL images of a full-size batch: 0.6 s for L0 on the GPU box's host cores
 TILES = ["4x16", "2x32", "2x16", "1x32", "1x16"]
 
 
@@ -315,14 +317,16 @@ def test_direct_variant_2d_tiles_on_wide_images(shape):
 
 
 @pytest.mark.parametrize("engine,kernel,k", [("auto", "auto", 3), ("direct", "auto", 3), ("mfma", "auto", 3), ("valu", "auto", 3),
-                                             ("valu", "general", 3), ("auto", "auto", 1), ("direct", "auto", 1)])
+                                             ("valu", "general", 3), ("auto", "auto", 1), ("direct", "auto", 1),
+                                             ("stream", "auto", 3)])
 @pytest.mark.parametrize("zp", [-128, -5, 0, 3, 127])
 def test_run_dual_on_an_int8_plan_is_run_followed_by_lcequantize(engine, kernel, k, zp):
     """lce_hip_bconv2d_run_dual with an int8 plan: the int8 tensor bit-equal to lce_hip_bconv2d_run's, the bits
     bit-equal to lce_hip_bitpack(I8, ., zero_point) of it (quantization.cc:76-114: bit = q < zero_point) -- from the
     same epilogue where the kernel variant can (block GEMM with the joint transpose, the pointwise kernel), by a
     second launch where not.  Scale and multipliers put results on and around the zero point, exact ties included."""
-    for shape in ((3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 136)):
+    # (the streaming kernel stores whole 16-byte groups of int8 channels: 144 in place of 136)
+    for shape in ((3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 144 if engine == "stream" else 136)):
         b, h, w_, cin, cout = shape
         spec = O.ConvSpec(b, h, w_, cin, k, k, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_NONE)
         x, w, mul, bias = synth.conv_inputs(spec, sum(shape) + zp, negative_mul_fraction=0.3)
@@ -339,6 +343,8 @@ def test_run_dual_on_an_int8_plan_is_run_followed_by_lcequantize(engine, kernel,
         bits = torch.full((b, spec.out_h, spec.out_w, (cout + 31) // 32), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
         plan.run_dual(xd, y2, bits)
         torch.cuda.synchronize()
+        if engine == "stream":
+            assert plan.kernel_name().startswith("bconv2d_stream<i8"), plan.kernel_name()
         assert torch.equal(y, y2), plan.kernel_name()
         assert torch.equal(bits, amd.bitpack(y, zp)), plan.kernel_name()
         want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp)
@@ -494,6 +500,41 @@ def test_conv_int8_exact_ties():
         assert np.array_equal(got, want)
 
 
+def _round_half_away_int8(num, den):
+    """saturate(round-half-away(num / den)) in exact integer arithmetic (output_transform.h:31-44: std::round, then the
+    clamp to int8's range)."""
+    num = num.astype(np.int64)
+    q = np.sign(num) * ((2 * np.abs(num) + den) // (2 * den))
+    return np.clip(q, -128, 127).astype(np.int8)
+
+
+@pytest.mark.parametrize("engine,want_kernel", [("stream", "bconv2d_stream<i8"), ("direct", "bconv2d_mfma_direct<i8"),
+                                                ("mfma", "bconv2d_mfma<i8"), ("valu", "bconv2d_tiled<i8")])
+def test_conv_int8_exact_ties_3x3x256(engine, want_kernel):
+    """Every engine's OWN int8 rounding on exact ties (the streaming kernel rounds in its woven epilogue,
+    lce_kernels_stream.h `rnd`): a 3x3x256 layer with multipliers of +-0.25 and integer biases, so that y = x / 4 + b
+    hits k + 0.5 whenever x = 2 (mod 4) -- x = <a, w> is even, a quarter of all outputs are ties.  The expected values
+    are LITERAL: round-half-away of the exact rational, from an integer convolution in NumPy/torch, not from the oracle
+    (which is checked against them too)."""
+    spec = O.ConvSpec(3, 14, 14, 256, 3, 3, 256, padding=O.PADDING_SAME, pad_values=1)
+    x, w, _, _ = synth.conv_inputs(spec, 41)
+    g = synth.rng(42)
+    mul = np.where(g.random(256) < 0.5, -0.25, 0.25).astype(np.float32)
+    bias = g.integers(-9, 10, 256).astype(np.float32)
+    from float_conv_ref import float_conv
+    xi, _ = float_conv(spec, x, w, mul, bias)                       # exact integers <a, w> (float64)
+    xi = np.rint(xi).astype(np.int64)
+    num = xi * np.where(mul < 0, -1, 1).astype(np.int64) + 4 * bias.astype(np.int64)     # y = num / 4
+    want = _round_half_away_int8(num, 4)
+    ties = (num % 4 == 2) & (np.abs(num) < 4 * 127)
+    assert ties.mean() > 0.15                                       # the case is what it claims to be
+    assert np.array_equal(O.bconv2d(spec, O.DST_I8, x, w, mul, bias), want)
+    got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, engine=engine)
+    assert name.startswith(want_kernel), name
+    assert np.array_equal(got, want), name
+    assert np.array_equal(got[ties], want[ties])
+
+
 def test_conv_adversarial_words():
     """All-zero / all-one activations and weights (SURVEY 8(d) adversarial fixtures)."""
     spec = O.ConvSpec(1, 8, 8, 160, 3, 3, 33, padding=O.PADDING_SAME, pad_values=1)
@@ -539,7 +580,7 @@ L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_ou
 @pytest.mark.parametrize("dst", [amd.F32, amd.I8, amd.BITPACKED])
 def test_l0_batch256_properties(dst, engine):
     """BASELINE config 2: 3x3 256->256 on 56x56, batch 256.
-    (a) a seeded 4-image subset is bit-exact vs the CPU oracle;
+    (a) ALL 256 images are bit-exact vs the CPU oracle;
     (b) batch independence: image i of the batched run == the same image run alone;
     (c) the tiled kernel and the independently written general kernel agree on a
         checksum of all 256 images;
@@ -557,12 +598,11 @@ def test_l0_batch256_properties(dst, engine):
     got, name = _gpu_conv(spec, dst, x, w, **kw)
     assert name.startswith({"valu": "bconv2d_tiled", "mfma": "bconv2d_mfma<", "direct": "bconv2d_mfma_direct<"}[engine])
     # (a)
-    subset = [0, 97, 200, 255]
-    sub_spec = O.ConvSpec(batch=len(subset), **L0)
     odst = {amd.F32: O.DST_F32, amd.I8: O.DST_I8, amd.BITPACKED: O.DST_BITPACKED}[dst]
-    want = O.bconv2d(sub_spec, odst, x[subset], w, mul, bias, thresholds=thr, out_scale=float(scale),
-                     out_zero_point=zp, threads=8)
-    assert np.array_equal(got[subset].view(np.uint8), want.view(np.uint8))
+    want = O.bconv2d(spec, odst, x, w, mul, bias, thresholds=thr, out_scale=float(scale),
+                     out_zero_point=zp, threads=NTHREADS)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    del want
     # (b)
     alone, _ = _gpu_conv(one, dst, x[97:98], w, **kw)
     assert np.array_equal(alone[0].view(np.uint8), got[97].view(np.uint8))
@@ -579,7 +619,7 @@ def test_l0_batch256_properties(dst, engine):
 @pytest.mark.parametrize("dst", [amd.F32, amd.I8, amd.BITPACKED])
 def test_l0_batch256_streaming_kernel(dst):
     """BASELINE config 2 on the weight-stationary streaming kernel (the auto choice for this layer):
-    (a) a seeded 4-image subset is bit-exact vs the CPU oracle; (b) all 256 images equal the block GEMM's (engine=direct);
+    (a) ALL 256 images are bit-exact vs the CPU oracle; (b) and equal the block GEMM's (engine=direct);
     (c) batch independence; (d) a batch that does not fill whole blocks (201 images) and forced 14-row segments."""
     B = 256
     spec = O.ConvSpec(batch=B, **L0)
@@ -591,11 +631,10 @@ def test_l0_batch256_streaming_kernel(dst):
         kw.update(scale=scale, zp=zp)
     got, name = _gpu_conv(spec, dst, x, w, engine="auto", **kw)
     assert name.startswith("bconv2d_stream<"), name
-    subset = [0, 97, 200, 255]
     odst = {amd.F32: O.DST_F32, amd.I8: O.DST_I8, amd.BITPACKED: O.DST_BITPACKED}[dst]
-    want = O.bconv2d(O.ConvSpec(batch=len(subset), **L0), odst, x[subset], w, mul, bias, thresholds=thr,
-                     out_scale=float(scale), out_zero_point=zp, threads=8)
-    assert np.array_equal(got[subset].view(np.uint8), want.view(np.uint8))
+    want = O.bconv2d(spec, odst, x, w, mul, bias, thresholds=thr, out_scale=float(scale), out_zero_point=zp, threads=NTHREADS)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    del want
     ref, rname = _gpu_conv(spec, dst, x, w, engine="direct", **kw)
     assert rname.startswith("bconv2d_mfma_direct<") and np.array_equal(ref.view(np.uint8), got.view(np.uint8))
     alone, _ = _gpu_conv(O.ConvSpec(batch=1, **L0), dst, x[97:98], w, engine="stream", **kw)
@@ -679,8 +718,8 @@ QUICKNET_LAYERS = [(56, 64), (28, 128), (14, 256), (7, 512)]
 
 @pytest.mark.parametrize("hw,c", QUICKNET_LAYERS)
 def test_quicknet_layer_shapes_batch256(hw, c):
-    """BASELINE config 3 layer shapes at batch 256: tiled vs general kernel agreement on
-    everything + oracle on a 3-image subset."""
+    """BASELINE config 3 layer shapes at batch 256: the planner's own choice, the xor-popcount kernels and both
+    matrix-core variants against the oracle on ALL 256 images."""
     B = 256
     kwargs = dict(in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3, channels_out=c,
                   padding=O.PADDING_SAME, pad_values=1)
@@ -692,22 +731,19 @@ def test_quicknet_layer_shapes_batch256(hw, c):
     for engine in ("mfma", "direct"):
         mf, mname = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine=engine)
         assert mname.startswith("bconv2d_mfma") and np.array_equal(mf.view(np.int32), gen.view(np.int32)), mname
-    subset = [0, 128, 255]
-    want = O.bconv2d(O.ConvSpec(batch=3, **kwargs), O.DST_F32, x[subset], w, mul, bias, threads=8)
-    assert np.array_equal(got[subset].view(np.int32), want.view(np.int32))
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=NTHREADS)
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
 
 
 @pytest.mark.parametrize("hw,cin,cout,stride", [(56, 64, 128, 2), (28, 128, 256, 2), (14, 256, 512, 2), (7, 512, 512, 1)])
 def test_pointwise_shortcut_layers_batch256(hw, cin, cout, stride):
     """The 1x1 layers round 3 moved to the pointwise kernel, at batch 256: strided shortcut convolutions of the ResNet-style
     sections and the 512-channel layer.  All three output types: the planner's choice (pointwise) equals the block GEMM
-    on the WHOLE batch bit for bit, and the oracle on a 3-image subset; float layers also through run_dual."""
+    on the WHOLE batch bit for bit, and the oracle on ALL 256 images; float layers also through run_dual."""
     kwargs = dict(in_h=hw, in_w=hw, channels_in=cin, filter_h=1, filter_w=1, channels_out=cout, stride_h=stride, stride_w=stride,
                   padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
     spec = O.ConvSpec(batch=256, **kwargs)
-    sub = O.ConvSpec(batch=3, **kwargs)
     x, w, mul, bias = synth.conv_inputs(spec, hw + cin, negative_mul_fraction=0.2)
-    subset = [0, 77, 255]
     scale, zp = synth.int8_quant_params(hw)
     thr = O.thresholds_converter(spec, mul, bias)
     for dst, kw, okw in ((amd.F32, {}, {}), (amd.I8, dict(scale=scale, zp=zp), dict(out_scale=float(scale), out_zero_point=zp)),
@@ -718,9 +754,8 @@ def test_pointwise_shortcut_layers_batch256(hw, cin, cout, stride):
         assert name.startswith("bconv2d_pointwise<") and rname.startswith("bconv2d_mfma"), (name, rname)
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), name
         odst = {amd.F32: O.DST_F32, amd.I8: O.DST_I8, amd.BITPACKED: O.DST_BITPACKED}[dst]
-        oargs = (x[subset], w) if dst == amd.BITPACKED else (x[subset], w, mul, bias)
-        want = O.bconv2d(sub, odst, *oargs, threads=8, **okw)
-        assert np.array_equal(got[subset].view(np.uint8), want.view(np.uint8)), name
+        want = O.bconv2d(spec, odst, *args, threads=NTHREADS, **okw)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), name
     plan = amd.Bconv2dPlan(_params(spec, amd.F32))
     plan.set_weights(w, mul, bias)
     y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
@@ -1026,7 +1061,7 @@ def _spec_of(L, batch):
 
 
 def _check_chain(chain, subset, odst):
-    """(a) the oracle, run as the same chain on a seeded subset of the images, reproduces every layer's bytes;
+    """(a) the oracle, run as the same chain on ALL images, reproduces every layer's bytes (and the second output's words);
     (b) batch independence: the subset run alone through a second chain gives the same bytes;
     (c) every layer, fed the very input the chain fed it, is bit-equal under the independently written
         any-shape xor-popcount kernel (all images)."""
@@ -1037,12 +1072,12 @@ def _check_chain(chain, subset, odst):
     for k, L in enumerate(chain.layers):
         w, mul, bias = chain.weights[k]
         scale, zp = chain.quant[k]
-        x = prev if chain.fed[k] else chain.x[k][subset].cpu().numpy()
-        want = O.bconv2d(_spec_of(L, len(subset)), odst, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=8)
-        got = chain.y[k][subset].cpu().numpy()
+        x = prev if chain.fed[k] else chain.x[k].cpu().numpy()
+        want = O.bconv2d(_spec_of(L, L.batch), odst, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=NTHREADS)
+        got = chain.y[k].cpu().numpy()
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (k, names[k])
         prev = O.bitpack(want, zp) if odst == O.DST_I8 else O.bitpack(want)
-        assert np.array_equal(chain.bits[k][subset].cpu().numpy(), prev), (k, names[k])
+        assert np.array_equal(chain.bits[k].cpu().numpy(), prev), (k, names[k])
     small = _chain([type(L)(**{**L.__dict__, "batch": len(subset)}) for L in chain.layers], chain.dst, 0)
     small.weights, small.quant = chain.weights, chain.quant
     for k, p in enumerate(small.plans):
