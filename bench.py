@@ -78,8 +78,36 @@ def spin_up(torch, dev, fn, ms=None):
     return n
 
 
-def time_layer(amd, torch, layer, dst, steps, warmup, seed, dev, scale=1.0, zp=0, engine="auto"):
-    """Returns (mean seconds per step from stream events, kernel name, plan, x, out).
+INFINITY_CACHE_BYTES = 256 << 20     # MI355X_MICROARCH.md: 256 MB Infinity Cache in front of HBM
+ROTATE_BYTES = 320 << 20             # a rotation of operand sets is at least this large (and at least 4 sets)
+
+
+class Rotation:
+    """Several (input, output) buffer sets of one layer, used round-robin: K back-to-back launches of ONE set re-read an
+    input and rewrite an output that fit the 256 MB Infinity Cache (every layer but L0's float output does), so such a
+    timing is a cache number, not an HBM number (round-3 review).  With >= 4 sets of > 256 MB in total every launch's
+    operands have been evicted by the time their turn comes again."""
+
+    def __init__(self, torch, x, out):
+        per_set = x.numel() * x.element_size() + out.numel() * out.element_size()
+        self.n = int(max(4, -(-ROTATE_BYTES // max(1, per_set))))
+        self.x = [x] + [x.clone() for _ in range(self.n - 1)]
+        self.out = [out] + [torch.empty_like(out) for _ in range(self.n - 1)]
+        self.i = 0
+        self.total_bytes = per_set * self.n
+
+    def run(self, plan):
+        k = self.i
+        self.i = (k + 1) % self.n
+        plan.run(self.x[k], self.out[k])
+
+    def describe(self):
+        return "%d operand sets used round-robin, %.0f MB in total (> the 256 MB Infinity Cache)" % (self.n, self.total_bytes / 1e6)
+
+
+def time_layer(amd, torch, layer, dst, steps, warmup, seed, dev, scale=1.0, zp=0, engine="auto", rotate=False):
+    """Returns (mean seconds per step from stream events, kernel name, plan, x, out) -- with rotate=True a sixth element,
+    the Rotation whose buffer sets the timed launches cycled through.
     Synthetic operands from tools/synthetic_layers.py -- the oracle is not involved."""
     w, mul, bias, thr = SL.weights(layer, seed)
     x = torch.from_numpy(SL.activations(layer, seed)).to(dev)
@@ -89,11 +117,14 @@ def time_layer(amd, torch, layer, dst, steps, warmup, seed, dev, scale=1.0, zp=0
     dt = {amd.F32: torch.float32, amd.I8: torch.int8, amd.BITPACKED: torch.int32}[dst]
     out = torch.empty(plan.output_shape, dtype=dt, device=dev)
     plan.run(x, out)
-    spin_up(torch, dev, lambda: plan.run(x, out))
+    rot = Rotation(torch, x, out) if rotate else None
+    fn = (lambda: rot.run(plan)) if rotate else (lambda: plan.run(x, out))
+    spin_up(torch, dev, fn)
     for _ in range(max(1, warmup)):
-        plan.run(x, out)
+        fn()
     torch.cuda.synchronize(dev)
-    return _event_time(torch, dev, lambda: plan.run(x, out), steps), plan.kernel_name(), plan, x, out
+    res = (_event_time(torch, dev, fn, steps), plan.kernel_name(), plan, x, out)
+    return res + (rot,) if rotate else res
 
 
 def graph_time(torch, dev, fn, steps, launches=20):
@@ -122,14 +153,24 @@ def graph_time(torch, dev, fn, steps, launches=20):
         return None
 
 
-def small_layer_entry(torch, dev, s_eager, plan, x, out, steps):
+def small_layer_entry(torch, dev, s_eager, plan, x, out, steps, rot=None):
     """(seconds per launch, how it was timed) for an `extra` layer: from a HIP graph when the eager figure is short enough to
-    be the host's launch rate."""
+    be the host's launch rate.  With a Rotation the launches (eager and captured alike) cycle through its operand sets, and
+    the entry also carries the round-3 figure -- one operand set, served by the Infinity Cache -- as `ms_one_operand_set`."""
+    how = {"timed_from": "back_to_back_launches"}
+    s_ = s_eager
     if s_eager < 60e-6:
-        g = graph_time(torch, dev, lambda: plan.run(x, out), steps)
+        launches = 20 if rot is None else max(20, rot.n)
+        g = graph_time(torch, dev, (lambda: plan.run(x, out)) if rot is None else (lambda: rot.run(plan)), steps, launches)
         if g is not None:
-            return g, {"timed_from": "hip_graph_x20", "ms_eager_launches": s_eager * 1e3}
-    return s_eager, {"timed_from": "back_to_back_launches"}
+            s_, how = g, {"timed_from": "hip_graph_x%d" % launches, "ms_eager_launches": s_eager * 1e3}
+    if rot is not None:
+        how["operands"] = rot.describe()
+        one = graph_time(torch, dev, lambda: plan.run(x, out), steps) if s_eager < 60e-6 else None
+        if one is None:
+            one = _event_time(torch, dev, lambda: plan.run(x, out), steps)
+        how["ms_one_operand_set"] = one * 1e3
+    return s_, how
 
 
 def cpu_baseline(target_seconds=8.0):
@@ -200,6 +241,55 @@ def launch_selftest(args):
         dist.destroy_process_group()
 
 
+def verify_sharding(amd, torch, shard, dist, dev, world, rank, share_gpu):
+    """Untimed, before the barrier-bracketed region of an N > 1 run: proves that the line the run is about to print comes
+    from N ranks on N distinct devices whose shards are right.  (i) every rank reports its device (UUID, name, compute
+    units) and the RCCL version; without --share-gpu the N UUIDs must differ.  (ii) a small batch-sharded LceBconv2d
+    (QuickNet's 14x14x256 layer, 8 N + 3 images: ragged shards) runs slab by slab on the ranks' GPUs, all_gather_batch
+    reassembles it over the collective backend, and EVERY rank compares the gathered tensor bit for bit with its own
+    full-batch run of the same seeded operands.  A mismatch ends the run: no line is better than a wrong one."""
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device_index": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name,
+            "compute_units": props.multi_processor_count, "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    uuids = [d["uuid"] for d in everyone]
+    if not share_gpu and (len(set(uuids)) != world or "" in uuids):
+        raise SystemExit(f"bench.py: {world} ranks but the devices are not {world} distinct GPUs: {everyone}")
+    gb = 8 * world + 3
+    layer = SL.Layer(batch=gb, in_h=14, in_w=14, channels_in=256, filter_h=3, filter_w=3, channels_out=256,
+                     padding=SL.PADDING_SAME, pad_values=1)
+    w, mul, bias, thr = SL.weights(layer, 77)
+    x = SL.activations(layer, 78)                                        # the same seeded operands on every rank
+
+    def run(images):
+        L = SL.Layer(**{**layer.__dict__, "batch": images.shape[0]})
+        plan = amd.Bconv2dPlan(L.params(amd, amd.F32, 1.0, 0))
+        plan.set_weights(w, mul, bias, None)
+        y = plan.run(torch.from_numpy(np.ascontiguousarray(images)).to(dev))
+        torch.cuda.synchronize(dev)
+        return y
+
+    start, count = shard.shard_range(gb, world, rank)
+    local = run(x[start:start + count])
+    gathered = shard.all_gather_batch(local.cpu() if share_gpu else local, gb, dist)
+    whole = run(x)
+    same = bool(torch.equal(gathered.to(dev).view(torch.int32), whole.view(torch.int32)))
+    verdicts = [None] * world
+    dist.all_gather_object(verdicts, same)
+    if not all(verdicts):
+        raise SystemExit(f"bench.py: the batch-sharded run differs from the single-GPU run on ranks "
+                         f"{[r for r, v in enumerate(verdicts) if not v]}: refusing to report a throughput")
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl = None
+    return {"devices": everyone, "distinct_devices": len(set(uuids)), "rccl_version": rccl,
+            "sharded_equals_single_gpu_on_every_rank": True,
+            "check": f"LceBconv2d 3x3 14x14x256->256, {gb} images in {world} ragged slabs, all_gather_batch over the run's "
+                     f"collective backend, float output compared bit for bit on every rank"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +343,8 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 and not args.share_gpu else 0)
     cdev = None if args.share_gpu else dev          # where the collectives' scalars live
     torch.cuda.set_device(dev)
+
+    verified = verify_sharding(amd, torch, shard, dist, dev, world, rank, args.share_gpu) if dist is not None else None
 
     # weak scaling (default): the global batch grows with N; --global-batch fixes it (strong scaling).  Either way
     # every rank owns a contiguous slab of it
@@ -363,6 +455,8 @@ def main():
         "per_rank_ms_per_step": [v / args.steps * 1e3 for v in per_rank],
         "kernel": kname + ("+expand_fp4" if mfma and not direct else ""),
     }
+    if verified is not None:
+        result["multi_gpu_self_check"] = verified
     if config4 is not None:
         result["config4_quicknet_large_sharded"] = config4
     if rank == 0:
@@ -461,8 +555,10 @@ def extra_measurements(amd, torch, spec, args, dev):
     sc, zp = 0.125, 3
     hbm = lambda b, s: {"GBps_algorithmic": b / s / 1e9, "hbm_frac": b / s / 1e9 / HBM_PEAK_GBS}
     for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
-        s_, kn, *_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp)
-        extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_)}
+        s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp, rotate=True)
+        extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_),
+                     "operands": rot_.describe()}
+        del _p, _x, _o, rot_
     # the other matrix-core variant (FP4 workspace + GEMM whose tiles span images) and the xor-popcount
     # engine (the north star's literal formulation) on the same layer
     s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="mfma")
@@ -474,15 +570,17 @@ def extra_measurements(amd, torch, spec, args, dev):
     for hw, c in SL.QUICKNET_STAGES:
         sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
                       channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
-        s_, kn, pl_, x_, o_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev)
-        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st)
+        s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev, rotate=True)
+        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+        del rot_
         extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
                                                 **hbm(sp.algorithmic_bytes(SL.DST_F32), s_), **how}
         # ... and the 1x1 int8 + RELU layers of config 5's flavour (the HBM-bound cases)
         sp1 = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
                        channels_out=c, activation=SL.ACT_RELU)
-        s_, kn, pl_, x_, o_ = time_layer(amd, torch, sp1, amd.I8, st, wu, hw + 1, dev, sc, zp)
-        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st)
+        s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp1, amd.I8, st, wu, hw + 1, dev, sc, zp, rotate=True)
+        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+        del rot_
         extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sp1.binary_macs / s_, "kernel": kn,
                                                        **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_), **how}
         del pl_, x_, o_
@@ -491,8 +589,9 @@ def extra_measurements(amd, torch, spec, args, dev):
     for hw, c in SL.QUICKNET_STAGES[:3]:
         sps = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1, channels_out=2 * c, stride=2,
                        activation=SL.ACT_RELU)
-        s_, kn, pl_, x_, o_ = time_layer(amd, torch, sps, amd.I8, st, wu, hw + 2, dev, sc, zp)
-        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st)
+        s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sps, amd.I8, st, wu, hw + 2, dev, sc, zp, rotate=True)
+        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+        del rot_
         # (a stride-2 1x1 layer reads only a quarter of its input pixels: count those)
         pix_out = args.batch * sps.out_h * sps.out_w
         by = pix_out * sps.in_words * 4 + sps.channels_out * sps.in_words * 4 + sps.channels_out * 8 + pix_out * sps.channels_out
@@ -505,9 +604,11 @@ def extra_measurements(amd, torch, spec, args, dev):
     for c in (64, 128, 256):
         spf = SL.Layer(batch=max(1, args.batch // 16), in_h=224, in_w=224, channels_in=c, filter_h=3, filter_w=3,
                        channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
-        s_, kn, *_ = time_layer(amd, torch, spf, amd.F32, st, wu, 224 + c, dev)
+        s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spf, amd.F32, st, wu, 224 + c, dev, rotate=True)
         extra[f"feature_map_224x224x{c}_f32_batch{spf.batch}"] = {"ms": s_ * 1e3, "bmac_per_s": spf.binary_macs / s_, "kernel": kn,
-                                                                 **hbm(spf.algorithmic_bytes(SL.DST_F32), s_)}
+                                                                 **hbm(spf.algorithmic_bytes(SL.DST_F32), s_),
+                                                                 "operands": rot_.describe()}
+        del _p, _x, _o, rot_
 
     # configs 3, 4 (one GPU's shard) and 5 as REAL stacks: every layer has its own plan, weights and
     # buffers, run back to back on one stream -- (a) the convolutions alone, each on its own input;
@@ -568,29 +669,34 @@ def extra_measurements(amd, torch, spec, args, dev):
     extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
     po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
     torch.cuda.synchronize(dev)
-    # (a 5 us kernel: timed from a captured HIP graph of 20 launches, or the host's launch rate is what is measured)
-    pool20 = lambda: [amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID, out=po) for _ in range(20)]
-    timed_from = "hip_graph"
+    # (a 5 us kernel: timed from a captured HIP graph, or the host's launch rate is what is measured; the launches cycle through
+    # enough input / output sets to exceed the Infinity Cache -- with one set the 26 MB input is a cache read)
+    n_sets = int(max(4, -(-ROTATE_BYTES // ((ow.numel() + po.numel()) * 4))))
+    ows = [ow] + [ow.clone() for _ in range(n_sets - 1)]
+    pos = [po] + [torch.empty_like(po) for _ in range(n_sets - 1)]
+    pool_all = lambda: [amd.bmaxpool(ows[k], 2, 2, 2, 2, amd.PADDING_VALID, out=pos[k]) for k in range(n_sets)]
+    timed_from = "hip_graph_x%d" % n_sets
     try:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            pool20()
+            pool_all()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            pool20()
+            pool_all()
         graph.replay()
         torch.cuda.synchronize(dev)
-        s_ = _event_time(torch, dev, graph.replay, st) / 20
+        s_ = _event_time(torch, dev, graph.replay, st) / n_sets
     except Exception:   # (a profiler attached to the process can invalidate the capture)
         torch.cuda.synchronize(dev)
-        timed_from, s_ = "back_to_back_launches", _event_time(torch, dev, pool20, st) / 20
+        timed_from, s_ = "back_to_back_launches", _event_time(torch, dev, pool_all, st) / n_sets
     pb = ow.numel() * 4 + po.numel() * 4
     extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(pb, s_),
                                                 "timed_from": timed_from,
-                                                "note": "26 MB input, just written: largely served by the 256 MB Infinity Cache"}
+                                                "operands": "%d input / output sets used round-robin, %.0f MB in total" % (n_sets, n_sets * pb / 1e6)}
+    del ows, pos
     del fx, ow, fo, po
     try:
         extra["tflite_ops_chain_host_tensors"] = tflite_chain_timing()
@@ -602,7 +708,8 @@ def extra_measurements(amd, torch, spec, args, dev):
 def tflite_chain_timing(batch=64):
     """PCIe-INCLUSIVE (never part of `value`): LceQuantize -> LceBconv2d -> LceBMaxPool2d -> LceBconv2d through the registered
     TFLite ops with HOST tensors (the interpreter's arena), as a converted model's binary section runs them, with and without
-    the ops' device residency (csrc/tflite/lce_ops.cc: tensors that only LCE ops read stay in HBM).  Synthetic operands; the
+    the ops' device residency (csrc/tflite/lce_ops.cc: once the host has declared its graph, tensors that only LCE ops read
+    stay in HBM).  Synthetic operands; the
     chain driver stands in for the interpreter (csrc/tflite/single_op_driver.cc)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import flexbuf               # flexbuffer writer for the ops' custom options (test tooling, not the oracle)
@@ -616,7 +723,7 @@ def tflite_chain_timing(batch=64):
     thr = np.full(c, 9 * c // 2, np.int32)
     mul, bias = np.ones(c, np.float32), np.zeros(c, np.float32)
     out = {}
-    for label, on in (("resident", True), ("every_op_stages_its_tensors", False)):
+    for label, on in (("resident_declared_graph", True), ("every_op_stages_its_tensors", False)):
         m = T.ChainModel()
         t_x = m.add_tensor(T.FLOAT32, x.shape, x)
         t_q = m.add_tensor(T.INT32, (0,) * 4)
@@ -633,6 +740,9 @@ def tflite_chain_timing(batch=64):
         m.add_node("LceBMaxPool2d", [t_c], [t_p], flexbuf.bmaxpool_options(2, 2, 2, 2, 1))
         m.add_node("LceBconv2d", [t_p, t_w2, t_m, t_b, -1], [t_y], flexbuf.bconv2d_options(c, 1, 1, 1, 1, 0, 1, 0))
         T.set_residency(on)
+        if on:
+            m.declare_graph([t_y])     # what an application does once (lce_ops_register.h, DeclareGraphForDeviceResidency);
+                                       # without it every op leaves its output in the arena, as the reference does
         try:
             if m.prepare() != 0 or m.invoke() != 0:
                 raise RuntimeError(m.log)

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -143,6 +144,44 @@ using lce::mfma_fn;
 
 size_t out_elem_bytes(int dst) { return dst == LCE_HIP_I8 ? 1 : 4; }
 
+// The unscaled FP4 MFMA's known-answer test (lce_mfma_selftest.h), once per device and kernel family (0: pointwise, 1: stream)
+lce_hip_status mfma_selftest_once(int dev, int family) {
+  static std::mutex mu;
+  static std::vector<int> state[2];       // -1 unknown, 0 passed, > 0 failed
+  std::lock_guard<std::mutex> lock(mu);
+  std::vector<int>& st = state[family];
+  if (dev < 0) return LCE_HIP_OK;
+  if ((size_t)dev >= st.size()) st.resize((size_t)dev + 1, -1);
+  if (st[dev] < 0) {
+    const int r = family ? lce::mfma_selftest_stream() : lce::mfma_selftest_pointwise();
+    if (r < 0) return fail(LCE_HIP_ERR_RUNTIME, "the FP4 matrix-core self-test could not run: %s", hipGetErrorString((hipError_t)(-r)));
+    st[dev] = r;
+  }
+  if (st[dev] != 0)
+    return fail(LCE_HIP_ERR_RUNTIME, "this build's unscaled FP4 MFMA (v_mfma_f32_32x32x64_f8f6f4 with FP4 operands at scale 1) does not "
+                "compute 3 - 64 = -61 for C = 3, A = +1, B = -1 on device %d: the compiler did not select the unscaled encoding "
+                "(lce_device_intrinsics.h, mfma_fp4_32x32x64_unscaled); refusing to run the %s kernels", dev, family ? "streaming" : "pointwise");
+  return LCE_HIP_OK;
+}
+
+// compute units of HIP device `dev` (0 when unknown), cached per device
+int device_compute_units(int dev) {
+  static std::mutex mu;
+  static std::vector<int> table;
+  if (dev < 0) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((size_t)dev >= table.size()) table.resize((size_t)dev + 1, -1);
+  if (table[dev] < 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      n = 0;
+    }
+    table[dev] = n;
+  }
+  return table[dev];
+}
+
 lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
   lce::HostPlan& h = plan->host;
   const int64_t pixels = (int64_t)batch_chunk * h.out_h * h.out_w;
@@ -151,15 +190,11 @@ lce_hip_status ensure_selected(lce_hip_bconv2d_plan* plan, int batch_chunk) {
       (!h.use_mfma || !h.wq.empty() || !h.have_weights))
     return LCE_HIP_OK;
   if (!plan->cus_forced) {
-    // the streaming kernel sizes its grid by the device's compute units (asked once per process)
-    static const int cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-        (void)hipGetLastError();
-        n = 0;
-      }
-      return n;
-    }();
+    // the streaming kernel sizes its grid by the compute units of the device the plan runs on: the one it is bound to, or
+    // the current one before its first run (asked once per device and process)
+    int dev = plan->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+    const int cus = device_compute_units(dev);
     if (cus > 0) h.num_cus = cus;
   }
   const std::string err = lce::select_kernel(h, pixels);
@@ -552,8 +587,10 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
                                  int32_t* sign_dev, int first, int count, hipStream_t st) {
   lce::HostPlan& h = plan->host;
   const int chunk = lce::max_batch_per_launch(h);
+  if (lce_hip_status s = check_device(plan)) return s;          // binds the plan to the current device on its first run ...
+  if (!plan->cus_forced && plan->host.num_cus != device_compute_units(plan->device) && device_compute_units(plan->device) > 0)
+    plan->selected_for_pixels = -1;                              // ... whose size the streaming kernel's grid follows
   if (lce_hip_status s = ensure_selected(plan, chunk)) return s;
-  if (lce_hip_status s = check_device(plan)) return s;
   if (lce_hip_status s = ensure_uploaded(plan)) return s;
 
   const size_t in_img_words = (size_t)h.d.in_height * h.d.in_width * h.cw;
@@ -570,6 +607,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     bool sign_fused = false;
     if (h.use_mfma && h.use_pointwise && ((uintptr_t)out & 15) == 0) {
       // 1x1 streaming kernel: waves walk 32-pixel tiles of the launch's pixel matrix
+      if (lce_hip_status s = mfma_selftest_once(plan->device, 0)) return s;
       lce::pointwise_fn fn = lce::lookup_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::PwArgs P = lce::make_pw_args(h, nb);
@@ -584,6 +622,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       sign_fused = true;   // (also when there is none to write)
     } else if (h.use_mfma && h.use_stream) {
       // weight-stationary streaming kernel: one persistent block per CU walks its run of segments
+      if (lce_hip_status s = mfma_selftest_once(plan->device, 1)) return s;
       const lce::StreamArgs G = lce::make_stream_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
       lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign);

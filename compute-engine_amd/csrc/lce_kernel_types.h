@@ -37,6 +37,10 @@ int launch_expand_fp4(unsigned grid_x, void* stream, const uint32_t* in, void* w
 pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided);
 // lce_tu_stream.hip
 stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign);
+// known-answer test of the unscaled FP4 MFMA as each of those two translation units compiled it (lce_mfma_selftest.h):
+// 0 = as assumed, 1 = wrong products, < 0 = -(hipError_t)
+int mfma_selftest_pointwise();
+int mfma_selftest_stream();
 
 // the streaming kernel's FAST variant's precondition (lce_kernels_stream.h)
 inline bool stream_fast(const StreamArgs& G) { return G.Cin % 64 == 0 && !G.zero_border; }

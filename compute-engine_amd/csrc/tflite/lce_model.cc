@@ -6,7 +6,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "flexbuffer_map.h"
@@ -19,6 +22,16 @@ struct lce_tflite_model {
   lce_tfl::Model m;
   std::vector<lce_tflite_section> sections;   // built by Partition() right after parsing
   void Partition();
+  // ---- state of lce_tflite_model_run_section (one run at a time per model) ----
+  std::mutex run_mu;
+  std::map<std::pair<int32_t, int64_t>, lce_hip_bconv2d_plan*> plans;   // (operator, batch * 2 + semantics) -> ready plan
+  struct DevBuf { void* ptr = nullptr; size_t bytes = 0; };
+  std::map<int32_t, DevBuf> scratch;                                    // intermediate tensors of a section, grow-only
+  int32_t last_run_fused = 0;                                           // LceQuantize launches the last run folded into a convolution
+  ~lce_tflite_model() {
+    for (auto& kv : plans) lce_hip_bconv2d_plan_destroy(kv.second);
+    for (auto& kv : scratch) if (kv.second.ptr) lce_hip_free(kv.second.ptr);
+  }
 };
 
 namespace {
@@ -29,61 +42,85 @@ bool IsLceOp(const lce_tfl::Operator& o) {
 }  // namespace
 
 // The partition a delegate would get (tensorflow/lite/graph_info.cc, PartitionGraphIntoIndependentNodeSubsets, restated from
-// its published description): alternate between epochs of LCE operators and epochs of the others; in an epoch every
-// operator of the epoch's kind whose inputs are all ready joins, repeatedly, until nothing more can; the LCE operators
-// of one epoch are one section.
+// its published description): alternate between epochs of LCE operators and epochs of the others, starting with an LCE
+// epoch; in an epoch every operator of the epoch's kind whose inputs are all ready joins, repeatedly, until nothing more
+// can; the LCE operators of one epoch, sorted by index, are one section.  (On a chain this is "walk the file, cut at
+// every builtin operator"; on a branched graph an LCE op further down the file joins an EARLIER section when nothing it
+// reads depends on a builtin operator in between.)  Linear in operators + tensor uses: per-tensor reader lists and a count
+// of unready inputs per operator; the model is untrusted input.
 void lce_tflite_model::Partition() {
   const int n_ops = (int)m.operators.size(), n_t = (int)m.tensors.size();
-  std::vector<char> ready(n_t, 1), done(n_ops, 0);
-  for (const lce_tfl::Operator& o : m.operators)
-    for (int32_t t : o.outputs)
-      if (t >= 0 && t < n_t) ready[t] = 0;                   // produced by an operator: not ready until it has run
+  auto valid = [&](int32_t t) { return t >= 0 && t < n_t; };
+  std::vector<char> produced(n_t, 0), is_output(n_t, 0), is_lce(n_ops, 0);
+  std::vector<std::vector<int32_t>> readers(n_t);
+  std::vector<int32_t> unready(n_ops, 0);
+  for (int i = 0; i < n_ops; ++i) {
+    is_lce[i] = IsLceOp(m.operators[i]) ? 1 : 0;
+    for (int32_t t : m.operators[i].outputs)
+      if (valid(t)) produced[t] = 1;                         // produced by an operator: not ready until it has run
+  }
+  for (int i = 0; i < n_ops; ++i)
+    for (int32_t t : m.operators[i].inputs)
+      if (valid(t)) {
+        readers[t].push_back(i);
+        if (produced[t]) ++unready[i];
+      }
+  for (int32_t t : m.outputs)
+    if (valid(t)) is_output[t] = 1;
+  // ready operators of either kind, waiting for their epoch
+  std::vector<int32_t> queue[2];
+  for (int i = 0; i < n_ops; ++i)
+    if (unready[i] == 0) queue[(int)is_lce[i]].push_back(i);
+  std::vector<int32_t> section_of(n_ops, -1);
+  std::vector<char> made(n_t, 0), listed(n_t, 0);
   int remaining = n_ops;
-  bool lce_epoch = true;
+  int kind = 1;                                              // 1: LCE epoch
   int idle_epochs = 0;
-  while (remaining > 0 && idle_epochs < 2) {
+  while (remaining > 0 && idle_epochs < 2) {                 // (a graph with a cycle or a dangling input never finishes)
+    std::vector<int32_t>& q = queue[kind];
     lce_tflite_section sec;
-    bool progress = true, any = false;
-    while (progress) {
-      progress = false;
-      for (int i = 0; i < n_ops; ++i) {
-        const lce_tfl::Operator& o = m.operators[i];
-        if (done[i] || IsLceOp(o) != lce_epoch) continue;
-        bool ok = true;
-        for (int32_t t : o.inputs) ok = ok && (t < 0 || t >= n_t || ready[t]);
-        if (!ok) continue;
-        done[i] = 1;
-        --remaining;
-        progress = any = true;
-        for (int32_t t : o.outputs)
-          if (t >= 0 && t < n_t) ready[t] = 1;
-        if (lce_epoch) sec.ops.push_back(i);
+    bool any = false;
+    for (size_t head = 0; head < q.size(); ++head) {         // grows while it is walked
+      const int32_t i = q[head];
+      any = true;
+      --remaining;
+      if (kind) sec.ops.push_back(i);
+      for (int32_t t : m.operators[i].outputs) {
+        if (!valid(t) || made[t]) continue;
+        made[t] = 1;
+        for (int32_t r : readers[t])
+          if (--unready[r] == 0) queue[(int)is_lce[r]].push_back(r);
       }
     }
-    if (lce_epoch && !sec.ops.empty()) {
+    q.clear();
+    if (kind && !sec.ops.empty()) {
       std::sort(sec.ops.begin(), sec.ops.end());
-      std::vector<char> inside(n_t, 0), in_sec(n_ops, 0);
+      const int32_t id = (int32_t)sections.size();
+      for (int32_t i : sec.ops) section_of[i] = id;
+      std::vector<int32_t> ins, outs;
       for (int32_t i : sec.ops) {
-        in_sec[i] = 1;
-        for (int32_t t : m.operators[i].outputs)
-          if (t >= 0 && t < n_t) inside[t] = 1;
-      }
-      for (int32_t i : sec.ops)
         for (int32_t t : m.operators[i].inputs)
-          if (t >= 0 && t < n_t && !inside[t] && !m.tensors[t].data &&
-              std::find(sec.inputs.begin(), sec.inputs.end(), t) == sec.inputs.end())
-            sec.inputs.push_back(t);
-      for (int32_t t = 0; t < n_t; ++t) {
-        if (!inside[t]) continue;
-        bool outside_reader = std::find(m.outputs.begin(), m.outputs.end(), t) != m.outputs.end();
-        for (int i = 0; i < n_ops && !outside_reader; ++i)
-          if (!in_sec[i]) outside_reader = std::find(m.operators[i].inputs.begin(), m.operators[i].inputs.end(), t) != m.operators[i].inputs.end();
+          if (valid(t) && !m.tensors[t].data) ins.push_back(t);
+        for (int32_t t : m.operators[i].outputs)
+          if (valid(t)) outs.push_back(t);
+      }
+      std::sort(outs.begin(), outs.end());
+      outs.erase(std::unique(outs.begin(), outs.end()), outs.end());
+      for (int32_t t : ins)                                  // first-use order
+        if (!listed[t] && !std::binary_search(outs.begin(), outs.end(), t)) {
+          listed[t] = 1;
+          sec.inputs.push_back(t);
+        }
+      for (int32_t t : sec.inputs) listed[t] = 0;
+      for (int32_t t : outs) {
+        bool outside_reader = is_output[t] != 0;
+        for (size_t k = 0; k < readers[t].size() && !outside_reader; ++k) outside_reader = section_of[readers[t][k]] != id;
         if (outside_reader) sec.outputs.push_back(t);
       }
       sections.push_back(sec);
     }
-    idle_epochs = any ? 0 : idle_epochs + 1;                 // (a graph with a cycle or a dangling input would never finish)
-    lce_epoch = !lce_epoch;
+    idle_epochs = any ? 0 : idle_epochs + 1;
+    kind ^= 1;
   }
 }
 
@@ -288,5 +325,218 @@ lce_hip_status lce_tflite_model_bconv2d_plan(const lce_tflite_model* model, int3
 }
 
 const char* lce_tflite_model_last_error(void) { return g_model_error.c_str(); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Running a binary section on device tensors (the C counterpart of examples/lce_minimal.cc:28-62 for a host without a
+// TensorFlow Lite interpreter, and what compute-engine_amd/model_runner.py calls).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Shape {
+  int32_t dims[4] = {0, 0, 0, 0};
+  int type = 0;
+  size_t bytes() const {
+    const size_t esz = (type == lce_tfl::kTensorInt8 || type == lce_tfl::kTensorBool) ? 1 : 4;
+    return (size_t)dims[0] * dims[1] * dims[2] * dims[3] * esz;
+  }
+};
+
+lce_hip_status PlanFor(lce_tflite_model* model, int32_t op, int32_t batch, int32_t semantics, lce_hip_bconv2d_plan** plan) {
+  const auto key = std::make_pair(op, (int64_t)batch * 2 + (semantics ? 1 : 0));
+  auto it = model->plans.find(key);
+  if (it == model->plans.end()) {
+    lce_hip_bconv2d_plan* p = nullptr;
+    if (lce_hip_status s = lce_tflite_model_bconv2d_plan(model, op, batch, semantics, &p)) return s;
+    it = model->plans.emplace(key, p).first;
+  }
+  *plan = it->second;
+  return LCE_HIP_OK;
+}
+
+// The LceQuantize operators of section `sec` that read the float / int8 output of LceBconv2d `conv` (their result is
+// the second output of the convolution's epilogue: lce_hip_bconv2d_run_dual).
+std::vector<int32_t> QuantizeConsumers(const lce_tflite_model* model, const lce_tflite_section& sec, int32_t conv) {
+  std::vector<int32_t> js;
+  const lce_tfl::Operator& op = model->m.operators[conv];
+  const int out_type = model->m.tensors[op.outputs[0]].type;
+  if (out_type != lce_tfl::kTensorFloat32 && out_type != lce_tfl::kTensorInt8) return js;
+  for (int32_t j : sec.ops) {
+    const lce_tfl::Operator& q = model->m.operators[j];
+    if (j > conv && q.custom_code == "LceQuantize" && q.inputs.size() == 1 && q.inputs[0] == op.outputs[0]) js.push_back(j);
+  }
+  return js;
+}
+
+// Walks section `sec` at `batch` images: shapes of every tensor it touches (shape inference exactly as the ops' Prepare
+// does it) and, with `run`, the launches.  `ptr` maps tensor -> device pointer (section inputs and outputs on entry;
+// intermediates are added from the model's scratch buffers).
+lce_hip_status WalkSection(lce_tflite_model* model, const lce_tflite_section& sec, int32_t batch, int32_t semantics,
+                           std::map<int32_t, Shape>* shapes, std::map<int32_t, void*>* ptr, bool run, void* stream) {
+  const lce_tfl::Model& M = model->m;
+  for (int32_t t : sec.inputs) {
+    const lce_tfl::Tensor& T = M.tensors[t];
+    if (T.shape.size() != 4) return Fail(LCE_HIP_ERR_UNSUPPORTED, "run_section: section inputs must be 4-D tensors (NHWC)");
+    Shape sh;
+    for (int k = 0; k < 4; ++k) sh.dims[k] = T.shape[k];
+    sh.dims[0] = batch;
+    sh.type = T.type;
+    (*shapes)[t] = sh;
+  }
+  auto buffer_for = [&](int32_t t, size_t bytes, void** out) -> lce_hip_status {
+    auto it = ptr->find(t);
+    if (it != ptr->end()) { *out = it->second; return LCE_HIP_OK; }
+    lce_tflite_model::DevBuf& b = model->scratch[t];
+    if (b.bytes < bytes) {
+      // (a buffer a previous run's kernels may still use: the free below is ordered behind them by the runtime)
+      if (b.ptr) lce_hip_free(b.ptr);
+      b.ptr = nullptr;
+      b.bytes = 0;
+      if (lce_hip_status s = lce_hip_malloc(&b.ptr, bytes ? bytes : 1)) return s;
+      b.bytes = bytes;
+    }
+    (*ptr)[t] = b.ptr;
+    *out = b.ptr;
+    return LCE_HIP_OK;
+  };
+  std::vector<char> done(M.operators.size(), 0);
+  for (int32_t i : sec.ops) {
+    if (done[i]) continue;
+    const lce_tfl::Operator& op = M.operators[i];
+    if (op.inputs.empty() || op.outputs.size() != 1 || op.inputs[0] < 0)
+      return Fail(LCE_HIP_ERR_INVALID, "run_section: malformed LCE operator");
+    auto in_it = shapes->find(op.inputs[0]);
+    if (in_it == shapes->end()) return Fail(LCE_HIP_ERR_INVALID, "run_section: an operator reads a tensor nothing produced");
+    const Shape in = in_it->second;
+    const int32_t out_t = op.outputs[0];
+    const lce_tfl::Tensor& OT = M.tensors[out_t];
+    Shape out = in;
+    out.type = OT.type;
+    const void* in_dev = nullptr;
+    if (run) {
+      auto p = ptr->find(op.inputs[0]);
+      if (p == ptr->end() || !p->second) return Fail(LCE_HIP_ERR_INVALID, "run_section: missing device pointer of an input tensor");
+      in_dev = p->second;
+    }
+    if (op.custom_code == "LceQuantize") {                      // quantization.cc:19-41,76-114
+      if (in.type != lce_tfl::kTensorFloat32 && in.type != lce_tfl::kTensorInt8 && in.type != lce_tfl::kTensorBool)
+        return Fail(LCE_HIP_ERR_INVALID, "LceQuantize: input must be float32, int8 or bool");
+      out.dims[3] = (in.dims[3] + 31) / 32;
+      out.type = lce_tfl::kTensorInt32;
+      (*shapes)[out_t] = out;
+      if (run) {
+        void* o = nullptr;
+        if (lce_hip_status s = buffer_for(out_t, out.bytes(), &o)) return s;
+        const lce_tfl::Tensor& IT = M.tensors[op.inputs[0]];
+        const lce_hip_dtype t = in.type == lce_tfl::kTensorFloat32 ? LCE_HIP_F32 : in.type == lce_tfl::kTensorInt8 ? LCE_HIP_I8 : LCE_HIP_BOOL;
+        const int32_t zp = in.type == lce_tfl::kTensorInt8 ? (int32_t)IT.zero_point : in.type == lce_tfl::kTensorBool ? 1 : 0;
+        if (lce_hip_status s = lce_hip_bitpack(t, in_dev, (size_t)in.dims[0] * in.dims[1] * in.dims[2], (size_t)in.dims[3], zp, (int32_t*)o, stream)) return s;
+      }
+    } else if (op.custom_code == "LceDequantize") {             // quantization.cc:43-74,116-147
+      if (OT.shape.size() != 4) return Fail(LCE_HIP_ERR_UNSUPPORTED, "LceDequantize: the output's channel count comes from the file (4-D)");
+      out.dims[3] = OT.shape[3];
+      if ((out.dims[3] + 31) / 32 != in.dims[3]) return Fail(LCE_HIP_ERR_INVALID, "LceDequantize: output channels do not match the packed input");
+      (*shapes)[out_t] = out;
+      if (run) {
+        void* o = nullptr;
+        if (lce_hip_status s = buffer_for(out_t, out.bytes(), &o)) return s;
+        const lce_hip_dtype t = out.type == lce_tfl::kTensorFloat32 ? LCE_HIP_F32 : out.type == lce_tfl::kTensorInt8 ? LCE_HIP_I8 : LCE_HIP_BOOL;
+        if (lce_hip_status s = lce_hip_unpack(t, (const int32_t*)in_dev, (size_t)out.dims[0] * out.dims[1] * out.dims[2], (size_t)out.dims[3],
+                                              OT.quantized ? OT.scale : 1.0f, OT.quantized ? (int32_t)OT.zero_point : 0, o, stream)) return s;
+      }
+    } else if (op.custom_code == "LceBMaxPool2d") {             // bmaxpool.cc:20-91
+      const lce_flex::Map fm(op.custom_options, op.custom_options_size);
+      if (!fm.valid()) return Fail(LCE_HIP_ERR_INVALID, "LceBMaxPool2d: unreadable options");
+      const int32_t fh = fm.AsInt32("filter_height"), fw = fm.AsInt32("filter_width"), sh = fm.AsInt32("stride_height"),
+                    sw = fm.AsInt32("stride_width"), pad = fm.AsInt32("padding");
+      if (lce_hip_status s = lce_hip_bmaxpool_output_shape(in.dims[1], in.dims[2], fh, fw, sh, sw, pad, &out.dims[1], &out.dims[2])) return s;
+      (*shapes)[out_t] = out;
+      if (run) {
+        void* o = nullptr;
+        if (lce_hip_status s = buffer_for(out_t, out.bytes(), &o)) return s;
+        if (lce_hip_status s = lce_hip_bmaxpool((const int32_t*)in_dev, in.dims[0], in.dims[1], in.dims[2], in.dims[3], fh, fw, sh, sw, pad, (int32_t*)o, stream)) return s;
+      }
+    } else if (op.custom_code == "LceBconv2d") {                // bconv2d.cc:137-300,550-564
+      lce_hip_bconv2d_plan* plan = nullptr;
+      if (lce_hip_status s = PlanFor(model, i, batch, semantics, &plan)) return s;
+      if (lce_hip_status s = lce_hip_bconv2d_plan_output_shape(plan, out.dims)) return s;
+      (*shapes)[out_t] = out;
+      const std::vector<int32_t> fused = QuantizeConsumers(model, sec, i);
+      for (int32_t j : fused) {                                 // their shapes; the first one's launch disappears
+        Shape q = out;
+        q.dims[3] = (out.dims[3] + 31) / 32;
+        q.type = lce_tfl::kTensorInt32;
+        (*shapes)[M.operators[j].outputs[0]] = q;
+      }
+      if (!fused.empty()) done[fused[0]] = 1;
+      if (run) {
+        void* o = nullptr;
+        if (lce_hip_status s = buffer_for(out_t, out.bytes(), &o)) return s;
+        if (fused.empty()) {
+          if (lce_hip_status s = lce_hip_bconv2d_run(plan, (const int32_t*)in_dev, o, stream)) return s;
+        } else {
+          void* bits = nullptr;
+          const int32_t bits_t = M.operators[fused[0]].outputs[0];
+          if (lce_hip_status s = buffer_for(bits_t, (*shapes)[bits_t].bytes(), &bits)) return s;
+          if (lce_hip_status s = lce_hip_bconv2d_run_dual(plan, (const int32_t*)in_dev, o, (int32_t*)bits, stream)) return s;
+          ++model->last_run_fused;
+        }
+      }
+    } else {
+      return Fail(LCE_HIP_ERR_UNSUPPORTED, "run_section: operator " + op.custom_code + " is not an LCE op");
+    }
+  }
+  return LCE_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+lce_hip_status lce_tflite_model_section_tensor_shape(lce_tflite_model* model, int32_t section, int32_t tensor, int32_t batch,
+                                                     int32_t semantics, int32_t dims[4], size_t* bytes) {
+  g_model_error.clear();
+  if (!model || section < 0 || section >= (int32_t)model->sections.size() || batch <= 0)
+    return Fail(LCE_HIP_ERR_INVALID, "lce_tflite_model_section_tensor_shape: bad argument");
+  std::lock_guard<std::mutex> lock(model->run_mu);
+  std::map<int32_t, Shape> shapes;
+  std::map<int32_t, void*> ptr;
+  if (lce_hip_status s = WalkSection(model, model->sections[section], batch, semantics, &shapes, &ptr, false, nullptr)) return s;
+  auto it = shapes.find(tensor);
+  if (it == shapes.end()) return Fail(LCE_HIP_ERR_INVALID, "lce_tflite_model_section_tensor_shape: the section does not touch this tensor");
+  for (int k = 0; dims && k < 4; ++k) dims[k] = it->second.dims[k];
+  if (bytes) *bytes = it->second.bytes();
+  return LCE_HIP_OK;
+}
+
+lce_hip_status lce_tflite_model_run_section(lce_tflite_model* model, int32_t section, int32_t batch, int32_t semantics,
+                                            const void* const* inputs_dev, void* const* outputs_dev, void* stream) {
+  g_model_error.clear();
+  if (!model || section < 0 || section >= (int32_t)model->sections.size() || batch <= 0 || !inputs_dev || !outputs_dev)
+    return Fail(LCE_HIP_ERR_INVALID, "lce_tflite_model_run_section: bad argument");
+  const lce_tflite_section& sec = model->sections[section];
+  std::lock_guard<std::mutex> lock(model->run_mu);
+  std::map<int32_t, Shape> shapes;
+  std::map<int32_t, void*> ptr;
+  for (size_t k = 0; k < sec.inputs.size(); ++k) {
+    if (!inputs_dev[k]) return Fail(LCE_HIP_ERR_INVALID, "lce_tflite_model_run_section: null input pointer");
+    ptr[sec.inputs[k]] = const_cast<void*>(inputs_dev[k]);
+  }
+  for (size_t k = 0; k < sec.outputs.size(); ++k) {
+    if (!outputs_dev[k]) return Fail(LCE_HIP_ERR_INVALID, "lce_tflite_model_run_section: null output pointer");
+    ptr[sec.outputs[k]] = outputs_dev[k];
+  }
+  model->last_run_fused = 0;
+  return WalkSection(model, sec, batch, semantics, &shapes, &ptr, true, stream);
+}
+
+void lce_tflite_model_run_stats(lce_tflite_model* model, int32_t* cached_plans, int32_t* fused_quantize_ops, size_t* scratch_bytes) {
+  if (!model) return;
+  std::lock_guard<std::mutex> lock(model->run_mu);
+  if (cached_plans) *cached_plans = (int32_t)model->plans.size();
+  if (fused_quantize_ops) *fused_quantize_ops = model->last_run_fused;
+  size_t b = 0;
+  for (auto& kv : model->scratch) b += kv.second.bytes;
+  if (scratch_bytes) *scratch_bytes = b;
+}
 
 }  // extern "C"

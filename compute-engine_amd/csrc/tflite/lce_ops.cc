@@ -80,16 +80,19 @@ size_t NumElements(const TfLiteTensor* t) {
 // =====================================================================================
 // Device residency between LCE ops.
 //
-// Every op's output lives in a device buffer keyed by (context, tensor index).  At Prepare time the producing node
-// scans the interpreter's execution plan (TfLiteContext::GetExecutionPlan / GetNodeAndRegistration) for the readers
-// of its output: readers that are LCE ops take the device buffer in their invoke (no upload); if ALL readers are LCE
-// ops -- and there is at least one -- the producer does not copy the tensor back to the arena at all; a tensor with a
-// non-LCE reader, or with no reader (a graph output), is copied back as before.  An interpreter that does not provide
-// the two callbacks (the single-op test driver) gets the old behaviour: every invoke uploads and downloads.
-// Caveat: TfLiteContext does not say which tensors are graph OUTPUTS; a tensor that is a graph output and ALSO feeds
-// an LCE op is indistinguishable from an intermediate and is not copied back.  Converted LCE models never expose a
-// bitpacked / pre-quantize intermediate as an output; set LCE_HIP_TFLITE_RESIDENCY=0 (or call
-// lce_tflite_ops_set_residency(0)) to copy every tensor back regardless.
+// Every op's output lives in a device buffer keyed by (context, tensor index).  Whether the tensor must ALSO travel back
+// to the arena depends on who reads it: LCE readers take the device buffer in their invoke (no upload); only when every
+// reader is an LCE op, there is at least one, and the tensor is not a graph output may the copy-back be skipped.
+//
+// An op cannot find that out by itself: TfLiteContext::GetExecutionPlan / GetNodeAndRegistration are delegate-only (in
+// kernel context TensorFlow Lite points them at a function that reports an error, Subgraph::SwitchToKernelContext), and
+// the context does not say which tensors are graph outputs.  So the HOST declares the graph, once, through the C entry
+// points at the end of this file (lce_tflite_ops_declare_graph_begin / _node / _output / _end; lce_ops_register.h wraps
+// them for a ::tflite::Interpreter as DeclareGraphForDeviceResidency).  Without a declaration -- the default, and all the
+// reference's own callers -- every op leaves its output in the arena exactly as the reference does
+// (tflite/kernels/bconv2d.cc:550-564): nothing can go stale, it just costs the copies.  With one, a tensor that is a
+// graph output is always copied back, also when LCE ops read it too.  LCE_HIP_TFLITE_RESIDENCY=0 (or
+// lce_tflite_ops_set_residency(0)) ignores declarations.  The ops never call the delegate-only callbacks.
 // =====================================================================================
 namespace resident {
 
@@ -98,8 +101,21 @@ struct Entry {
   size_t bytes = 0;       // allocated
   bool valid = false;     // holds the tensor's current value (set by the producer's invoke)
 };
+// Who reads a tensor, from the host's declaration.
+struct Readers {
+  bool known = false;
+  int lce = 0, other = 0;
+  bool graph_output = false;
+  bool keep_on_device() const { return known && lce > 0; }                                     // an LCE reader will pick it up
+  bool needs_host() const { return !known || other > 0 || lce == 0 || graph_output; }          // someone reads the arena
+};
+constexpr int kStagingTensor = -1;       // key of a context's shared staging buffer for inputs no LCE op produced
 std::mutex g_mu;
 std::map<std::pair<const TfLiteContext*, int>, Entry> g_table;
+std::map<const TfLiteContext*, std::map<int, Readers>> g_graphs;     // declared graphs
+std::map<const TfLiteContext*, std::map<int, Readers>> g_pending;    // ... being declared
+std::map<const TfLiteContext*, int> g_nodes;                         // live LCE nodes per context (Init / Free)
+std::atomic<uint64_t> g_version{1};                                  // bumped whenever a declaration changes
 std::atomic<uint64_t> g_h2d{0}, g_d2h{0}, g_h2d_bytes{0}, g_d2h_bytes{0};
 std::atomic<int> g_enabled{-1};   // -1: read LCE_HIP_TFLITE_RESIDENCY on first use
 
@@ -139,41 +155,51 @@ void invalidate(const TfLiteContext* c, int tensor) {
   auto it = g_table.find(std::make_pair(c, tensor));
   if (it != g_table.end()) it->second.valid = false;
 }
-void drop(const TfLiteContext* c, int tensor) {
-  std::lock_guard<std::mutex> lock(g_mu);
+void drop_locked(const TfLiteContext* c, int tensor) {
   auto it = g_table.find(std::make_pair(c, tensor));
   if (it == g_table.end()) return;
   if (it->second.dev) lce_hip_free(it->second.dev);
   g_table.erase(it);
 }
+void drop(const TfLiteContext* c, int tensor) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  drop_locked(c, tensor);
+}
+// A node of this library was created in / removed from `c`.  With the last one go the context's shared staging buffer
+// and its declared graph (an interpreter that is destroyed takes everything it caused with it).
+void node_created(const TfLiteContext* c) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  ++g_nodes[c];
+}
+void node_freed(const TfLiteContext* c) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_nodes.find(c);
+  if (it == g_nodes.end() || --it->second > 0) return;
+  g_nodes.erase(it);
+  drop_locked(c, kStagingTensor);
+  if (g_graphs.erase(c) + g_pending.erase(c)) ++g_version;
+}
 
 bool is_lce_invoke(TfLiteStatus (*fn)(TfLiteContext*, TfLiteNode*));   // defined at the end of this file
 
-// Who reads `tensor`?  known = the interpreter answered; then lce / other count its readers.
-struct Readers {
-  bool known = false;
-  int lce = 0, other = 0;
-  bool keep_on_device() const { return known && lce > 0; }                     // an LCE reader will pick it up
-  bool needs_host() const { return !known || other > 0 || lce == 0; }          // someone reads the arena (or nobody we know of)
-};
-Readers readers_of(TfLiteContext* c, const TfLiteNode* self, int tensor) {
+// Readers of `tensor` as the host declared them; `cache` / `cache_version` belong to the asking node: the table is
+// consulted again only after a declaration changed (no lock, no lookup on the steady-state invoke).
+const Readers& readers_of(const TfLiteContext* c, int tensor, Readers* cache, uint64_t* cache_version) {
+  const uint64_t v = g_version.load(std::memory_order_acquire);
+  if (*cache_version == v) return *cache;
   Readers r;
-  if (!enabled() || !c->GetExecutionPlan || !c->GetNodeAndRegistration) return r;
-  TfLiteIntArray* plan = nullptr;
-  if (c->GetExecutionPlan(c, &plan) != kTfLiteOk || !plan) return r;
-  for (int i = 0; i < plan->size; ++i) {
-    TfLiteNode* node = nullptr;
-    void* reg = nullptr;
-    if (c->GetNodeAndRegistration(c, plan->data[i], &node, &reg) != kTfLiteOk || !node || !reg) return Readers{};
-    if (node == self || !node->inputs) continue;
-    bool reads = false;
-    for (int k = 0; k < node->inputs->size; ++k) reads = reads || node->inputs->data[k] == tensor;
-    if (!reads) continue;
-    if (is_lce_invoke(static_cast<const TfLiteRegistration*>(reg)->invoke)) ++r.lce;
-    else ++r.other;
+  if (enabled()) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto g = g_graphs.find(c);
+    if (g != g_graphs.end()) {
+      auto t = g->second.find(tensor);
+      r = t != g->second.end() ? t->second : Readers{};
+      r.known = true;          // a declared graph in which nobody reads the tensor: lce == 0 -> copied back
+    }
   }
-  r.known = true;
-  return r;
+  *cache = r;
+  *cache_version = v;
+  return *cache;
 }
 
 // a host-in / host-out call that stages its tensors inside the library (lce_hip_bconv2d_run_host)
@@ -185,15 +211,17 @@ void count_host_pass(size_t up_bytes, size_t down_bytes) {
 }
 
 // ---- what an op's invoke does with its tensors ----
-// input: the producer's device copy when there is one, else an upload into a per-tensor staging buffer
+// input: the producer's device copy when there is one, else an upload into the context's ONE staging buffer (grow-only,
+// bounded by the largest such tensor; released with the context's last LCE node).  Uploads, kernels and downloads all
+// run on the null stream, so the next op's upload into the same buffer is ordered behind this op's kernel.
 lce_hip_status input(TfLiteContext* c, int tensor, const void* host, size_t bytes, const void** dev) {
   if (void* cur = current(c, tensor, bytes)) { *dev = cur; return LCE_HIP_OK; }
-  Entry* e = ensure(c, tensor, bytes);
+  Entry* e = ensure(c, kStagingTensor, bytes);
   if (!e) return LCE_HIP_ERR_RUNTIME;
   ++g_h2d;
   g_h2d_bytes += bytes;
   *dev = e->dev;
-  return lce_hip_memcpy_h2d(e->dev, host, bytes, nullptr);   // (not marked valid: the arena may change before the next invoke)
+  return lce_hip_memcpy_h2d(e->dev, host, bytes, nullptr);
 }
 // output: the device buffer the kernel writes ...
 lce_hip_status output(TfLiteContext* c, int tensor, size_t bytes, void** dev) {
@@ -217,6 +245,27 @@ lce_hip_status publish(TfLiteContext* c, int tensor, const Readers& r, void* hos
   }
   return r.needs_host() ? lce_hip_stream_synchronize(nullptr) : LCE_HIP_OK;
 }
+
+// what a node remembers about the tensor it produces
+struct OutputRef {
+  const TfLiteContext* context = nullptr;   // where the node lives (set by init)
+  const TfLiteContext* out_context = nullptr;
+  int tensor = -1;
+  Readers readers;
+  uint64_t readers_version = 0;
+  explicit OutputRef(const TfLiteContext* c) : context(c) { node_created(c); }
+  ~OutputRef() {
+    if (out_context) drop(out_context, tensor);
+    node_freed(context);
+  }
+  void remember(const TfLiteContext* c, int t) {        // Prepare (may run again after a resize)
+    if (out_context) invalidate(out_context, tensor);
+    out_context = c;
+    tensor = t;
+    readers_version = 0;
+  }
+  const Readers& who_reads() { return readers_of(out_context, tensor, &readers, &readers_version); }
+};
 
 }  // namespace resident
 
@@ -243,17 +292,15 @@ struct OpData {  // bconv2d.cc:44-74
   bool successfully_initialized = false;
   bool one_time_setup_complete = false;
   // device residency of the output (namespace resident)
-  const TfLiteContext* out_context = nullptr;
-  int out_tensor = -1;
-  resident::Readers readers;
+  resident::OutputRef out;
+  explicit OpData(const TfLiteContext* c) : out(c) {}
   ~OpData() {
     if (plan) lce_hip_bconv2d_plan_destroy(plan);
-    if (out_context) resident::drop(out_context, out_tensor);
   }
 };
 
 void* Init(TfLiteContext* context, const char* buffer, size_t length) {  // bconv2d.cc:85-131
-  auto* op = new (std::nothrow) OpData{};
+  auto* op = new (std::nothrow) OpData(context);
   if (!op) return nullptr;
   const lce_flex::Map m(reinterpret_cast<const uint8_t*>(buffer), length);
   static const char* const kRequired[] = {"stride_height", "stride_width", "dilation_height_factor",
@@ -398,11 +445,9 @@ TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bconv2d.cc:
   // [B,OH,OW,KH*KW*Cw] here, :250-293).
   // Prepare may run again after a resize: redo the one-time setup (:295-297).
   op->one_time_setup_complete = false;
-  // who reads the output decides whether it has to travel back to the arena
-  if (op->out_context) resident::invalidate(op->out_context, op->out_tensor);
-  op->out_context = context;
-  op->out_tensor = node->outputs->data[0];
-  op->readers = resident::readers_of(context, node, op->out_tensor);
+  // who reads the output decides whether it has to travel back to the arena (asked at invoke: the host may declare the
+  // graph before or after AllocateTensors)
+  op->out.remember(context, node->outputs->data[0]);
   return kTfLiteOk;
 }
 
@@ -432,7 +477,8 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // :550-564
     return kTfLiteError;
   const int in_idx = node->inputs->data[0];
   const bool in_resident = resident::current(context, in_idx, input->bytes) != nullptr;
-  if (!in_resident && !op->readers.keep_on_device()) {
+  const resident::Readers& readers = op->out.who_reads();
+  if (!in_resident && !readers.keep_on_device()) {
     // host in, host out: the pipelined path (batch slices on three streams); counted as one pass in each direction
     resident::count_host_pass(input->bytes, output->bytes);
     LCE_ENSURE_HIP(context, lce_hip_bconv2d_run_host(op->plan, input->data.i32, output->data.data));
@@ -441,9 +487,9 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // :550-564
   const void* in_dev = nullptr;
   void* out_dev = nullptr;
   LCE_ENSURE_HIP(context, resident::input(context, in_idx, input->data.data, input->bytes, &in_dev));
-  LCE_ENSURE_HIP(context, resident::output(context, op->out_tensor, output->bytes, &out_dev));
+  LCE_ENSURE_HIP(context, resident::output(context, op->out.tensor, output->bytes, &out_dev));
   LCE_ENSURE_HIP(context, lce_hip_bconv2d_run(op->plan, (const int32_t*)in_dev, out_dev, nullptr));
-  LCE_ENSURE_HIP(context, resident::publish(context, op->out_tensor, op->readers, output->data.data, output->bytes));
+  LCE_ENSURE_HIP(context, resident::publish(context, op->out.tensor, readers, output->data.data, output->bytes));
   return kTfLiteOk;
 }
 
@@ -478,22 +524,17 @@ namespace {
 
 // The reference's LceQuantize / LceDequantize have no per-node state (init = free = nullptr, quantization.cc:149-159);
 // here a node remembers which tensor it produces so that the tensor's device buffer is released with the node.
-struct OutputRef {
-  const TfLiteContext* context = nullptr;
-  int tensor = -1;
-};
-void* OutputRefInit(TfLiteContext*, const char*, size_t) { return new (std::nothrow) OutputRef{}; }
-void OutputRefFree(TfLiteContext*, void* buffer) {
-  auto* r = reinterpret_cast<OutputRef*>(buffer);
-  if (r && r->context) resident::drop(r->context, r->tensor);
-  delete r;
-}
+using resident::OutputRef;
+void* OutputRefInit(TfLiteContext* context, const char*, size_t) { return new (std::nothrow) OutputRef(context); }
+void OutputRefFree(TfLiteContext*, void* buffer) { delete reinterpret_cast<OutputRef*>(buffer); }
 void RememberOutput(TfLiteContext* context, TfLiteNode* node) {
+  if (auto* r = reinterpret_cast<OutputRef*>(node->user_data)) r->remember(context, node->outputs->data[0]);
+}
+// (a node without user data -- init failed to allocate -- copies back: the safe default)
+const resident::Readers& ReadersOfOutput(TfLiteNode* node) {
+  static const resident::Readers unknown;
   auto* r = reinterpret_cast<OutputRef*>(node->user_data);
-  if (!r) return;
-  if (r->context) resident::invalidate(r->context, r->tensor);
-  r->context = context;
-  r->tensor = node->outputs->data[0];
+  return r && r->out_context ? r->who_reads() : unknown;
 }
 
 TfLiteStatus QuantizePrepare(TfLiteContext* context, TfLiteNode* node) {  // quantization.cc:19-41
@@ -528,7 +569,7 @@ TfLiteStatus QuantizeEval(TfLiteContext* context, TfLiteNode* node) {  // quanti
   const size_t rows = total / cols;
   const size_t out_bytes = rows * (size_t)BitpackedSize((int)cols) * 4;
   const int out_idx = node->outputs->data[0];
-  const resident::Readers readers = resident::readers_of(context, node, out_idx);
+  const resident::Readers& readers = ReadersOfOutput(node);
   const void* in_dev = nullptr;
   void* out_dev = nullptr;
   LCE_ENSURE_HIP(context, resident::input(context, node->inputs->data[0], input->data.data, total * esz, &in_dev));
@@ -569,7 +610,7 @@ TfLiteStatus DequantizeEval(TfLiteContext* context, TfLiteNode* node) {  // quan
   const size_t rows = total / cols;
   const size_t in_bytes = rows * (size_t)BitpackedSize((int)cols) * 4;
   const int out_idx = node->outputs->data[0];
-  const resident::Readers readers = resident::readers_of(context, node, out_idx);
+  const resident::Readers& readers = ReadersOfOutput(node);
   const void* in_dev = nullptr;
   void* out_dev = nullptr;
   LCE_ENSURE_HIP(context, resident::input(context, node->inputs->data[0], input->data.data, in_bytes, &in_dev));
@@ -598,13 +639,12 @@ namespace bmaxpool {
 
 struct PoolParams {  // core/bmaxpool.h:15-22
   int32_t filter_height = 0, filter_width = 0, stride_height = 0, stride_width = 0, padding = 0;
-  const TfLiteContext* out_context = nullptr;   // device residency of the output (namespace resident)
-  int out_tensor = -1;
-  ~PoolParams() { if (out_context) resident::drop(out_context, out_tensor); }
+  resident::OutputRef out;                      // device residency of the output (namespace resident)
+  explicit PoolParams(const TfLiteContext* c) : out(c) {}
 };
 
-void* Init(TfLiteContext*, const char* buffer, size_t length) {  // bmaxpool.cc:20-35
-  auto* p = new (std::nothrow) PoolParams{};
+void* Init(TfLiteContext* context, const char* buffer, size_t length) {  // bmaxpool.cc:20-35
+  auto* p = new (std::nothrow) PoolParams(context);
   if (!p) return nullptr;
   const lce_flex::Map m(reinterpret_cast<const uint8_t*>(buffer), length);
   p->filter_height = m.AsInt32("filter_height");
@@ -639,9 +679,7 @@ TfLiteStatus Prepare(TfLiteContext* context, TfLiteNode* node) {  // bmaxpool.cc
   out->data[1] = oh;
   out->data[2] = ow;
   out->data[3] = SizeOfDimension(input, 3);
-  if (p->out_context) resident::invalidate(p->out_context, p->out_tensor);
-  p->out_context = context;
-  p->out_tensor = node->outputs->data[0];
+  p->out.remember(context, node->outputs->data[0]);
   return context->ResizeTensor(context, output, out);
 }
 
@@ -652,7 +690,7 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // bmaxpool.cc:79
   const size_t in_bytes = NumElements(input) * 4, out_bytes = NumElements(output) * 4;
   if (in_bytes == 0 || out_bytes == 0) return kTfLiteOk;
   const int out_idx = node->outputs->data[0];
-  const resident::Readers readers = resident::readers_of(context, node, out_idx);
+  const resident::Readers& readers = p->out.who_reads();
   const void* in_dev = nullptr;
   void* out_dev = nullptr;
   LCE_ENSURE_HIP(context, resident::input(context, node->inputs->data[0], input->data.data, in_bytes, &in_dev));
@@ -685,10 +723,66 @@ bool is_lce_invoke(TfLiteStatus (*fn)(TfLiteContext*, TfLiteNode*)) {
 }  // namespace tflite
 }  // namespace compute_engine
 
-// Test / tuning hooks of the residency layer (plain C, not part of the reference's interface).
+// Residency: the host's declaration of its graph, and test / tuning hooks (plain C, not part of the reference's
+// interface; declared in lce_ops_register.h).
 extern "C" {
+// Declaring the graph of `context` (the TfLiteContext the ops of that graph are invoked with):
+//   begin; one _node call per node of the execution plan -- its input / output tensor indices (-1 = optional tensor
+//   absent) and its registration's invoke function, by which this library recognises its own ops --; one _output call
+//   per graph output; end.  May be repeated (a new declaration replaces the old one), before or after AllocateTensors.
+void lce_tflite_ops_declare_graph_begin(const TfLiteContext* context) {
+  using namespace compute_engine::tflite::resident;
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_pending[context].clear();
+}
+void lce_tflite_ops_declare_graph_node(const TfLiteContext* context, const int* inputs, int n_inputs, const int* outputs,
+                                       int n_outputs, TfLiteStatus (*invoke)(TfLiteContext*, TfLiteNode*)) {
+  using namespace compute_engine::tflite::resident;
+  (void)outputs; (void)n_outputs;
+  const bool lce = invoke && is_lce_invoke(invoke);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto& g = g_pending[context];
+  for (int i = 0; i < n_inputs; ++i) {
+    if (inputs[i] < 0) continue;
+    bool seen = false;                       // a node that lists a tensor twice reads it once
+    for (int k = 0; k < i; ++k) seen = seen || inputs[k] == inputs[i];
+    if (seen) continue;
+    Readers& r = g[inputs[i]];
+    if (lce) ++r.lce; else ++r.other;
+  }
+}
+void lce_tflite_ops_declare_graph_output(const TfLiteContext* context, int tensor) {
+  using namespace compute_engine::tflite::resident;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (tensor >= 0) g_pending[context][tensor].graph_output = true;
+}
+void lce_tflite_ops_declare_graph_end(const TfLiteContext* context) {
+  using namespace compute_engine::tflite::resident;
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_graphs[context] = std::move(g_pending[context]);
+  g_pending.erase(context);
+  ++g_version;
+}
+// forget the declaration: every op of `context` copies its output back again
+void lce_tflite_ops_forget_graph(const TfLiteContext* context) {
+  using namespace compute_engine::tflite::resident;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_graphs.erase(context) + g_pending.erase(context)) ++g_version;
+}
+// device buffers currently held by the residency layer (all contexts): count and bytes
+void lce_tflite_ops_device_buffers(uint64_t* count, uint64_t* bytes) {
+  using namespace compute_engine::tflite::resident;
+  std::lock_guard<std::mutex> lock(g_mu);
+  uint64_t n = 0, b = 0;
+  for (auto& kv : g_table) if (kv.second.dev) { ++n; b += kv.second.bytes; }
+  if (count) *count = n;
+  if (bytes) *bytes = b;
+}
 // 1 / 0: keep LCE-only intermediates on the device / copy every tensor back (also: LCE_HIP_TFLITE_RESIDENCY=0)
-void lce_tflite_ops_set_residency(int on) { compute_engine::tflite::resident::g_enabled.store(on ? 1 : 0); }
+void lce_tflite_ops_set_residency(int on) {
+  compute_engine::tflite::resident::g_enabled.store(on ? 1 : 0);
+  ++compute_engine::tflite::resident::g_version;
+}
 // host -> device and device -> host tensor copies made by the ops' invokes since the last reset
 void lce_tflite_ops_transfer_counts(uint64_t* h2d, uint64_t* d2h, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset) {
   using namespace compute_engine::tflite::resident;

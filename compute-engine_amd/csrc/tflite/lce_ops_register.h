@@ -57,4 +57,42 @@ inline void RegisterLCECustomOps(Resolver* resolver, const bool use_reference_bc
 }  // namespace tflite
 }  // namespace compute_engine
 
+// ---- device residency between LCE ops (an extension; the reference has no counterpart) ----
+// By default every op leaves its output in the interpreter's arena, exactly as the reference's kernels do
+// (tflite/kernels/bconv2d.cc:550-564).  A host that DECLARES its graph lets tensors that only LCE ops read -- and that
+// are not graph outputs -- stay in HBM between them: a binary section then crosses PCIe once in each direction.  The
+// ops cannot find this out themselves (TfLiteContext::GetExecutionPlan / GetNodeAndRegistration are delegate-only).
+extern "C" {
+void lce_tflite_ops_declare_graph_begin(const TfLiteContext* context);
+void lce_tflite_ops_declare_graph_node(const TfLiteContext* context, const int* inputs, int n_inputs, const int* outputs,
+                                       int n_outputs, TfLiteStatus (*invoke)(TfLiteContext*, TfLiteNode*));
+void lce_tflite_ops_declare_graph_output(const TfLiteContext* context, int tensor);
+void lce_tflite_ops_declare_graph_end(const TfLiteContext* context);
+void lce_tflite_ops_forget_graph(const TfLiteContext* context);
+void lce_tflite_ops_set_residency(int on);
+}
+
+#ifdef LCE_USE_SYSTEM_TFLITE
+#include "tensorflow/lite/interpreter.h"
+namespace compute_engine {
+namespace tflite {
+// Call once after building the interpreter (before or after AllocateTensors; again after ModifyGraphWithDelegate or any
+// other change of the execution plan).  Walks the primary subgraph from APPLICATION code, where that is legal.
+inline void DeclareGraphForDeviceResidency(::tflite::Interpreter* interpreter) {
+  const TfLiteContext* context = interpreter->primary_subgraph().context();
+  lce_tflite_ops_declare_graph_begin(context);
+  for (int node_index : interpreter->execution_plan()) {
+    const auto* nr = interpreter->node_and_registration(node_index);
+    if (!nr) continue;
+    const TfLiteNode& node = nr->first;
+    lce_tflite_ops_declare_graph_node(context, node.inputs->data, node.inputs->size, node.outputs->data,
+                                      node.outputs->size, nr->second.invoke);
+  }
+  for (int t : interpreter->outputs()) lce_tflite_ops_declare_graph_output(context, t);
+  lce_tflite_ops_declare_graph_end(context);
+}
+}  // namespace tflite
+}  // namespace compute_engine
+#endif
+
 #endif  // COMPUTE_ENGINE_AMD_TFLITE_LCE_OPS_REGISTER_H_

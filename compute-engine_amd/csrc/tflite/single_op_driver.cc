@@ -68,7 +68,6 @@ struct Model {
     std::string options;
   };
   std::vector<Extra*> extra;
-  TfLiteIntArray* plan = nullptr;
 
   static Model* self(TfLiteContext* c) { return (Model*)c->impl_; }
 
@@ -101,23 +100,15 @@ struct Model {
     return kTfLiteOk;
   }
 
-  static TfLiteStatus ExecutionPlan(TfLiteContext* c, TfLiteIntArray** out) {
-    Model* m = self(c);
-    const int n = (m->reg ? 1 : 0) + (int)m->extra.size();
-    TfLiteIntArrayFree(m->plan);
-    m->plan = TfLiteIntArrayCreate(n);
-    for (int i = 0; i < n; ++i) m->plan->data[i] = i;
-    *out = m->plan;
-    return kTfLiteOk;
+  // What TensorFlow Lite installs for these two callbacks while kernels run (Subgraph::SwitchToKernelContext ->
+  // ForbiddenContextFunction): an error report and kTfLiteError.  The ops must never call them; a test greps the log.
+  static TfLiteStatus ForbiddenPlan(TfLiteContext* c, TfLiteIntArray**) {
+    self(c)->log += "The function is forbidden if not calling in delegate.\n";
+    return kTfLiteError;
   }
-  static TfLiteStatus NodeAndRegistration(TfLiteContext* c, int idx, TfLiteNode** node, void** reg) {
-    Model* m = self(c);
-    if (idx == 0 && m->reg) { *node = &m->node; *reg = (void*)m->reg; return kTfLiteOk; }
-    const int k = idx - (m->reg ? 1 : 0);
-    if (k < 0 || k >= (int)m->extra.size()) return kTfLiteError;
-    *node = &m->extra[k]->node;
-    *reg = (void*)m->extra[k]->reg;
-    return kTfLiteOk;
+  static TfLiteStatus ForbiddenNode(TfLiteContext* c, int, TfLiteNode**, void**) {
+    self(c)->log += "The function is forbidden if not calling in delegate.\n";
+    return kTfLiteError;
   }
 
   Model() {
@@ -129,10 +120,8 @@ struct Model {
     ctx.ReportError = Report;
     ctx.AddTensors = AddTensors;
     ctx.recommended_num_threads = 1;
-  }
-  void enable_plan() {          // chains only: the single-op tests keep an interpreter that answers no questions
-    ctx.GetExecutionPlan = ExecutionPlan;
-    ctx.GetNodeAndRegistration = NodeAndRegistration;
+    ctx.GetExecutionPlan = ForbiddenPlan;
+    ctx.GetNodeAndRegistration = ForbiddenNode;
   }
   ~Model() {
     if (reg && reg->free && inited) reg->free(&ctx, node.user_data);
@@ -143,7 +132,6 @@ struct Model {
       TfLiteIntArrayFree(e->node.temporaries);
       delete e;
     }
-    TfLiteIntArrayFree(plan);
     for (auto& t : tensors) TfLiteIntArrayFree(t.dims);
     TfLiteIntArrayFree(node.inputs);
     TfLiteIntArrayFree(node.outputs);
@@ -214,11 +202,21 @@ const TfLiteRegistration* find_registration(const char* op_name, int variant, in
 extern "C" {
 
 // ---- chains: an empty model, nodes added in execution order, an execution plan the ops may inspect ----
-void* lce_driver_create_chain(void) {
-  Model* m = new Model();
-  m->enable_plan();
-  return m;
+void* lce_driver_create_chain(void) { return new Model(); }
+// What an application does once with its interpreter (lce_ops_register.h, DeclareGraphForDeviceResidency): tell the ops
+// who reads which tensor and which tensors are graph outputs.
+void lce_driver_declare_graph(void* h, const int* graph_outputs, int n_outputs) {
+  Model* m = (Model*)h;
+  lce_tflite_ops_declare_graph_begin(&m->ctx);
+  if (m->reg) lce_tflite_ops_declare_graph_node(&m->ctx, m->node.inputs->data, m->node.inputs->size, m->node.outputs->data,
+                                                m->node.outputs->size, m->reg->invoke);
+  for (Model::Extra* e : m->extra)
+    lce_tflite_ops_declare_graph_node(&m->ctx, e->node.inputs->data, e->node.inputs->size, e->node.outputs->data,
+                                      e->node.outputs->size, e->reg->invoke);
+  for (int i = 0; i < n_outputs; ++i) lce_tflite_ops_declare_graph_output(&m->ctx, graph_outputs[i]);
+  lce_tflite_ops_declare_graph_end(&m->ctx);
 }
+void lce_driver_forget_graph(void* h) { lce_tflite_ops_forget_graph(&((Model*)h)->ctx); }
 // returns the node's index in the execution plan, or -1
 int lce_driver_add_node(void* h, const char* op_name, int variant, int use_resolver, const int* inputs, int n_in,
                         const int* outputs, int n_out, const char* options, size_t options_len) {

@@ -86,6 +86,12 @@ def tflite_lib() -> C.CDLL:
         l.lce_tflite_model_last_error.restype = C.c_char_p
         l.lce_tflite_model_num_sections.argtypes = [C.c_void_p]
         l.lce_tflite_model_section.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_SectionInfo)]
+        l.lce_tflite_model_run_section.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                                   C.POINTER(C.c_void_p), C.c_void_p]
+        l.lce_tflite_model_run_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+        l.lce_tflite_model_run_stats.restype = None
+        l.lce_tflite_model_section_tensor_shape.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                            C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         _tfl = l
     return _tfl
 
@@ -153,6 +159,30 @@ class LceModel:
 
     __del__ = close
 
+    def _check(self, rc: int):
+        if rc:
+            msg = tflite_lib().lce_tflite_model_last_error().decode() or _amd.lib().lce_hip_last_error().decode()
+            raise _amd.LceHipError(rc, msg)
+
+    def section_tensor_shape(self, section: int, tensor: int, batch: int, semantics: int = _amd.SEM_OPTIMIZED):
+        """([N, H, W, C], bytes) of a tensor the section reads or produces at ``batch`` images (C in words when bitpacked)."""
+        dims, nbytes = (C.c_int32 * 4)(), C.c_size_t()
+        self._check(tflite_lib().lce_tflite_model_section_tensor_shape(self._h, section, tensor, batch, semantics, dims, C.byref(nbytes)))
+        return tuple(dims), int(nbytes.value)
+
+    def run_section(self, section: int, batch: int, inputs_dev: Sequence[int], outputs_dev: Sequence[int], stream: int = 0,
+                    semantics: int = _amd.SEM_OPTIMIZED):
+        """``lce_tflite_model_run_section`` (include/lce_tflite_model.h) on raw device pointers."""
+        i = (C.c_void_p * max(1, len(inputs_dev)))(*inputs_dev)
+        o = (C.c_void_p * max(1, len(outputs_dev)))(*outputs_dev)
+        self._check(tflite_lib().lce_tflite_model_run_section(self._h, section, batch, semantics, i, o, C.c_void_p(stream)))
+
+    def run_stats(self):
+        """(plans cached in the model, LceQuantize ops the last run folded into a convolution, bytes of intermediates)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_size_t()
+        tflite_lib().lce_tflite_model_run_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
     def bconv2d_plan(self, op_index: int, batch: int, semantics: int = _amd.SEM_OPTIMIZED) -> "_amd.Bconv2dPlan":
         """A ready plan (weights set) for LceBconv2d operator ``op_index`` at the given batch size."""
         h = C.c_void_p()
@@ -177,8 +207,6 @@ class Interpreter:
         self._sem = _amd.SEM_REFERENCE if use_reference_bconv else _amd.SEM_OPTIMIZED
         self._foreign = [(i, op) for i, op in enumerate(self.model.operators)
                          if op.builtin_code != 32 or op.custom_code not in LCE_OPS]
-        self._plans = {}   # (operator index, batch) -> Bconv2dPlan
-        self._fused = None  # LceBconv2d operator index -> LceQuantize consumers of its output (see _quantize_consumers)
 
     @property
     def sections(self) -> List[Section]:
@@ -234,59 +262,31 @@ class Interpreter:
     def output_zero_points(self):
         return [t.zero_point for t in self._props(self.model.outputs)]
 
-    # ---- execution ------------------------------------------------------------------------------
-    def _plan(self, op_index: int, batch: int):
-        key = (op_index, batch)
-        if key not in self._plans:
-            self._plans[key] = self.model.bconv2d_plan(op_index, batch, self._sem)
-        return self._plans[key]
-
-    def _quantize_consumers(self):
-        """op index of an LceBconv2d with a float / int8 output -> the LceQuantize ops OF THE SAME SECTION that read that
-        output: the convolution's epilogue writes their result as its second output (lce_hip_bconv2d_run_dual)."""
-        if self._fused is None:
-            ops = self.model.operators
-            self._fused = {}
-            for sec in self.model.sections:
-                for i in sec.ops:
-                    op = ops[i]
-                    if op.custom_code != "LceBconv2d" or self.model.tensors[op.outputs[0]].type not in (FLOAT32, INT8):
-                        continue
-                    js = [j for j in sec.ops if j > i and ops[j].custom_code == "LceQuantize" and ops[j].inputs[0] == op.outputs[0]]
-                    if js:
-                        self._fused[i] = js
-        return self._fused
-
-    def _run_ops(self, live, batch, op_indices=None, wanted=None):
-        """Runs operators `op_indices` (default: the whole graph) on device tensors; `live` maps tensor index -> CUDA
-        tensor and must hold every non-constant tensor they read from outside; returns the tensors `wanted`
-        (default: the graph outputs)."""
+    # ---- execution: the C entry lce_tflite_model_run_section does the work (plans cached per batch size in the model,
+    # LceBconv2d + LceQuantize fused through run_dual, intermediates in buffers the model owns) -------------------------
+    def _run_section_device(self, index: int, live, batch: int, wanted=None):
+        """Section `index` on CUDA tensors: `live` maps tensor index -> tensor for every entry of ``sections[index].inputs``;
+        returns the tensors `wanted` (default: the section's outputs) as new CUDA tensors.  Asynchronous on the current
+        torch stream."""
         import torch
-        fused, done = self._quantize_consumers(), set()
-        for i in (range(len(self.model.operators)) if op_indices is None else op_indices):
-            op = self.model.operators[i]
-            if i in done:
-                continue
-            x = live[op.inputs[0]]
-            out_t = self.model.tensors[op.outputs[0]]
-            if i in fused:                           # LceBconv2d + the LceQuantize of its output, one pass
-                y, bits = self._plan(i, batch).run_dual(x)
-                for j in fused[i]:
-                    live[self.model.operators[j].outputs[0]] = bits
-                    done.add(j)
-            elif op.custom_code == "LceQuantize":    # quantization.cc:76-114
-                in_t = self.model.tensors[op.inputs[0]]
-                y = _amd.bitpack(x, in_t.zero_point if x.dtype == torch.int8 else 0)
-            elif op.custom_code == "LceDequantize":  # quantization.cc:116-147
-                dt = {FLOAT32: torch.float32, INT8: torch.int8, BOOL: torch.bool}[out_t.type]
-                y = _amd.unpack(x, out_t.shape[-1], dt, out_t.scale or 1.0, out_t.zero_point or 0)
-            elif op.custom_code == "LceBMaxPool2d":  # bmaxpool.cc:20-98
-                y = _amd.bmaxpool(x, op.option("filter_height"), op.option("filter_width"), op.option("stride_height"),
-                                  op.option("stride_width"), op.option("padding"))
-            else:
-                y = self._plan(i, batch).run(x)
-            live[op.outputs[0]] = y
-        return [live[o] for o in (self.model.outputs if wanted is None else wanted)]
+        sec = self.model.sections[index]
+        dt = {FLOAT32: torch.float32, INT32: torch.int32, BOOL: torch.bool, INT8: torch.int8}
+        outs = []
+        for t in sec.outputs:
+            dims, _ = self.model.section_tensor_shape(index, t, batch, self._sem)
+            outs.append(torch.empty(dims, dtype=dt[self.model.tensors[t].type], device=self.device))
+        ins = [live[t].contiguous() for t in sec.inputs]
+        with torch.cuda.device(torch.device(self.device)):
+            stream = torch.cuda.current_stream().cuda_stream
+            self.model.run_section(index, batch, [x.data_ptr() for x in ins], [y.data_ptr() for y in outs], stream, self._sem)
+            for x in ins:                                    # (the launches read them after this call returns)
+                x.record_stream(torch.cuda.current_stream())
+        by_index = dict(zip(sec.outputs, outs))
+        return [by_index[t] for t in (sec.outputs if wanted is None else wanted)]
+
+    def _run_ops(self, live, batch):
+        """The whole graph (LCE ops only: ONE section) on device tensors; returns the graph outputs."""
+        return self._run_section_device(0, live, batch, self.model.outputs)
 
     def run_section(self, index: int, inputs: Union[Sequence[np.ndarray], Dict[int, np.ndarray]]):
         """Runs binary section `index` of a (mixed) graph on its boundary tensors: `inputs` = one array per entry of
@@ -311,7 +311,7 @@ class Interpreter:
         batch = arrs[0].shape[0]
         if any(a.shape[0] != batch for a in arrs):
             raise ValueError("all inputs of a section share the batch dimension")
-        return [y.cpu().numpy() for y in self._run_ops(live, batch, sec.ops, sec.outputs)]
+        return [y.cpu().numpy() for y in self._run_section_device(index, live, batch)]
 
     def _run_batch(self, inputs):
         """One batch, synchronously (kept for callers that drive batches themselves)."""

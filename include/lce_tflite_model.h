@@ -63,9 +63,12 @@ lce_hip_status lce_tflite_model_operator(const lce_tflite_model* model, int32_t 
 
 /* Binary SECTIONS of a mixed graph.  A converted model interleaves builtin float operators (the stem, batch norms, adds,
  * the head) with LCE custom ops; what this library runs are the maximal groups of LCE ops that can execute without a
- * builtin operator in between -- the partition a TFLite delegate would be handed (the operators are walked in the file's
- * execution order; an LCE op joins the current section when every tensor it reads is a constant, a graph input, or was
- * produced before or inside this section; the first op that is not LCE and cannot wait closes it).  The reference runs whole
+ * builtin operator in between -- the partition a TFLite delegate would be handed (TensorFlow Lite's
+ * PartitionGraphIntoIndependentNodeSubsets, restated): epochs alternate between LCE operators and all others, starting
+ * with LCE; in an epoch EVERY operator of the epoch's kind whose inputs are all ready joins -- wherever it stands in the
+ * file -- repeatedly, until none is left; the LCE operators of one epoch, sorted by index, are one section.  On a chain
+ * that is "cut at every builtin operator"; on a branched graph an LCE op further down the file belongs to an earlier
+ * section when nothing it reads depends on a builtin operator in between.  The reference runs whole
  * graphs through one interpreter (tflite/python/interpreter_base.py:74-95, examples/lce_minimal.cc:28-62); a host that
  * keeps TensorFlow Lite for the float operators calls a section between them: feed `inputs`, collect `outputs`.
  *   ops     : operator indices of the section, in execution order
@@ -82,6 +85,30 @@ typedef struct lce_tflite_section_info {
 } lce_tflite_section_info;
 int32_t lce_tflite_model_num_sections(const lce_tflite_model* model);
 lce_hip_status lce_tflite_model_section(const lce_tflite_model* model, int32_t index, lce_tflite_section_info* info);
+
+/* Runs section `section` on DEVICE tensors at `batch` images per tensor (the file's own leading dimension, which the
+ * converter pins to 1, is replaced): the C entry for a host without a TensorFlow Lite interpreter -- what
+ * examples/lce_minimal.cc:28-62 / tflite/benchmark/lce_benchmark_main.cc:24-48 do with Interpreter::Invoke, for the
+ * binary part of the graph -- and what compute-engine_amd/model_runner.py calls.
+ *   inputs_dev[k]  : device pointer of tensor section.inputs[k]  ([batch, H, W, C] in the file's type)
+ *   outputs_dev[k] : device buffer for tensor section.outputs[k] (lce_tflite_model_section_tensor_shape says how large)
+ * Everything in between stays in device buffers the MODEL owns (grow-only, reused by the next call); plans are made
+ * once per (operator, batch, semantics) and cached in the model; an LceBconv2d whose float / int8 output feeds an
+ * LceQuantize of the same section writes both tensors from one epilogue (lce_hip_bconv2d_run_dual), the quantize launch
+ * disappears.  Asynchronous on `stream` (a hipStream_t, or NULL); calls on one model are serialised by a mutex and must
+ * use one stream at a time.  `semantics`: lce_hip_semantics (which registration's SAME-zero behaviour).  Shape inference
+ * is the ops' own Prepare (quantization.cc:19-41, bmaxpool.cc:41-77, bconv2d.cc:137-300). */
+lce_hip_status lce_tflite_model_run_section(lce_tflite_model* model, int32_t section, int32_t batch, int32_t semantics,
+                                            const void* const* inputs_dev, void* const* outputs_dev, void* stream);
+/* Shape ([N,H,W,C], C in words for bitpacked tensors) and size in bytes of a tensor section `section` reads or produces,
+ * at `batch` images.  Host-only (no device needed). */
+lce_hip_status lce_tflite_model_section_tensor_shape(lce_tflite_model* model, int32_t section, int32_t tensor, int32_t batch,
+                                                     int32_t semantics, int32_t dims[4], size_t* bytes);
+
+/* What the model holds for lce_tflite_model_run_section: plans cached so far (one per operator x batch size x semantics),
+ * LceQuantize launches the LAST run folded into a convolution's epilogue, bytes of intermediate buffers.  Any pointer may
+ * be NULL. */
+void lce_tflite_model_run_stats(lce_tflite_model* model, int32_t* cached_plans, int32_t* fused_quantize_ops, size_t* scratch_bytes);
 
 /* Builds a ready-to-run plan for operator `index`, which must be an LceBconv2d: descriptor
  * from the op's option map + tensor shapes / types / output quantization exactly as

@@ -28,10 +28,13 @@ def test_interpreter_predict_matches_oracle_in_true_batches():
     got_i8, got_deq = it.predict(x)
     assert got_i8.shape == want_i8.shape and np.array_equal(got_i8, want_i8)
     assert np.array_equal(got_deq, want_deq)
-    # the float LceBconv2d and the LceQuantize of its output ran as ONE pass (second output of the epilogue)
-    assert it._quantize_consumers() == {1: [2]}
-    # plans were made once per distinct batch size: 16 and the ragged 5
-    assert sorted({b for (_, b) in it._plans}) == [5, 16]
+    # the float LceBconv2d and the LceQuantize of its output ran as ONE pass (second output of the epilogue); plans were
+    # made once per convolution and distinct batch size (16 and the ragged 5) and live in the model
+    n_convs = sum(op.custom_code == "LceBconv2d" for op in it.model.operators)
+    plans, fused, scratch = it.model.run_stats()
+    assert fused == 1 and plans == 2 * n_convs and scratch > 0
+    it.predict(x)
+    assert it.model.run_stats()[0] == plans
     # the reference's contract (interpreter_base.py:74-95): sample by sample gives the same answer
     one = mr.Interpreter(data, batch_size=1)
     a, b = one.predict(x[:3])
@@ -94,3 +97,46 @@ def test_binary_sections_of_a_mixed_graph_run_on_their_boundary_tensors():
         it.run_section(2, [r1, r1])
     with pytest.raises(ValueError, match="has shape"):
         it.run_section(2, [r1[:, :5]])
+
+
+def test_run_section_through_the_c_abi_alone():
+    """lce_tflite_model_run_section as a C host calls it: device memory from lce_hip_malloc, copies through lce_hip_memcpy_*,
+    no torch anywhere -- the route of examples/lce_minimal.cc:28-62 for the binary part of a graph -- against the oracle
+    run op by op, at two batch sizes on one model (plans cached per batch)."""
+    import ctypes as C
+    data, p = small_model(24)
+    model = mr.LceModel(data)
+    assert len(model.sections) == 1
+    sec = model.sections[0]
+    lib = amd.lib()
+    for n in (6, 3):
+        x = synth.rng(30 + n).uniform(-1.5, 1.5, (n, 12, 12, 64)).astype(np.float32)
+        want = dict(zip(model.outputs, oracle_forward(x, p)))
+        ins, outs, host = [], [], []
+        for t in sec.inputs:
+            dims, nbytes = model.section_tensor_shape(0, t, n)
+            assert dims == x.shape and nbytes == x.nbytes
+            d = C.c_void_p()
+            amd.check(lib.lce_hip_malloc(C.byref(d), C.c_size_t(nbytes)))
+            amd.check(lib.lce_hip_memcpy_h2d(d, x.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), None))
+            ins.append(d.value)
+        for t in sec.outputs:
+            dims, nbytes = model.section_tensor_shape(0, t, n)
+            d = C.c_void_p()
+            amd.check(lib.lce_hip_malloc(C.byref(d), C.c_size_t(nbytes)))
+            outs.append(d.value)
+            host.append(np.empty(dims, mr._NP[model.tensors[t].type]))
+            assert host[-1].nbytes == nbytes
+        model.run_section(0, n, ins, outs)
+        for t, d, h in zip(sec.outputs, outs, host):
+            amd.check(lib.lce_hip_memcpy_d2h(h.ctypes.data_as(C.c_void_p), C.c_void_p(d), C.c_size_t(h.nbytes), None))
+        amd.check(lib.lce_hip_stream_synchronize(None))
+        for t, h in zip(sec.outputs, host):
+            assert np.array_equal(h.view(np.uint8), want[t].view(np.uint8)), (n, t)
+        for d in ins + outs:
+            amd.check(lib.lce_hip_free(C.c_void_p(d)))
+    assert model.run_stats()[1] == 1                      # the float convolution + its LceQuantize: one launch
+    with pytest.raises(amd.LceHipError):
+        model.run_section(5, 1, [0], [0])
+    with pytest.raises(amd.LceHipError):
+        model.run_section(0, 1, [0] * len(sec.inputs), outs)     # null input pointer

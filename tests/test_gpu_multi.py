@@ -195,6 +195,9 @@ def test_bench_on_every_gpu_of_the_node_over_rccl():
     assert r["n_gpus"] == n and r["rccl_world_size"] == n and len(r["per_rank_ms_per_step"]) == n
     assert r["config"]["global_batch"] == 256 * n and r["scaling"] == "weak"
     assert abs(r["value"] - n * r["per_gpu_value"]) < 1e-6 * r["value"]          # whole-job value = sum over ranks
+    chk = r["multi_gpu_self_check"]                                              # the line proves what it came from
+    assert chk["distinct_devices"] == n and chk["sharded_equals_single_gpu_on_every_rank"] and chk["rccl_version"]
+    assert sorted(d["rank"] for d in chk["devices"]) == list(range(n)) and len({d["uuid"] for d in chk["devices"]}) == n
     # BASELINE config 4 as stated: 2048 images over the node (on fewer than 8 GPUs: the same per-GPU share)
     r = _bench("--gpus", str(n), "--global-batch", str(256 * n))
     assert r["scaling"] == "strong" and r["config"]["global_batch"] == 256 * n and r["rccl_world_size"] == n
@@ -212,3 +215,6 @@ def test_bench_multi_rank_path_with_two_ranks_sharing_one_gpu():
     assert c4["global_batch"] == 512 and len(c4["per_rank_chain_ms"]) == 2 and c4["chain_ms"] >= max(c4["per_rank_chain_ms"]) - 1e-9
     assert abs(c4["images_per_s"] - 512 / (c4["chain_ms"] * 1e-3)) < 1e-6 * c4["images_per_s"]
     assert "extra" not in r and "cpu_baseline" not in r      # N = 1 only
+    chk = r["multi_gpu_self_check"]       # the sharded run was reassembled and compared on both ranks before anything was timed
+    assert chk["sharded_equals_single_gpu_on_every_rank"] and chk["distinct_devices"] == 1 and len(chk["devices"]) == 2
+    assert {d["rank"] for d in chk["devices"]} == {0, 1} and len({d["pid"] for d in chk["devices"]}) == 2

@@ -145,11 +145,12 @@ def _binary_section(m, b=3, h=12, w_=10, c0=64, c1=96, c2=64, host_reader=False,
 def test_a_binary_section_crosses_pcie_once_in_each_direction():
     """LceQuantize -> LceBconv2d -> LceBMaxPool2d -> LceBconv2d through RegisterLCECustomOps: tensors that only LCE ops read
     stay in HBM (the reference hands them over in the arena, bconv2d.cc:550-564, quantization.cc:76-114, bmaxpool.cc:79-91),
-    so one invoke makes exactly ONE upload (the float input) and ONE download (the float output), bit-equal to the oracle --
-    also for a second invoke with new input data."""
+    so, once the host has declared its graph (lce_ops_register.h), one invoke makes exactly ONE upload (the float input)
+    and ONE download (the float output), bit-equal to the oracle -- also for a second invoke with new input data."""
     m = T.ChainModel()
     t_x, t_y, t_c1, _, x, reference = _binary_section(m)
     T.set_residency(True)
+    m.declare_graph([t_y])
     assert m.prepare() == 0, m.log
     for k in range(2):
         xin = x if k == 0 else (x[::-1] * -1.0).copy()
@@ -162,12 +163,83 @@ def test_a_binary_section_crosses_pcie_once_in_each_direction():
         assert np.array_equal(got.view(np.int32), want.view(np.int32))
         assert (up, down) == (1, 1), (up, down)
         assert up_bytes == xin.nbytes and down_bytes == want.nbytes
+    assert "forbidden" not in m.log                      # the ops never call the delegate-only context functions
+
+
+def test_without_a_declared_graph_every_output_is_in_the_arena():
+    """The default (and every caller of the reference): no declaration -> each op copies its output back, as the reference's
+    kernels leave theirs in the arena (bconv2d.cc:550-564).  Nothing can be stale; the ops ask the context nothing.
+    Declaring the graph AFTER AllocateTensors switches residency on from the next invoke; forgetting it switches it off."""
+    m = T.ChainModel()
+    t_x, t_y, t_c1, _, x, reference = _binary_section(m)
+    T.set_residency(True)
+    assert m.prepare() == 0, m.log
+    m.set_data(t_x, x)
+    c1, want = reference(x)
+    for declared, expect in ((False, (4, 4)), (True, (1, 1)), (False, (4, 4))):
+        if declared:
+            m.declare_graph([t_y])
+        else:
+            m.forget_graph()
+        m.set_data(t_c1, np.full(m.shape(t_c1), 0x5A5A5A5A, np.int32) if m.shape(t_c1)[0] else np.zeros(m.shape(t_c1), np.int32))
+        T.transfer_counts(reset=True)
+        assert m.invoke() == 0, m.log
+        up, down, _, _ = T.transfer_counts()
+        assert np.array_equal(m.get(t_y).view(np.int32), want.view(np.int32))
+        if not declared:
+            assert np.array_equal(m.get(t_c1), c1)                 # the arena copy is current
+        assert (up, down) == expect, (declared, up, down)
+    assert "forbidden" not in m.log
+
+
+def test_a_graph_output_that_also_feeds_an_lce_op_is_copied_back():
+    """The case the round-3 layer got wrong: the first convolution's bitpacked output is BOTH a graph output and the
+    pooling op's input.  Declared as an output it is downloaded (one more copy) and the LCE reader still takes the device
+    buffer (no extra upload)."""
+    m = T.ChainModel()
+    t_x, t_y, t_c1, _, x, reference = _binary_section(m)
+    T.set_residency(True)
+    m.declare_graph([t_y, t_c1])
+    assert m.prepare() == 0, m.log
+    m.set_data(t_x, x)
+    m.set_data(t_c1, np.full(m.shape(t_c1), 0x5A5A5A5A, np.int32))          # poison the arena copy
+    T.transfer_counts(reset=True)
+    assert m.invoke() == 0, m.log
+    up, down, _, _ = T.transfer_counts()
+    c1, want = reference(x)
+    assert np.array_equal(m.get(t_c1), c1)
+    assert np.array_equal(m.get(t_y).view(np.int32), want.view(np.int32))
+    assert (up, down) == (1, 2), (up, down)
+
+
+def test_device_buffers_are_bounded_and_die_with_the_interpreter():
+    """One device buffer per tensor an LCE op produces + ONE shared staging buffer per context for inputs no LCE op
+    produced (round 3 kept one per such tensor, forever); all of them are released with the interpreter's nodes."""
+    n0, _ = T.device_buffers()
+    m = T.ChainModel()
+    t_x, t_y, t_c1, _, x, reference = _binary_section(m)
+    T.set_residency(False)                               # every op stages its input: the worst case for staging buffers
+    try:
+        assert m.prepare() == 0, m.log
+        m.set_data(t_x, x)
+        for _ in range(3):
+            assert m.invoke() == 0, m.log
+        n1, bytes1 = T.device_buffers()
+        # LceQuantize and LceBMaxPool2d each hold their output's buffer and share the staging buffer (the convolutions ran
+        # host to host inside lce_hip_bconv2d_run_host)
+        assert n1 - n0 == 3, (n0, n1)
+        assert bytes1 <= 4 * x.nbytes
+    finally:
+        T.set_residency(True)
+    m.close()
+    assert T.device_buffers()[0] == n0
 
 
 def test_a_tensor_with_a_host_reader_is_still_copied_back():
     m = T.ChainModel()
     t_x, t_y, t_c1, t_copy, x, reference = _binary_section(m, host_reader=True)
     T.set_residency(True)
+    m.declare_graph([t_y, t_copy])
     assert m.prepare() == 0, m.log
     m.set_data(t_x, x)
     T.transfer_counts(reset=True)
@@ -183,6 +255,7 @@ def test_residency_can_be_switched_off():
     m = T.ChainModel()
     t_x, t_y, t_c1, _, x, reference = _binary_section(m)
     T.set_residency(False)
+    m.declare_graph([t_y])                               # (a declaration is ignored while residency is off)
     try:
         assert m.prepare() == 0, m.log
         m.set_data(t_x, x)

@@ -295,3 +295,51 @@ def test_section_partition_terminates_on_a_cyclic_graph():
     b.custom_op("LceBMaxPool2d", [t0], [t1], flexbuf.bmaxpool_options(1, 1, 1, 1, O.PADDING_VALID))
     m = mr.LceModel(b.finish())
     assert m.sections == []
+
+
+def test_section_shapes_at_any_batch_without_a_device_and_run_fails_loudly_without_one():
+    """lce_tflite_model_section_tensor_shape is the ops' own shape inference (quantization.cc:19-41, bmaxpool.cc:41-77,
+    bconv2d.cc:137-300) at a caller-chosen batch, host-only; lce_tflite_model_run_section has no CPU fallback."""
+    data, p = small_model(40)
+    m = mr.LceModel(data)
+    sec = m.sections[0]
+    assert sec.inputs == m.inputs and sorted(sec.outputs) == sorted(m.outputs)
+    oh = p["s2"].out_h
+    by_name = {t.name: i for i, t in enumerate(m.tensors)}
+    for n in (1, 7):
+        assert m.section_tensor_shape(0, by_name["input"], n) == ((n, 12, 12, 64), n * 12 * 12 * 64 * 4)
+        assert m.section_tensor_shape(0, by_name["q1"], n) == ((n, 12, 12, 2), n * 12 * 12 * 2 * 4)
+        assert m.section_tensor_shape(0, by_name["y1"], n) == ((n, 12, 12, 96), n * 12 * 12 * 96 * 4)
+        assert m.section_tensor_shape(0, by_name["q2"], n)[0] == (n, 12, 12, 3)
+        assert m.section_tensor_shape(0, by_name["y2"], n)[0] == (n, oh, oh, 2)
+        assert m.section_tensor_shape(0, by_name["pooled"], n)[0] == (n, oh // 2, oh // 2, 2)
+        assert m.section_tensor_shape(0, by_name["y3"], n) == ((n, oh // 2, oh // 2, 33), n * (oh // 2) ** 2 * 33)
+        assert m.section_tensor_shape(0, by_name["dequantized"], n)[0] == (n, oh // 2, oh // 2, 40)
+    assert m.run_stats()[0] == 6                       # three convolutions x two batch sizes, planned on the host
+    with pytest.raises(amd.LceHipError):
+        m.section_tensor_shape(0, by_name["w1"], 1)    # a constant: not a tensor the section computes or is fed
+    with pytest.raises(amd.LceHipError):
+        m.section_tensor_shape(3, 0, 1)
+    if amd.device_count() == 0:
+        with pytest.raises(amd.LceHipError, match="no CPU fallback"):
+            m.run_section(0, 1, [8], [8, 8])
+
+
+def test_partition_is_linear_in_the_model_size():
+    """Model open on an adversarially long chain: 4000 operators partition in well under a second (round 3's partition was
+    quadratic in the operator count)."""
+    import time
+    b = ModelBuilder()
+    prev = b.tensor([1, 4, 4, 2], np.int32, "t0")
+    b.inputs = [prev]
+    for i in range(4000):
+        nxt = b.tensor([1, 4, 4, 2], np.int32, "t%d" % (i + 1))
+        b.custom_op("LceBMaxPool2d", [prev], [nxt], flexbuf.bmaxpool_options(1, 1, 1, 1, O.PADDING_VALID))
+        prev = nxt
+    b.outputs = [prev]
+    data = b.finish()
+    t = time.perf_counter()
+    m = mr.LceModel(data)
+    dt = time.perf_counter() - t
+    assert len(m.sections) == 1 and len(m.sections[0].ops) == 4000 and m.sections[0].outputs == [4000]
+    assert dt < 5.0, dt

@@ -210,9 +210,10 @@ def test_invoke_without_gpu_reports_error_instead_of_falling_back():
     assert m.invoke() == 1 and "no CPU fallback" in m.log
 
 
-def test_a_chain_of_ops_prepares_through_one_context_with_an_execution_plan():
-    """The chain driver: four LCE nodes behind one context that answers GetExecutionPlan / GetNodeAndRegistration (what the
-    ops' residency layer asks); shape inference runs node by node; without a GPU invoke fails loudly at the first op."""
+def test_a_chain_of_ops_prepares_through_one_context():
+    """The chain driver: LCE nodes behind one context whose GetExecutionPlan / GetNodeAndRegistration are forbidden to
+    kernels, as TensorFlow Lite's are (the ops never call them: the host declares its graph, lce_ops_register.h); shape
+    inference runs node by node; without a GPU invoke fails loudly at the first op."""
     m = T.ChainModel()
     x = m.add_tensor(T.FLOAT32, (2, 12, 10, 64))
     q = m.add_tensor(T.INT32, (0,) * 4)
@@ -224,9 +225,14 @@ def test_a_chain_of_ops_prepares_through_one_context_with_an_execution_plan():
     m.add_node("LceQuantize", [x], [q])
     m.add_node("LceBconv2d", [q, f1, -1, -1, th], [c1], flexbuf.bconv2d_options(64, 1, 1, 1, 1, O.PADDING_SAME, 1, O.ACT_NONE))
     m.add_node("LceBMaxPool2d", [c1], [p], flexbuf.bmaxpool_options(2, 2, 2, 2, 1))
+    m.declare_graph([p])
     assert m.prepare() == 0, m.log
     assert m.shape(q) == (2, 12, 10, 2) and m.shape(c1) == (2, 12, 10, 3) and m.shape(p) == (2, 6, 5, 3)
     if amd.device_count() == 0:
         assert m.invoke() == 1 and "no CPU fallback" in m.log
+    assert "forbidden" not in m.log
+    n0 = T.device_buffers()[0]
+    m.close()                                   # a declared graph and its buffers go with the interpreter's nodes
+    assert T.device_buffers()[0] <= n0
     with pytest.raises(ValueError):
         m.add_node("NoSuchOp", [x], [q])

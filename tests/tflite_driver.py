@@ -29,6 +29,8 @@ def lib():
         l = C.CDLL(path)
         l.lce_driver_create.restype = C.c_void_p
         l.lce_driver_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        l.lce_driver_forget_graph.argtypes = [C.c_void_p]
+        l.lce_driver_forget_graph.restype = None
         l.lce_driver_destroy.argtypes = [C.c_void_p]
         l.lce_driver_add_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
                                             C.c_float, C.c_int, C.c_int]
@@ -52,6 +54,12 @@ def lib():
         l.lce_driver_prepare_all.argtypes = [C.c_void_p]
         l.lce_driver_invoke_all.argtypes = [C.c_void_p]
         l.lce_tflite_ops_set_residency.argtypes = [C.c_int]
+        l.lce_driver_declare_graph.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
+        l.lce_driver_declare_graph.restype = None
+        l.lce_driver_forget_graph.argtypes = [C.c_void_p]
+        l.lce_driver_forget_graph.restype = None
+        l.lce_tflite_ops_device_buffers.argtypes = [C.POINTER(C.c_uint64)] * 2
+        l.lce_tflite_ops_device_buffers.restype = None
         l.lce_tflite_ops_transfer_counts.argtypes = [C.POINTER(C.c_uint64)] * 4 + [C.c_int]
         _lib = l
     return _lib
@@ -123,9 +131,10 @@ class SingleOpModel:
 
 
 class ChainModel(SingleOpModel):
-    """Several nodes in execution order behind ONE context that answers GetExecutionPlan / GetNodeAndRegistration --
-    what the LCE ops need to keep tensors that only they read on the device.  "HostCopy" is a stand-in for a builtin CPU
-    kernel (copies its input to its output in the arena)."""
+    """Several nodes in execution order behind ONE context.  As in TensorFlow Lite, the context's GetExecutionPlan /
+    GetNodeAndRegistration are forbidden to kernels (they log an error and fail); `declare_graph` is what an application
+    does once with its interpreter so that tensors only LCE ops read stay on the device.  "HostCopy" is a stand-in for a
+    builtin CPU kernel (copies its input to its output in the arena)."""
 
     def __init__(self):
         self._keep = []
@@ -141,6 +150,14 @@ class ChainModel(SingleOpModel):
             raise ValueError(f"unknown op {op_name}")
         return idx
 
+    def declare_graph(self, graph_outputs):
+        """lce_tflite_ops_declare_graph_* as lce_ops_register.h's DeclareGraphForDeviceResidency makes them."""
+        o = (C.c_int * len(graph_outputs))(*graph_outputs)
+        lib().lce_driver_declare_graph(self._h, o, len(graph_outputs))
+
+    def forget_graph(self):
+        lib().lce_driver_forget_graph(self._h)
+
     def prepare(self) -> int:
         return lib().lce_driver_prepare_all(self._h)
 
@@ -153,6 +170,13 @@ def transfer_counts(reset: bool = False):
     v = [C.c_uint64() for _ in range(4)]
     lib().lce_tflite_ops_transfer_counts(*[C.byref(x) for x in v], int(reset))
     return tuple(int(x.value) for x in v)
+
+
+def device_buffers():
+    """(count, bytes) of the device buffers the ops' residency layer holds right now, over all contexts."""
+    n, b = C.c_uint64(), C.c_uint64()
+    lib().lce_tflite_ops_device_buffers(C.byref(n), C.byref(b))
+    return int(n.value), int(b.value)
 
 
 def set_residency(on: bool):
