@@ -256,7 +256,8 @@ LCE_DEVICE void pin(f32x16& c) { asm volatile("" : "+v"(c)); }
 // runs out, and copies them through v_accvgpr_read in front of every use.
 LCE_DEVICE void keep_in_agpr(u32x4& v) { asm volatile("" : "+a"(v)); }
 LCE_DEVICE void keep_in_vgpr(u32x4& v) { asm volatile("" : "+v"(v)); }
-LCE_DEVICE void keep_in_vgpr(float& v) { asm volatile("" : "+v"(v)); }   // a uniform value kept per lane (spares a scalar register)
+LCE_DEVICE void keep_in_vgpr(float& v) { asm volatile("" : "+v"(v)); }
+LCE_DEVICE void keep_in_vgpr(int& v) { asm volatile("" : "+v"(v)); }   // a uniform value kept per lane (spares a scalar register)
 // a + b, saturating at 2^32 - 1 (v_add_u32 ... clamp): two "out of range" markers must not add up to an in-range offset
 LCE_DEVICE uint32_t sat_add_u32(uint32_t a, uint32_t b) { return __builtin_elementwise_add_sat(a, b); }
 // Between a wave's scratch writes and its reads of other lanes' values.  The LDS runs one wave's DS operations in

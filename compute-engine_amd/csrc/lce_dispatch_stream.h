@@ -7,11 +7,12 @@
 
 namespace lce {
 
-// 3x3 filters over 64 / 128 / 256 (padded) input channels; FAST = every padded word exists and padding is +1;
+// 3x3 filters over 64 / 128 / 256 / 512 (padded) input channels; FAST = every padded word exists and padding is +1;
 // CLAMP = the float transform's clamp is not the identity; SIGN = the epilogue also writes the output's LceQuantize
 template <int DST, bool FAST, bool CLAMP, bool SIGN>
 stream_fn stream_by_kch(int kch) {
   switch (kch) {
+    case 8: return bconv2d_stream<DST, 3, 3, 8, FAST, CLAMP, SIGN, true>;     // 512 input channels: K split over wave pairs
     case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN>;
     case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP, SIGN>;
     case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP, SIGN>;

@@ -516,6 +516,22 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     plan->device_current = false;
     return LCE_HIP_OK;
   }
+  if (!strcmp(key, "stream_flat")) {       // testing aid for the streaming kernel: 0 = never cut pixel blocks across a block's images
+    if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_flat must be 0 or 1");
+    h.stream_noflat = value[0] == '0';
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
+  if (!strcmp(key, "stream_pixel_phases")) {   // tuning aid for the streaming kernel: pixel phases per block (the other waves take channel slices)
+    const int v = atoi(value);
+    if (!(v == 1 || v == 2 || v == 4 || (v == 0 && !strcmp(value, "0"))))
+      return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_pixel_phases must be 0 (auto), 1, 2 or 4");
+    h.stream_phases_pref = v;
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "compute_units")) {     // testing aid: the device's CU count as the streaming kernel's planner sees it
     const int v = atoi(value);
     if (v < 1) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: compute_units must be positive");

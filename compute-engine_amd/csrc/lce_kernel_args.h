@@ -152,6 +152,9 @@ struct StreamArgs {
   int32_t S;                   // segments of this launch = B * SPI
   int32_t SPB;                 // segments per block
   int32_t pph_log;             // log2 of the pixel blocks per block step: 4 waves = (4 >> pph_log) channel slices x that
+  int32_t flat;                // 1: pixel blocks are cut from the block's segments laid end to end (NPX pixels each)
+  int32_t NPX;                 // output pixels per segment = RS * OW
+  int32_t NQ;                  // pixel blocks of a full block's stream = rows of the context table
   uint32_t in_bytes, w_bytes, out_bytes;   // bytes bound to the input / weight / output buffer resources (< 2^31)
   // the planner's tables (one buffer): sched at byte 0, one dword per tile step; lim: one dword per pixel block (its
   // last real row); ctx: 16 bytes per (pixel block, lane) = {tap-row LDS addresses 0..2, output byte offset}

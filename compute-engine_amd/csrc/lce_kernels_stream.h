@@ -43,8 +43,9 @@ namespace lce {
 __device__ unsigned long long lce_stream_tl[512 * 64];
 #define LCE_SPH(slot)                                                                               \
   do {                                                                                              \
-    if (thread_idx_x() == 0 && block_idx_x() < 512 && (slot) < 64)                                  \
-      lce_stream_tl[block_idx_x() * 64 + (slot)] = __builtin_readcyclecounter();                    \
+    const int sph_b = block_idx_y() * grid_dim_x() + block_idx_x();                                 \
+    if (thread_idx_x() == 0 && sph_b < 512 && (slot) < 64)                                          \
+      lce_stream_tl[sph_b * 64 + (slot)] = __builtin_readcyclecounter();                            \
   } while (0)
 #else
 #define LCE_SPH(slot) do {} while (0)
@@ -74,14 +75,25 @@ constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 // SIGN (float / int8 output): the epilogue also writes the LceQuantize of the values it produces (the second output of
 // lce_hip_bconv2d_run_dual: bit = value < bit_thr, as the block GEMM's epilogues do) -- the next binary layer of a
 // chain reads 1/32 of the bytes and no separate quantize launch runs.
-template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN>
+// KSPLIT (round 4; 512 input channels): a 64-channel wave cannot hold 9 x 8 K-steps of weights (576 registers), and
+// 32-channel waves would each need their own A fragment per MFMA (4 KiB of LDS reads per 33 cycles per CU: the LDS port's
+// whole rate).  Instead the K dimension is split over a PAIR of waves: waves w and w ^ 2 own the same 64 channels and the
+// same pixel block, each holds the weights of one HALF of the input channels (KCH / 2 chunks per tap: 288 registers) and
+// accumulates a partial sum; before the epilogue the pair swaps halves through LDS -- each wave sends the 32-channel tile
+// it does not finalise (4 ds_write_b128 into the partner's inbox), a block barrier, 4 ds_read_b128 + 16 adds -- and then
+// transforms and stores ITS 32 channels.  A-fragment traffic stays at one 1-KiB read per two MFMAs.  So that all register
+// indices are static, a wave's LOCAL tile 0 is the one it finalises: the K-half-1 wave holds the slice's two channel
+// tiles in swapped order.  Block = 2 channel slices x 2 K-halves, one pixel block per block step.
+template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false>
 LCE_KERNEL void __launch_bounds__(256, 1)
 bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
                const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
                const uint32_t* __restrict__ tabs, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
   static_assert(!SIGN || DST != kDstBitpacked, "a bitpacked-output plan already writes bits");
-  constexpr int KS = KH * KW * KCH;            // K-steps of one pixel block
+  constexpr int KCHW = KSPLIT ? KCH / 2 : KCH; // 64-channel chunks per tap that ONE wave multiplies
+  constexpr int KS = KH * KW * KCHW;           // K-steps of one pixel block (per wave)
   constexpr int PS = KCH * 32 + 16;            // LDS bytes per ring pixel (the +16 staggers the banks)
+  static_assert(!KSPLIT || KCH % 2 == 0, "the K split halves the chunks of a tap");
   constexpr int GA = 4;                        // K-steps per fragment group (one counted wait per group)
   constexpr int NG = (KS + GA - 1) / GA;
   static_assert(KH == 3, "the context table holds three tap-row addresses");
@@ -92,22 +104,39 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   const int l31 = lane & 31, half = lane >> 5;
   // waves -> (64-channel slice, pixel phase): N >= 256: four slices of one pixel block; N = 128: two slices x two
   // pixel blocks; N = 64: four pixel blocks
-  const int nslb = 4 >> G.pph_log;
-  const int slice = wave & (nslb - 1), pp = wave >> (2 - G.pph_log);
+  const int nslb = KSPLIT ? 2 : 4 >> G.pph_log;
+  const int slice = wave & (nslb - 1), pp = KSPLIT ? 0 : wave >> (2 - G.pph_log);
+  const int khalf = KSPLIT ? wave >> 1 : 0;                 // which half of the input channels this wave multiplies
   const int n0 = (block_idx_y() * nslb + slice) * 64;
   const bool slice_ok = n0 < G.Npad;
+  const int nown = n0 + khalf * 32;                         // KSPLIT: first of the 32 channels this wave finalises
 
   uint8_t* const lds0 = lds_base();
-  float* const scratch = (float*)(lds0 + G.ring_bytes) + wave * (32 * 64);   // [32 pixel rows][64 channels]
-  const uint32_t dump = (uint32_t)G.ring_bytes + 4u * 8192u + (uint32_t)lane * 64u;   // where idle lanes' items go
+  constexpr int SCW = KSPLIT ? 32 : 64;                    // floats per scratch row: the channels a wave transposes and stores
+  constexpr int SCRB = 32 * SCW * 4;                       // bytes of a wave's epilogue scratch
+  float* const scratch = (float*)(lds0 + G.ring_bytes) + wave * (32 * SCW);   // [32 pixel rows][SCW channels]
+  const uint32_t dump = (uint32_t)G.ring_bytes + 4u * (uint32_t)SCRB + (uint32_t)lane * 64u;   // where idle lanes' items go
+  // KSPLIT: every wave's inbox for its partner's partial tile, two slots of 4 KiB (block parity), behind the dump area
+  uint8_t* const inbox = lds0 + G.ring_bytes + 4 * SCRB + 4096 + wave * 8192;
+  uint8_t* const outbox = lds0 + G.ring_bytes + 4 * SCRB + 4096 + (wave ^ 2) * 8192;
 
   LCE_SPH(0);
   // ---- this block's run of segments ----
   const int g0 = block_idx_x() * G.SPB;
   int nseg = G.S - g0;
   nseg = nseg < 0 ? 0 : (nseg > G.SPB ? G.SPB : nseg);
-  const int nblk = slice_ok ? nseg * G.PBS : 0;        // pixel blocks of this block's stream that produce output
-  const int usteps = (nseg * G.PBS + (1 << G.pph_log) - 1) >> G.pph_log;   // block steps (2^pph_log pixel blocks each)
+  // pixel blocks of this block's stream: per segment, or (flat) cut from its segments' pixels laid end to end -- a short last
+  // block's spare lanes then hold pixels past the launch, whose stores fall outside the output's buffer resource
+  const int nblk_all = G.flat ? (nseg * G.NPX + 31) >> 5 : nseg * G.PBS;
+  const int nblk = slice_ok ? nblk_all : 0;            // ... that produce output
+  const int usteps = (nblk_all + (1 << G.pph_log) - 1) >> G.pph_log;   // block steps (2^pph_log pixel blocks each)
+  // flat: the pixel block at which this block's run ends in mid-block (-1: none, or the table says so itself), and the last
+  // real row of that block -- ONE scalar each for the K loop, which has no scalar registers to spare
+  // (kept per lane: the K loop has no scalar registers to spare)
+  int dyn_last = G.flat && ((nseg * G.NPX) & 31) != 0 ? nblk_all - 1 : -1;
+  int dyn_lim = nseg * G.NPX - (nblk_all - 1) * 32 - 1;
+  keep_in_vgpr(dyn_last);
+  keep_in_vgpr(dyn_lim);
   const int ntile = (usteps + 3) >> 2;                 // tile steps (four block steps + one barrier)
   const uint32_t* const sched = tabs;
   const rsrc_t rtab = make_rsrc(tabs, G.tab_bytes);
@@ -229,7 +258,13 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     constexpr int a = decltype(ac)::value, b = decltype(bc)::value;
 #pragma unroll
     for (int i = a; i < b; ++i)
-      W[i >> 1][i & 1] = buf_load(rw, slice_ok ? (uint32_t)(((i >> 1) * 2 + half) * G.Npad + n0 + (i & 1) * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
+    {
+      // (KSPLIT: the wave's K-step ks = (tap, kc) is the layer's K-step tap * KCH + khalf * KCHW + kc, and its local
+      //  channel tile j is the slice's tile j ^ khalf)
+      const int ksl = i >> 1, ksg = KSPLIT ? (ksl / KCHW) * KCH + khalf * KCHW + ksl % KCHW : ksl;
+      const int jt = KSPLIT ? (i & 1) ^ khalf : (i & 1);
+      W[i >> 1][i & 1] = buf_load(rw, slice_ok ? (uint32_t)((ksg * 2 + half) * G.Npad + n0 + jt * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
+    }
     sched_fence();
   };
   constexpr int kBankFirst = KS / 2;                        // the first run: a quarter of the bank
@@ -260,7 +295,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   f32x2 mj[2], bj[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = slice_ok ? n0 + j * 32 + l31 : 0;
+    const int n = slice_ok ? n0 + (KSPLIT ? j ^ khalf : j) * 32 + l31 : 0;
     tj[j] = uj[j] = 0.0f;
     mj[j] = f32x2{0.0f, 0.0f};
     bj[j] = f32x2{0.0f, 0.0f};
@@ -269,7 +304,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     if constexpr (DST == kDstInt8) { tj[j] = thrf[n]; uj[j] = thrf[G.Npad + n]; }
   }
   // the accumulators' start value K_bt as a constant C tile (the first MFMA of every pixel block reads it)
-  f32x16 kbt = f32x16_fill(G.a_bt);
+  f32x16 kbt = f32x16_fill(khalf ? 0.0f : G.a_bt);   // (KSPLIT: the pair's two partial sums add up to K_bt - <a, w>)
   pin(kbt);
   float cminv = G.cmin, cmaxv = G.cmax;     // per-lane copies: the scalar registers are for the loop's addressing
   keep_in_vgpr(cminv);
@@ -322,20 +357,34 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // The items tile step 0 writes (needed from tile step 1 on) are on their way.  Item A (the first 256 of a tile
   // step's quota) rides between the MFMAs; item B (the rest -- the planner's schedule makes it rare) is handled
   // out of line at the end of a tile step.
-  u32x4 pwa, pwb = {0u, 0u, 0u, 0u};
-  uint32_t pda, pdb = dump;
-  int pma, pmb = 0;
+  // KSPLIT (a pixel is four items wide): a second woven item, C = the second 256 of a quota, rides in block steps 2 (expand)
+  // and 3 (issue) exactly as A does in steps 0 and 1; B is then the third 256.
+  constexpr uint32_t kItemB = KSPLIT ? 512u : 256u;        // where item B starts inside a tile step's quota
+  u32x4 pwa, pwb = {0u, 0u, 0u, 0u}, pwc = {0u, 0u, 0u, 0u};
+  uint32_t pda, pdb = dump, pdc = dump;
+  int pma, pmb = 0, pmc = 0;
   bool have_b;
   {
     const uint32_t a = sched[0], b = sched[1];
     item_issue(a + (uint32_t)tid, b, pwa, pda, pma);
-    have_b = b - a > 256u;
-    if (have_b) item_issue(a + (uint32_t)(256 + tid), b, pwb, pdb, pmb);
+    if constexpr (KSPLIT) item_issue(a + (uint32_t)(256 + tid), b, pwc, pdc, pmc);
+    have_b = b - a > kItemB;
+    if (have_b) item_issue(a + kItemB + (uint32_t)tid, b, pwb, pdb, pmb);
   }
   // The filter bank's home: 256 accumulator registers hold the first 32 K-steps' fragments, the rest stay in VGPRs.
-  // The hint is a USE of the loaded value (a counted wait), placed here so that the first rows' expansion above ran
-  // while the bank was still arriving -- and after all its loads were issued: behind each load it would wait for that
-  // load alone, 72 round trips in a row.
+  // The hint is a USE of the loaded value (a counted wait).  Round 4: it no longer sits here, in front of the first MFMA
+  // -- the FIRST block step below takes each K-step's two fragments as they arrive (the bank is 295 KB per CU and takes
+  // ~6 k cycles to come in; the first pixel block's 72 MFMAs now run inside that time instead of behind it).
+  // LCE_STREAM_BANK_UPFRONT (A/B aid): the round-3 order, all of the bank before the first MFMA.
+  auto bank_home = [&](auto ksc) LCE_LAMBDA_INLINE {
+    constexpr int ks = decltype(ksc)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (ks < 32) keep_in_agpr(W[ks][j]);
+      else keep_in_vgpr(W[ks][j]);
+    }
+  };
+#ifdef LCE_STREAM_BANK_UPFRONT
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -343,6 +392,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       if (ks < 32) keep_in_agpr(W[ks][j]);
       else keep_in_vgpr(W[ks][j]);
     }
+#endif
   block_barrier_keep_vm();
   LCE_SPH(1);
 
@@ -357,28 +407,45 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   const uint32_t row_bytes = DST == kDstBitpacked ? (uint32_t)G.Wout * 4u : (uint32_t)G.N * (DST == kDstInt8 ? 1u : 4u);
   const rsrc_t rout = make_rsrc(out, G.out_bytes);
   // this lane's share of a stored row, and the block's first output pixel
+  // (KSPLIT: a wave stores its OWN 32 channels -- 8 lanes x 16 bytes of floats, 2 lanes x 16 bytes of int8, one word)
+  constexpr int LPR = DST == kDstFloat ? (KSPLIT ? 8 : 16) : DST == kDstInt8 ? (KSPLIT ? 2 : 4) : 64;   // lanes per stored pixel row
+  constexpr int RPI = 64 / LPR;                                                                          // pixel rows per store instruction
   uint32_t chan_off;
   if constexpr (DST == kDstFloat) {
-    const int n = n0 + (lane & 15) * 4;                                // 16 lanes x 16 bytes = a pixel's 64 channels
+    const int n = (KSPLIT ? nown : n0) + (lane & (LPR - 1)) * 4;      // 16 lanes x 16 bytes = a pixel's 64 channels
     chan_off = n < G.N ? (uint32_t)n * 4u : kOobOffset;
   } else if constexpr (DST == kDstInt8) {
-    const int n = n0 + (lane & 3) * 16;                                // 4 lanes x 16 bytes = a pixel's 64 channels
+    const int n = (KSPLIT ? nown : n0) + (lane & (LPR - 1)) * 16;     // 4 lanes x 16 bytes = a pixel's 64 channels
     chan_off = n < G.N ? (uint32_t)n : kOobOffset;
+  } else if constexpr (KSPLIT) {
+    chan_off = lane < 32 && (nown >> 5) < G.Wout ? (uint32_t)(nown >> 5) * 4u : kOobOffset;   // lane p owns pixel row p: its one word
   } else {
     chan_off = lane < 32 ? (uint32_t)(n0 >> 5) * 4u : kOobOffset;      // lane p owns pixel row p: two words
   }
   chan_off += (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * row_bytes;      // < 2^31 with the whole output
-  const int nq = G.SPB * G.PBS;
+  const int nq = G.NQ;
   auto load_ctx = [&](int u, Ctx& cx) LCE_LAMBDA_INLINE {
     int q = (u << G.pph_log) + pp;
     q = q < nq ? q : nq - 1;
     cx.t = buf_load(rtab, (uint32_t)G.tab_ctx + (uint32_t)(q * 64 + lane) * 16u, (u32x4*)nullptr);
+    if constexpr (KSPLIT) {            // this wave's half of a pixel's channels: KCHW chunks of 32 bytes further on
+      const uint32_t koff = (uint32_t)khalf * (uint32_t)(KCHW * 32);
+      cx.t[0] += koff; cx.t[1] += koff; cx.t[2] += koff;
+    }
     if constexpr (SIGN) cx.s = buf_load(rtab, (uint32_t)G.tab_sgn + (uint32_t)(q * 64 + lane) * 4u, (uint32_t*)nullptr);
     else cx.s = 0u;
+    // flat: the last block of a run that is SHORTER than the planned one is partial where the table does not say so (its
+    // rows past the run are pixels of images beyond the launch; a store's uniform row offset is not range-checked): it
+    // gets the table's marker here
+    const uint32_t mark = (u << G.pph_log) + pp == dyn_last ? 0x80000000u : 0u;
+    cx.t[3] |= mark;
+    if constexpr (SIGN) cx.s |= mark;
   };
   // second output: lane p (< 32) owns pixel row p's two sign words of this wave's 64 channels
   const rsrc_t rsgn = make_rsrc(sign_words, SIGN ? G.sign_bytes : 0u);
-  const uint32_t sign_chan_off = lane < 32 ? (uint32_t)(n0 >> 5) * 4u + (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * (uint32_t)G.Wout * 4u : kOobOffset;
+  const uint32_t sign_chan_off = lane < 32 && (!KSPLIT || (nown >> 5) < G.Wout)
+                                     ? (uint32_t)((KSPLIT ? nown : n0) >> 5) * 4u + (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * (uint32_t)G.Wout * 4u
+                                     : kOobOffset;
   auto sign_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
     const int q = (u << G.pph_log) + pp;
     return sat_add_u32(cx.s, q < nblk ? sign_chan_off : kOobOffset);
@@ -386,7 +453,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // per lane: channels past the last one never set a bit (padding bits of the last word are 0, bitpack.h:248-308)
   float bit_thrv[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) bit_thrv[j] = n0 + j * 32 + l31 < G.N ? G.bit_thr : -__builtin_inff();
+  for (int j = 0; j < 2; ++j) bit_thrv[j] = n0 + (KSPLIT ? j ^ khalf : j) * 32 + l31 < G.N ? G.bit_thr : -__builtin_inff();
   // the store offset of a context: out of range for pixel blocks past the stream and for partial blocks
   auto out_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
     const int q = (u << G.pph_log) + pp;
@@ -411,9 +478,19 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   f32x4 yb[8];
   u32x4 pk[2];
   uint32_t bw[2] = {0u, 0u};
+  // (KSPLIT: only local tile 0, the wave's own 32 channels -- 8 units for float / int8, 16 single-word units for bits;
+  //  the scratch is [32 pixel rows][32 channels])
+  constexpr int NUA = (KSPLIT && DST != kDstBitpacked) ? 8 : 16;   // phase A units
   auto epi_a = [&](auto tc, f32x16 (&acc)[2]) LCE_LAMBDA_INLINE {
     constexpr int t = decltype(tc)::value;
-    if constexpr (DST == kDstBitpacked) {
+    if constexpr (DST == kDstBitpacked && KSPLIT) {
+      constexpr int r = t, q = (r & 3) + 8 * (r >> 2);
+      unsigned long long bits[1];
+      bits[0] = wave_ballot(acc[0][r] > tj[0]);
+      settle_ballots(bits);
+      bw[0] = write_lane_settled<q>((uint32_t)bits[0], bw[0]);
+      bw[0] = write_lane_settled<q + 4>((uint32_t)(bits[0] >> 32), bw[0]);
+    } else if constexpr (DST == kDstBitpacked) {
       // unit t = register r: the 32 channel bits of rows q and q + 4, dropped into the lanes that will store them
       constexpr int r = t, q = (r & 3) + 8 * (r >> 2);
       unsigned long long bits[2];
@@ -426,7 +503,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         bw[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), bw[j]);
       }
     } else {
-      constexpr int j = t >> 3, r0 = (t & 7) * 2;          // registers r0, r0 + 1: pixel rows row0, row0 + 1
+      constexpr int j = KSPLIT ? 0 : t >> 3, r0 = (t & 7) * 2;          // registers r0, r0 + 1: pixel rows row0, row0 + 1
       const int row0 = (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
       f32x2 y;
       if constexpr (DST == kDstFloat) {
@@ -439,8 +516,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         y[0] = med3(y[0], tj[j], uj[j]);                   // one clamp: see lce_kernels_pointwise.h
         y[1] = med3(y[1], tj[j], uj[j]);
       }
-      scratch[row0 * 64 + j * 32 + l31] = y[0];
-      scratch[(row0 + 1) * 64 + j * 32 + l31] = y[1];
+      scratch[row0 * SCW + j * 32 + l31] = y[0];
+      scratch[(row0 + 1) * SCW + j * 32 + l31] = y[1];
       if constexpr (SIGN) {
         // the 32 channel bits of the four pixel rows these two registers hold, dropped into the lanes that store them
         unsigned long long bits[2];
@@ -457,7 +534,9 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   };
   // the second output's store: two words per pixel row (one when the last word does not exist)
   auto sign_store = [&](uint32_t sob) LCE_LAMBDA_INLINE {
-    if ((G.Wout & 1) == 0) {
+    if constexpr (KSPLIT) {
+      buf_store1(rsgn, sob, bw[0]);                   // the wave's one word (sign_chan_off is out of range when it does not exist)
+    } else if ((G.Wout & 1) == 0) {
       const u32x2 v = {bw[0], bw[1]};
       buf_store2(rsgn, sob, v);
     } else {
@@ -468,27 +547,29 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   auto epi_b = [&](auto kc) LCE_LAMBDA_INLINE {
     constexpr int k = decltype(kc)::value;
     if constexpr (DST == kDstFloat) {
-      yb[k] = *(const f32x4*)(scratch + ((lane >> 4) + 4 * k) * 64 + (lane & 15) * 4);
+      yb[k] = *(const f32x4*)(scratch + ((lane / LPR) + RPI * k) * SCW + (lane & (LPR - 1)) * 4);
     } else if constexpr (DST == kDstInt8) {
       // store instruction k / 4 covers rows (lane >> 2) + 16 * (k / 4); a lane's 16 channels = reads 4 (k % 4) .. + 3
-      yb[k] = *(const f32x4*)(scratch + ((lane >> 2) + 16 * (k >> 2)) * 64 + (lane & 3) * 16 + (k & 3) * 4);
+      yb[k] = *(const f32x4*)(scratch + ((lane / LPR) + RPI * (k >> 2)) * SCW + (lane & (LPR - 1)) * 16 + (k & 3) * 4);
     }
   };
   // `ob` = this lane's byte offset for store instruction 0 (out of range: nothing is stored)
   auto epi_c = [&](auto kc, uint32_t ob) LCE_LAMBDA_INLINE {
     constexpr int k = decltype(kc)::value;
     if constexpr (DST == kDstFloat) {
-      buf_store_streaming_so(rout, ob, (uint32_t)(4 * k) * row_bytes, yb[k]);
+      buf_store_streaming_so(rout, ob, (uint32_t)(RPI * k) * row_bytes, yb[k]);
     } else if constexpr (DST == kDstInt8) {
       // round half away from zero on values already clamped to [-128, 127] (lce_kernels.h, round_sat_i8); scalar adds:
       // a packed-f32 add beside the MFMA stream costs a dozen cycles more than its issue slot
       auto rnd = [](float c) LCE_LAMBDA_INLINE -> int { return (int)(c + __builtin_copysignf(0x1.fffffep-2f, c)); };
       pk[k >> 2][k & 3] = pack4_u8(rnd(yb[k][0]), rnd(yb[k][1]), rnd(yb[k][2]), rnd(yb[k][3]));
-      if constexpr ((k & 3) == 3) buf_store_so(rout, ob, (uint32_t)(16 * (k >> 2)) * row_bytes, pk[k >> 2]);
+      if constexpr ((k & 3) == 3) buf_store_so(rout, ob, (uint32_t)(RPI * (k >> 2)) * row_bytes, pk[k >> 2]);
     } else {
       if constexpr (k == 0) {
         // lane p (< 32) owns pixel row p: the two words of this wave's 64 channels
-        if ((G.Wout & 1) == 0) {
+        if constexpr (KSPLIT) {
+          buf_store1(rout, ob, bw[0]);
+        } else if ((G.Wout & 1) == 0) {
           const u32x2 v = {bw[0], bw[1]};
           buf_store2(rout, ob, v);
         } else {
@@ -498,47 +579,71 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       }
     }
   };
-  // A partial pixel block (the last of a segment whose pixel count is not a multiple of 32): rows past the segment
-  // hold copies of its last pixel (their lanes re-read it), so every store is redirected to min(row, last real
-  // row) -- the same bytes to the same place.  Out of line, after the K loop that carried the block's epilogue.
+  // A partial pixel block (the last of a segment whose pixel count is not a multiple of 32): the rows past the segment
+  // are not stored (their lanes re-read the segment's last pixel -- or, in a flat run that is shorter than the planned
+  // one, pixels of images past the launch).  Out of line, after the K loop that carried the block's epilogue.
   auto epi_partial = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE {
     int q = (u << G.pph_log) + pp;
     if (q >= nblk) return;
-    const uint32_t lim1 = tabs[G.tab_lim / 4 + q];                     // last real row of the block
+    // last real row of the block (flat: the run's last block ends where the block's segments end -- a short last run of a
+    // launch ends earlier than the table's)
+    const uint32_t lim1 = q == dyn_last ? (uint32_t)dyn_lim : tabs[G.tab_lim / 4 + q];   // (per lane)
     const uint32_t base = (cx.t[3] & 0x7fffffffu) + chan_off;          // the table's offset is for row (lane's first row)
     if constexpr (DST == kDstFloat) {
-      const uint32_t rowl = (uint32_t)(lane >> 4);
+      const uint32_t rowl = (uint32_t)(lane / LPR);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t row = rowl + 4u * k < lim1 ? rowl + 4u * k : lim1;
-        buf_store_streaming(rout, base + (row - rowl) * row_bytes, yb[k]);
+      for (int k = 0; k < 32 / RPI; ++k) {
+        const uint32_t row = rowl + (uint32_t)(RPI * k);
+        buf_store_streaming(rout, row <= lim1 ? base + (row - rowl) * row_bytes : kOobOffset, yb[k]);
       }
     } else if constexpr (DST == kDstInt8) {
-      const uint32_t rowl = (uint32_t)(lane >> 2);
+      const uint32_t rowl = (uint32_t)(lane / LPR);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const uint32_t row = rowl + 16u * k < lim1 ? rowl + 16u * k : lim1;
-        buf_store(rout, base + (row - rowl) * row_bytes, pk[k]);
+      for (int k = 0; k < 32 / RPI; ++k) {
+        const uint32_t row = rowl + (uint32_t)(RPI * k);
+        buf_store(rout, row <= lim1 ? base + (row - rowl) * row_bytes : kOobOffset, pk[k]);
       }
     } else {
       const uint32_t rowl = (uint32_t)(lane & 31);
-      const uint32_t row = rowl < lim1 ? rowl : lim1;
-      const uint32_t o = base + (row - rowl) * row_bytes;
+      const uint32_t o = rowl <= lim1 ? base : kOobOffset;                 // (base may itself be past the range: chan_off's marker)
       buf_store1(rout, o, bw[0]);
-      buf_store1(rout, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(o, 4u) : kOobOffset, bw[1]);
+      if constexpr (!KSPLIT) buf_store1(rout, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(o, 4u) : kOobOffset, bw[1]);
     }
     if constexpr (SIGN) {
       const uint32_t rowl = (uint32_t)(lane & 31);
-      const uint32_t row = rowl < lim1 ? rowl : lim1;
-      sign_store((cx.s & 0x7fffffffu) + sign_chan_off + (row - rowl) * (uint32_t)G.Wout * 4u);
+      sign_store(rowl <= lim1 ? sat_add_u32(cx.s & 0x7fffffffu, sign_chan_off) : kOobOffset);
     }
   };
   // which units ride in K-step ks: A in the first 4/9 of the steps, B from the middle on, C at the end
   // B's gaps are the K-steps ks >= SB0 with ks % 4 in {2, 3} (SBG of them); C's the last SBN K-steps
-  constexpr int SA = KS * 4 / 9, SB0 = (SA + GA - 1) / GA * GA, SBN = (KS * 2 + 8) / 9, SC0 = KS - SBN;
+  // KSPLIT: the pair's exchange comes first -- K-steps 0..3 send one accumulator quad each, a block barrier behind K-step 4,
+  // the four inbox reads behind K-step 5, four adds behind each of K-steps 6..9 -- then the (halved) phases as above
+  constexpr int XS = KSPLIT ? 10 : 0;                     // K-steps of the exchange
+  constexpr int NUB = KSPLIT ? 4 : 8;                     // phase B reads / phase C units
+  constexpr int SA0 = XS, SA = SA0 + (KSPLIT ? NUA : KS * 4 / 9);   // phase A rides in K-steps [SA0, SA)
+  constexpr int SB0 = (SA + GA - 1) / GA * GA, SBN = KSPLIT ? 4 : (KS * 2 + 8) / 9, SC0 = KS - SBN;
+  static_assert(SA < KS - 1, "phase layout");
   constexpr int SBG_avail = (SC0 - SB0) / GA * 2 + ((SC0 - SB0) % GA > 2 ? (SC0 - SB0) % GA - 2 : 0);
   constexpr int SBG = SBG_avail >= 4 ? 4 : (SBG_avail >= 2 ? 2 : 1);
-  static_assert(SA <= SB0 && SB0 <= SC0 && SBG_avail >= 1, "phase layout");
+  static_assert(SA <= SB0 && SB0 <= SC0 && (SBG_avail >= 1 || DST == kDstBitpacked), "phase layout");
+
+  // KSPLIT: the exchange of partial sums between the two waves of a pair (set = the accumulator set being drained,
+  // SLOT = the parity of its block).  A wave's local tile 1 is its partner's local tile 0.
+  f32x4 xch[4];
+  auto x_send = [&](auto qc, f32x16 (&set)[2], int slot) LCE_LAMBDA_INLINE {
+    constexpr int q = decltype(qc)::value;
+    const f32x4 v = {set[1][4 * q], set[1][4 * q + 1], set[1][4 * q + 2], set[1][4 * q + 3]};
+    *(f32x4*)(outbox + slot * 4096 + q * 1024 + lane * 16) = v;
+  };
+  auto x_recv = [&](int slot) LCE_LAMBDA_INLINE {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xch[q] = *(const f32x4*)(inbox + slot * 4096 + q * 1024 + lane * 16);
+  };
+  auto x_add = [&](auto qc, f32x16 (&set)[2]) LCE_LAMBDA_INLINE {
+    constexpr int q = decltype(qc)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) set[0][4 * q + i] += xch[q][i];
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -555,7 +660,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   u32x4 af[2][GA];
 
   auto frag_addr = [&](const Ctx& cx, int ks) LCE_LAMBDA_INLINE -> uint32_t {
-    const int fy = ks / (KW * KCH), fx = (ks / KCH) % KW, kc = ks % KCH;
+    const int fy = ks / (KW * KCHW), fx = (ks / KCHW) % KW, kc = ks % KCHW;
     return cx.t[fy] + (uint32_t)(fx * PS + kc * 32);
   };
 
@@ -568,9 +673,13 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   constexpr int NPG = KS - SA - 1;                          // gap-1 slots behind phase A and the context load
   uint32_t next_ob = kOobOffset, next_sob = kOobOffset, epi_sob = kOobOffset;
   bool next_part = false;
-  Issue isa;
-  auto step = [&](auto kc_, int u, uint32_t sch1, uint32_t sch2) LCE_LAMBDA_INLINE {
+  Issue isa, isc;
+  // FIRST (compile-time): the block's very first block step -- each K-step's bank fragments are waited for where they are
+  // first used, and there is no previous block to drain (no epilogue units ride along)
+  auto step = [&](auto kc_, auto first_, int u, uint32_t sch1, uint32_t sch2) LCE_LAMBDA_INLINE {
     constexpr int k = decltype(kc_)::value, PAR = k & 1;
+    constexpr bool FIRST = decltype(first_)::value != 0;
+    static_assert(!FIRST || k == 0, "the first block step is step 0 of tile step 0");
     if constexpr (k == 0) {
       // first block of a tile step: its fragments may live in rows the previous tile step wrote
 #pragma unroll
@@ -581,6 +690,9 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       if constexpr (ks < KS) {
         constexpr int g = ks / GA;
         constexpr int fs = (g + k * NG) & 1;     // the fragment set this block's group g lives in (set 0 after a barrier)
+#ifndef LCE_STREAM_BANK_UPFRONT
+        if constexpr (FIRST) bank_home(IntC<ks>{});     // this K-step's weights have arrived (a counted wait) and are at home
+#endif
         // ---------------- MFMA 0 ----------------
         if constexpr (ks == 0) acc[PAR][0] = mfma_fp4_32x32x64_unscaled(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
         else acc[PAR][0] = mfma_fp4_32x32x64_unscaled(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
@@ -608,9 +720,9 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
 #ifndef LCE_ST_NOEPI    // timing ablation (results are wrong): no epilogue units
         // phase B: two reads per gap, in the gaps the fragment reads leave free
-        if constexpr (ks >= SB0 && ks % GA >= 2 && (ks - SB0) / GA * 2 + (ks % GA - 2) < SBG) {
+        if constexpr (!FIRST && ks >= SB0 && ks % GA >= 2 && (ks - SB0) / GA * 2 + (ks % GA - 2) < SBG) {
           constexpr int slot = (ks - SB0) / GA * 2 + (ks % GA - 2);
-          constexpr int lo = stream_unit_lo(8, slot, SBG), hi = stream_unit_lo(8, slot + 1, SBG);
+          constexpr int lo = stream_unit_lo(NUB, slot, SBG), hi = stream_unit_lo(NUB, slot + 1, SBG);
           if constexpr (slot == 0) wave_lds_scratch_fence();   // phase A's writes before phase B's reads
 #ifndef LCE_ST_NOEPI_B
           if constexpr (lo + 0 < hi) epi_b(IntC<lo + 0>{});
@@ -637,8 +749,15 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         sched_fence();
         // ---------------- gap 1 ----------------
 #ifndef LCE_ST_NOEPI
-        if constexpr (ks < SA) {
-          constexpr int lo = stream_unit_lo(16, ks, SA), hi = stream_unit_lo(16, ks + 1, SA);
+        if constexpr (KSPLIT && !FIRST && ks < XS) {
+          constexpr int slot = (k + 1) & 1;            // parity of the block being drained (u - 1; u = 4 T + k)
+          if constexpr (ks < 4) x_send(IntC<ks>{}, acc[PAR ^ 1], slot);
+          else if constexpr (ks == 4) block_barrier_keep_vm();     // both halves are in the inboxes
+          else if constexpr (ks == 5) x_recv(slot);
+          else x_add(IntC<ks - 6>{}, acc[PAR ^ 1]);
+        }
+        if constexpr (!FIRST && ks >= SA0 && ks < SA) {
+          constexpr int lo = stream_unit_lo(NUA, ks - SA0, SA - SA0), hi = stream_unit_lo(NUA, ks - SA0 + 1, SA - SA0);
           if constexpr (lo == 0) wave_lds_order();     // the scratch's previous readers are done (in-order LDS)
 #ifndef LCE_ST_NOEPI_A
           if constexpr (lo + 0 < hi) epi_a(IntC<lo + 0>{}, acc[PAR ^ 1]);
@@ -648,8 +767,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
           static_assert(hi - lo <= 4, "units per gap");
         }
-        if constexpr (ks >= SC0) {
-          constexpr int lo = stream_unit_lo(8, ks - SC0, SBN), hi = stream_unit_lo(8, ks - SC0 + 1, SBN);
+        if constexpr (!FIRST && ks >= SC0) {
+          constexpr int lo = stream_unit_lo(NUB, ks - SC0, SBN), hi = stream_unit_lo(NUB, ks - SC0 + 1, SBN);
 #ifndef LCE_ST_NOEPI_C
           if constexpr (lo + 0 < hi) epi_c(IntC<lo + 0>{}, epi_ob);
           if constexpr (lo + 1 < hi) epi_c(IntC<lo + 1>{}, epi_ob);
@@ -658,7 +777,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         }
 #endif
-        if constexpr (SIGN && ks == SA) sign_store(epi_sob);      // phase A is complete: the drained block's sign words
+        if constexpr (SIGN && !FIRST && ks == SA) sign_store(epi_sob);      // phase A is complete: the drained block's sign words
         if constexpr (ks == SA) load_ctx(u + 1, nxt);
 #ifndef LCE_ST_NOPROD   // timing ablation (results are wrong): no production between the MFMAs
         // production: block step 0 expands item A (16 chunks), block step 1 issues the next one (12 chunks; its load
@@ -677,6 +796,17 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
             if constexpr (lo + 1 < hi) issue_chunk(IntC<lo + 1>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
             if constexpr (lo + 2 < hi) issue_chunk(IntC<lo + 2>{}, isa, sch1 + (uint32_t)tid, sch2, pwa, pda, pma);
             static_assert(hi - lo <= 3, "chunks per gap");
+          } else if constexpr (KSPLIT && k == 2) {
+            constexpr int lo = stream_unit_lo(16, ks - SA - 1, NPG), hi = stream_unit_lo(16, ks - SA, NPG);
+            if constexpr (lo + 0 < hi) write_chunk(IntC<lo + 0>{}, pwc, pdc, pmc);
+            if constexpr (lo + 1 < hi) write_chunk(IntC<lo + 1>{}, pwc, pdc, pmc);
+            if constexpr (lo + 2 < hi) write_chunk(IntC<lo + 2>{}, pwc, pdc, pmc);
+            if constexpr (lo + 3 < hi) write_chunk(IntC<lo + 3>{}, pwc, pdc, pmc);
+          } else if constexpr (KSPLIT && k == 3) {
+            constexpr int lo = stream_unit_lo(kIssueChunks, ks - SA - 1, NPG), hi = stream_unit_lo(kIssueChunks, ks - SA, NPG);
+            if constexpr (lo + 0 < hi) issue_chunk(IntC<lo + 0>{}, isc, sch1 + (uint32_t)(256 + tid), sch2, pwc, pdc, pmc);
+            if constexpr (lo + 1 < hi) issue_chunk(IntC<lo + 1>{}, isc, sch1 + (uint32_t)(256 + tid), sch2, pwc, pdc, pmc);
+            if constexpr (lo + 2 < hi) issue_chunk(IntC<lo + 2>{}, isc, sch1 + (uint32_t)(256 + tid), sch2, pwc, pdc, pmc);
           }
         }
 #endif
@@ -691,7 +821,9 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     kstep(IntC<30>{}); kstep(IntC<31>{}); kstep(IntC<32>{}); kstep(IntC<33>{}); kstep(IntC<34>{}); kstep(IntC<35>{});
     static_assert(KS <= 36, "kstep calls above");
     // the drained block was a partial one: its stores, redirected, out of line
-    if (epi_part) epi_partial(epi_u, epi_cx);
+    if constexpr (!FIRST) {
+      if (epi_part) epi_partial(epi_u, epi_cx);
+    }
     // this block becomes the one being drained
     epi_ob = next_ob;
     epi_sob = next_sob;
@@ -701,39 +833,63 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     cur = nxt;
   };
 
-  for (int T = 0; T < ntile; ++T) {
+  using TagFirst = IntC<1>;
+  using TagSteady = IntC<0>;
+  auto tile_step = [&](auto first_, int T) LCE_LAMBDA_INLINE {
     const uint32_t sch1 = sched[T + 1], sch2 = sched[T + 2];
     // (the last tile step may be short: block steps past the stream are skipped, not computed and masked)
-    step(IntC<0>{}, 4 * T + 0, sch1, sch2);
-    if (4 * T + 1 < usteps) step(IntC<1>{}, 4 * T + 1, sch1, sch2);
-    if (4 * T + 2 < usteps) step(IntC<2>{}, 4 * T + 2, sch1, sch2);
-    if (4 * T + 3 < usteps) step(IntC<3>{}, 4 * T + 3, sch1, sch2);
-    // the rare second item of a tile step's quota
+    step(IntC<0>{}, first_, 4 * T + 0, sch1, sch2);
+    if (4 * T + 1 < usteps) step(IntC<1>{}, TagSteady{}, 4 * T + 1, sch1, sch2);
+    if (4 * T + 2 < usteps) step(IntC<2>{}, TagSteady{}, 4 * T + 2, sch1, sch2);
+    if (4 * T + 3 < usteps) step(IntC<3>{}, TagSteady{}, 4 * T + 3, sch1, sch2);
+    // the rare last item of a tile step's quota (beyond what rides between the MFMAs)
     if (have_b) item_write(pwb, pdb, pmb);
-    have_b = sch2 - sch1 > 256u;
-    if (have_b) item_issue(sch1 + (uint32_t)(256 + tid), sch2, pwb, pdb, pmb);
+    have_b = sch2 - sch1 > kItemB;
+    if (have_b) item_issue(sch1 + kItemB + (uint32_t)tid, sch2, pwb, pdb, pmb);
     block_barrier_keep_vm();     // this tile step's rows are visible; the rows it read may be overwritten
     LCE_SPH(2 + T);
-  }
+  };
+#ifdef LCE_STREAM_BANK_UPFRONT
+  for (int T = 0; T < ntile; ++T) tile_step(TagSteady{}, T);
+#else
+  if (ntile > 0) tile_step(TagFirst{}, 0);
+  for (int T = 1; T < ntile; ++T) tile_step(TagSteady{}, T);
+#endif
 
   // drain: the last block step's accumulators (its set by the parity of the step count)
-  auto drain = [&](f32x16 (&last)[2]) LCE_LAMBDA_INLINE {
+  auto drain = [&](f32x16 (&last)[2], int slot) LCE_LAMBDA_INLINE {
+    if constexpr (KSPLIT) {
+      x_send(IntC<0>{}, last, slot); x_send(IntC<1>{}, last, slot); x_send(IntC<2>{}, last, slot); x_send(IntC<3>{}, last, slot);
+      block_barrier_keep_vm();
+      x_recv(slot);
+      x_add(IntC<0>{}, last); x_add(IntC<1>{}, last); x_add(IntC<2>{}, last); x_add(IntC<3>{}, last);
+    }
     wave_lds_order();
-    auto drain_a = [&](auto tc) LCE_LAMBDA_INLINE { epi_a(tc, last); };
+    auto drain_a = [&](auto tc) LCE_LAMBDA_INLINE {
+      if constexpr (decltype(tc)::value < NUA) epi_a(tc, last);
+    };
     drain_a(IntC<0>{}); drain_a(IntC<1>{}); drain_a(IntC<2>{}); drain_a(IntC<3>{});
     drain_a(IntC<4>{}); drain_a(IntC<5>{}); drain_a(IntC<6>{}); drain_a(IntC<7>{});
     drain_a(IntC<8>{}); drain_a(IntC<9>{}); drain_a(IntC<10>{}); drain_a(IntC<11>{});
     drain_a(IntC<12>{}); drain_a(IntC<13>{}); drain_a(IntC<14>{}); drain_a(IntC<15>{});
     if constexpr (SIGN) sign_store(epi_sob);
     wave_lds_fence();
-    epi_b(IntC<0>{}); epi_b(IntC<1>{}); epi_b(IntC<2>{}); epi_b(IntC<3>{});
-    epi_b(IntC<4>{}); epi_b(IntC<5>{}); epi_b(IntC<6>{}); epi_b(IntC<7>{});
-    epi_c(IntC<0>{}, epi_ob); epi_c(IntC<1>{}, epi_ob); epi_c(IntC<2>{}, epi_ob); epi_c(IntC<3>{}, epi_ob);
-    epi_c(IntC<4>{}, epi_ob); epi_c(IntC<5>{}, epi_ob); epi_c(IntC<6>{}, epi_ob); epi_c(IntC<7>{}, epi_ob);
+    auto drain_bc = [&](auto kc) LCE_LAMBDA_INLINE {
+      if constexpr (decltype(kc)::value < NUB) epi_b(kc);
+    };
+    drain_bc(IntC<0>{}); drain_bc(IntC<1>{}); drain_bc(IntC<2>{}); drain_bc(IntC<3>{});
+    drain_bc(IntC<4>{}); drain_bc(IntC<5>{}); drain_bc(IntC<6>{}); drain_bc(IntC<7>{});
+    auto drain_c = [&](auto kc) LCE_LAMBDA_INLINE {
+      if constexpr (decltype(kc)::value < NUB) epi_c(kc, epi_ob);
+    };
+    drain_c(IntC<0>{}); drain_c(IntC<1>{}); drain_c(IntC<2>{}); drain_c(IntC<3>{});
+    drain_c(IntC<4>{}); drain_c(IntC<5>{}); drain_c(IntC<6>{}); drain_c(IntC<7>{});
     if (epi_part) epi_partial(epi_u, epi_cx);
   };
-  if (usteps & 1) drain(acc[0]);
-  else drain(acc[1]);
+  // (a block without work -- past the launch's segments -- still takes part in the barriers of the pair exchange: every
+  //  wave of a block runs the same steps)
+  if (usteps & 1) drain(acc[0], 0);     // the last block step u = usteps - 1 is even: set 0, slot 0
+  else drain(acc[1], 1);
   LCE_SPH(63);
 }
 

@@ -336,20 +336,25 @@ bool stream_supported(const HostPlan& p) {
   if (d.dst_type == LCE_HIP_F32 && d.channels_out % 4) return false;
   if (d.dst_type == LCE_HIP_I8 && d.channels_out % 16) return false;
   const int kch = ceil_div(d.channels_in, 64);
-  return kch == 1 || kch == 2 || kch == 4;                                 // the filter bank must fit the register file
+  // the filter bank must fit the register file: up to 4 chunks of 64 input channels per wave, or 8 split over a pair of
+  // waves (KSPLIT, lce_kernels_stream.h)
+  return kch == 1 || kch == 2 || kch == 4 || kch == 8;
 }
 
 // Simulates a block's stream for segments of `rs` output rows, `spb` segments per block: what each tile step needs
 // resident, a production schedule in quotas of 256 items (one per lane; 512 where 256 would fall behind) that meets
 // it, and the ring rows that keep every row a tile step reads apart from every row it writes.
-static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, int* ring_rows, std::vector<uint32_t>* sched) {
+// flat: pixel blocks are cut from the CONCATENATED pixels of the block's segments (whole images whose pixel count is not a
+// multiple of 32 -- 7x7: 49 pixels would fill 77 % of two blocks): a block may then read rows of two segments.
+static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, bool flat, int* ring_rows, std::vector<uint32_t>* sched) {
   const lce_hip_bconv2d_desc& d = p.d;
   const int ow = p.out_w, kh = d.filter_height, sh = d.stride_height;
   const int srs = (rs - 1) * sh + kh, pbs = ceil_div(rs * ow, 32);
   const int cpw = ceil_div(d.channels_in, 64) * 2, qg = ceil_div(cpw, 4);
   const int64_t ipr = (int64_t)d.in_width * qg;
   const int pph = 1 << pph_log;
-  const int64_t nblk = (int64_t)spb * pbs;
+  const int64_t npx = (int64_t)rs * ow;
+  const int64_t nblk = flat ? (spb * npx + 31) / 32 : (int64_t)spb * pbs;
   const int64_t usteps = (nblk + pph - 1) / pph, ntile = (usteps + 3) / 4;
   const int64_t total = (int64_t)spb * srs * ipr;
   if (ntile < 1 || total >= (1ll << 31) || ntile > (1 << 20)) return false;
@@ -357,6 +362,12 @@ static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, int
   for (int64_t t = 0; t < ntile; ++t) {
     int64_t hi = 0, lo = INT64_MAX;
     for (int64_t q = 4 * t * pph; q < std::min<int64_t>(nblk, 4 * (t + 1) * pph); ++q) {
+      if (flat) {
+        const int64_t p0 = q * 32, p1 = std::min<int64_t>(q * 32 + 31, spb * npx - 1);   // first / last pixel of the block
+        lo = std::min(lo, (p0 / npx) * srs + (p0 % npx) / ow * sh);
+        hi = std::max(hi, (p1 / npx) * srs + (p1 % npx) / ow * sh + kh - 1);
+        continue;
+      }
       const int64_t gl = q / pbs, pb = q % pbs;
       const int64_t r_first = std::min<int64_t>(pb * 32 / ow, rs - 1), r_last = std::min<int64_t>((pb * 32 + 31) / ow, rs - 1);
       lo = std::min(lo, gl * srs + r_first * sh);
@@ -367,17 +378,19 @@ static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, int
   }
   need[ntile] = need[ntile + 1] = need[ntile - 1];
   for (int64_t t = 1; t < ntile; ++t) need[t] = std::max(need[t], need[t - 1]);
-  // latest production that still works with at most 512 items per tile step ...
+  // latest production that still works with at most 512 items per tile step (768 on the K-split kernel, whose pixels are
+  // four items wide: it weaves a second item between the MFMAs of block steps 2 and 3) ...
+  const int64_t cap = stream_ksplit(p) ? 768 : 512;
   std::vector<int64_t> m(ntile + 2), s(ntile + 2);
   m[ntile + 1] = m[ntile] = need[ntile];
-  for (int64_t t = ntile - 1; t >= 0; --t) m[t] = std::max(need[t], m[t + 1] - 512);
+  for (int64_t t = ntile - 1; t >= 0; --t) m[t] = std::max(need[t], m[t + 1] - cap);
   // ... and going forward, the smallest quota (nothing, one item per lane, two) that keeps up with it
   s[0] = m[0];
   for (int64_t t = 0; t <= ntile; ++t) {
     int64_t inc = 0;
     while (s[t] + inc < m[t + 1]) inc += 256;
     s[t + 1] = std::min(total, s[t] + inc);
-    if (s[t + 1] < m[t + 1] || inc > 512) return false;   // cannot happen (m is feasible by construction)
+    if (s[t + 1] < m[t + 1] || inc > cap) return false;   // cannot happen (m is feasible by construction)
   }
   int64_t rows = kh;
   for (int64_t t = 0; t < ntile; ++t)
@@ -396,14 +409,20 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!stream_supported(p))
     return "bconv2d: the streaming kernel runs ungrouped 3x3 convolutions without dilation, with at most 256 input "
-           "channels (64, 128 or 256 after padding) and whole 16-byte groups of output channels (float: a multiple of 4, "
+           "channels (64, 128 or 256 after padding; 512 on the K-split variant) and whole 16-byte groups of output channels (float: a multiple of 4, "
            "int8: of 16), and not the SAME-zero correction semantics";
   const uint32_t row_bytes = stream_row_bytes(p);
   if ((int64_t)batch_chunk * p.out_h * p.out_w * row_bytes >= (1ll << 31))
     return "bconv2d: the streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
   const int nsl = ceil_div(d.channels_out, 64);
-  const int pph_log = nsl >= 3 ? 0 : nsl == 2 ? 1 : 2;
-  const int nslb = 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
+  // waves of a block = (64-channel slices) x (pixel phases).  By default all four waves take slices when there are >= 3 of
+  // them; `stream_pixel_phases` forces the split (256 channels as 2 slices x 2 phases puts half the filter bank on a CU and
+  // two images' rows through it: the bank's arrival -- 295 KB per CU otherwise -- is what a single-round launch waits for)
+  int pph_log = nsl >= 3 ? 0 : nsl == 2 ? 1 : 2;
+  if (p.stream_phases_pref > 0) pph_log = std::max(pph_log, p.stream_phases_pref == 4 ? 2 : p.stream_phases_pref == 2 ? 1 : 0);
+  const bool ksplit = stream_ksplit(p);     // 512 input channels: waves = 2 slices x 2 K-halves, one pixel block per step
+  if (ksplit) pph_log = 0;
+  const int nslb = ksplit ? 2 : 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
   const int wp = (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
   const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16;
   // Ring row pitch.  An A-fragment read is one 16-byte piece per lane, lane = pixel; the LDS serves 16 lanes per pass without
@@ -431,7 +450,9 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     if (p.out_h % rs) continue;
     if (p.stream_rows_pref > 0 && rs != p.stream_rows_pref) continue;
     const int64_t s = (int64_t)batch_chunk * (p.out_h / rs), gx = std::min<int64_t>(s, cus), spb = (s + gx - 1) / gx;
-    const int64_t steps = (spb * ceil_div(rs * p.out_w, 32) + pph - 1) / pph;
+    const bool flat_c = rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
+    const int64_t blocks = flat_c ? (spb * rs * p.out_w + 31) / 32 : spb * ceil_div(rs * p.out_w, 32);
+    const int64_t steps = (blocks + pph - 1) / pph;
     cands.push_back(Cand{rs, steps + 4});
   }
   if (cands.empty()) return "bconv2d: stream_rows must divide the output height";
@@ -441,11 +462,16 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     const int64_t s = (int64_t)batch_chunk * spi, gx = std::min<int64_t>(s, cus), spb = (s + gx - 1) / gx;
     int rows = 0;
     std::vector<uint32_t> sched;
-    if (!simulate_stream(p, rs, (int)spb, pph_log, &rows, &sched)) continue;
+    // whole small images whose pixels do not fill 32-pixel blocks: cut the blocks from the block's images laid end to end
+    // (the output tensor is laid out that way: NHWC with nothing between images)
+    const bool flat = rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
+    if (!simulate_stream(p, rs, (int)spb, pph_log, flat, &rows, &sched)) continue;
     const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
-    if (ring + kStreamLdsExtra > 160 * 1024) continue;
+    if (ring + stream_lds_extra(p) > 160 * 1024) continue;
     const int pbs = ceil_div(rs * p.out_w, 32);
-    const int64_t nq = spb * pbs;
+    const int64_t nq = flat ? (spb * (int64_t)rs * p.out_w + 31) / 32 : spb * pbs;
+    p.st_flat = flat ? 1 : 0;
+    p.st_nq = (int)nq;
     if (nq * 1024 > (64ll << 20)) continue;               // the context table: 1 KiB per pixel block
     p.st_rs = rs; p.st_spi = spi; p.st_srs = (rs - 1) * d.stride_height + d.filter_height;
     p.st_pbs = pbs; p.st_pph_log = pph_log; p.st_ny = ny;
@@ -464,25 +490,33 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     std::copy(sched.begin(), sched.end(), p.st_tabs.begin());
     for (size_t i = sched.size(); i < n_sched; ++i) p.st_tabs[i] = sched.back();
     const int npx = rs * p.out_w, sh = d.stride_height, sw = d.stride_width;
-    const bool ragged = npx % 32 != 0;
+    const int64_t total_px = spb * (int64_t)npx;                             // flat: pixels of a full block's stream
+    const bool ragged = flat ? total_px % 32 != 0 : npx % 32 != 0;
+    // lanes that share a stored pixel row (lce_kernels_stream.h, LPR): the K-split kernel stores 32 channels per wave
+    const int lpr = d.dst_type == LCE_HIP_F32 ? (ksplit ? 8 : 16) : d.dst_type == LCE_HIP_I8 ? (ksplit ? 2 : 4) : 0;
     for (int64_t q = 0; q < nq; ++q) {
-      const int64_t gl = q / pbs, pb = q % pbs;
-      p.st_tabs[n_sched + q] = (uint32_t)std::min<int64_t>(31, npx - pb * 32 - 1);
+      // pixel block q = pixels [first, first + 32) of segment gl (flat: of the block's segments laid end to end)
+      const int64_t gl = flat ? 0 : q / pbs, pb = flat ? q : q % pbs;
+      const int64_t seg_px = flat ? total_px : npx;
+      const bool partial = ragged && (flat ? q == nq - 1 : pb == pbs - 1);
+      p.st_tabs[n_sched + q] = (uint32_t)std::min<int64_t>(31, seg_px - pb * 32 - 1);
       for (int lane = 0; lane < 64; ++lane) {
         const int l31 = lane & 31, half = lane >> 5;
-        const int64_t pix = std::min<int64_t>(pb * 32 + l31, npx - 1);     // rows past the segment re-read its last pixel
+        int64_t pix = std::min<int64_t>(pb * 32 + l31, seg_px - 1);          // rows past the segment re-read its last pixel
+        const int64_t sg_ = flat ? pix / npx : gl;                           // the segment the pixel lies in
+        if (flat) pix %= npx;
         const int64_t r = pix / p.out_w, ox = pix % p.out_w;
-        const int64_t s0 = gl * p.st_srs + r * sh;
+        const int64_t s0 = sg_ * p.st_srs + r * sh;
         uint32_t* e = &p.st_tabs[n_sched + n_lim + ((size_t)q * 64 + lane) * 4];
         for (int fy = 0; fy < 3; ++fy)
           e[fy] = (uint32_t)(((s0 + fy) % rows) * pitch + ox * sw * ps + half * 16);
-        const int rowl = d.dst_type == LCE_HIP_F32 ? lane >> 4 : d.dst_type == LCE_HIP_I8 ? lane >> 2 : l31;
+        const int rowl = lpr ? lane / lpr : l31;
         e[3] = (uint32_t)((gl * npx + pb * 32 + rowl) * (int64_t)row_bytes);
-        if (ragged && pb == pbs - 1) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
+        if (partial) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
         if (n_sgn) {
           uint32_t& sg = p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + (size_t)q * 64 + lane];
           sg = (uint32_t)((gl * npx + pb * 32 + l31) * (int64_t)p.wout * 4);
-          if (ragged && pb == pbs - 1) sg |= 0x80000000u;
+          if (partial) sg |= 0x80000000u;
         }
       }
     }
@@ -505,7 +539,13 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   // a smaller launch than the one planned for (the last chunk of a batch): the same segments and tables, fewer per block
   const int gx = std::min(G.S, std::max(1, p.num_cus / p.st_ny));
   G.SPB = std::min(p.st_spb, ceil_div(G.S, std::max(1, gx)));
+  // (flat pixel blocks are cut for runs of exactly st_spb segments: a shorter run's last block would spill into the next
+  //  block's pixels, so a smaller launch keeps the planned run length and uses fewer blocks)
+  if (p.st_flat) G.SPB = p.st_spb;
   G.pph_log = p.st_pph_log;
+  G.flat = p.st_flat;
+  G.NPX = p.st_rs * p.out_w;
+  G.NQ = p.st_nq;
   G.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
   G.w_bytes = (uint32_t)p.wq.size();
   G.out_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p));
@@ -784,12 +824,24 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
 // block GEMM a tile's whole 4x larger input neighbourhood): timed alone they gain 5-25 % (profiles/r03/stream_stride2.txt),
 // inside config 5's chain -- where every layer also writes its sign words -- nothing (0.2529 vs 0.2520 ms,
 // profiles/r03/strided_stream_chain.txt), so they stay where they were.
+// Which layers the planner tries the streaming kernel on by itself (everything else: engine=stream).  Measured against the
+// block GEMM at batch 256 (profiles/r03/stream_vs_block_gemm.txt, profiles/r04/ksplit_vs_block_gemm.txt):
+//   193..256 input channels, 192..256 output channels: 1.2-1.3x (L0, 14x14x256, 7x7x256);
+//   449..512 input channels (K split over wave pairs), >= 128 output channels: 7x7x512 1.1-1.25x, 7x7x512 -> 128 / 256 1.3-1.7x,
+//   7x7x512 stride 2 1.8x, 14x14x512 1.0-1.1x;
+//   64 / 128 input channels: slower (18 / 36 MFMAs per pixel block do not carry the epilogue) -- not tried.
 static bool stream_candidate(const HostPlan& p) {
-  return stream_supported(p) && ceil_div(p.d.channels_in, 64) == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
+  if (!stream_supported(p)) return false;
+  const int kch = ceil_div(p.d.channels_in, 64);
+#ifdef LCE_STREAM_AUTO_STRIDED   // (A/B aid: strided 3x3 layers of 128 / 256 input channels, any width of output)
+  if ((p.d.stride_height > 1 || p.d.stride_width > 1) && (kch == 2 || kch == 4) && p.d.channels_out >= 128) return true;
+#endif
+  if (kch == 8) return p.d.channels_out >= 128;
+  return kch == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
 }
 static bool stream_worthwhile(const HostPlan& p) {
   const int cus = std::max(1, p.num_cus / p.st_ny);
-  const int64_t steps = ((int64_t)p.st_spb * p.st_pbs + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
+  const int64_t steps = ((int64_t)p.st_nq + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
   // (segments of fewer than 4 rows re-expand their halo rows more than 1.5 times: left to the block GEMM)
 #ifndef LCE_STREAM_MIN_STEPS
 #define LCE_STREAM_MIN_STEPS 6
@@ -827,8 +879,10 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height, (int64_t)(p.out_h - 1) * d.stride_height + d.filter_height);
       if (repack && p.have_weights) pack_for_mfma(p);
       char nm[96];
-      snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d>",
-               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.st_rs);
+      char ph[16] = "";
+      if ((4 >> p.st_pph_log) < std::min(4, ceil_div(d.channels_out, 64))) snprintf(ph, sizeof ph, ",phases%d", 1 << p.st_pph_log);
+      snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d%s>",
+               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.st_rs, ph);
       p.kernel_name = nm;
       return "";
     }

@@ -481,6 +481,7 @@ TfLiteStatus Eval(TfLiteContext* context, TfLiteNode* node) {  // :550-564
   if (!in_resident && !readers.keep_on_device()) {
     // host in, host out: the pipelined path (batch slices on three streams); counted as one pass in each direction
     resident::count_host_pass(input->bytes, output->bytes);
+    resident::invalidate(context, op->out.tensor);      // (a device copy from an earlier invoke under a declaration is now stale)
     LCE_ENSURE_HIP(context, lce_hip_bconv2d_run_host(op->plan, input->data.i32, output->data.data));
     return kTfLiteOk;
   }

@@ -90,6 +90,7 @@ std::string g_err;
 void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call (float output, matrix-core engine)
 int g_num_cus = 256;          // what the streaming kernel's planner takes for the device's CU count
 int g_stream_rows = 0;        // its segment size (0 = auto)
+int g_stream_phases = 0;      // its pixel phases per block (0 = auto)
 int g_pw_nj = 0;              // the pointwise kernel's 32-channel tiles per block (0 = auto)
 
 }  // namespace
@@ -100,6 +101,7 @@ const char* hostsim_last_error() { return g_err.c_str(); }
 float hostsim_int8_below_threshold(int32_t zero_point) { return int8_below_threshold(zero_point); }
 void hostsim_set_sign_output(void* words) { g_sign_out = words; }
 void hostsim_set_stream(int num_cus, int rows) { g_num_cus = num_cus; g_stream_rows = rows; }
+void hostsim_set_stream_phases(int phases) { g_stream_phases = phases; }
 void hostsim_set_pointwise(int channel_tiles) { g_pw_nj = channel_tiles; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
@@ -116,6 +118,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   h.engine_pref = engine_pref;
   h.num_cus = g_num_cus;
   h.stream_rows_pref = g_stream_rows;
+  h.stream_phases_pref = g_stream_phases;
   h.pw_nj_pref = g_pw_nj;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};

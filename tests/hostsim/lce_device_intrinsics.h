@@ -179,6 +179,7 @@ inline void pin(f32x16&) {}
 inline void keep_in_agpr(u32x4&) {}
 inline void keep_in_vgpr(u32x4&) {}
 inline void keep_in_vgpr(float&) {}
+inline void keep_in_vgpr(int&) {}
 inline uint32_t sat_add_u32(uint32_t a, uint32_t b) { const uint64_t r = (uint64_t)a + b; return r > 0xffffffffull ? 0xffffffffu : (uint32_t)r; }
 inline void wave_lds_scratch_fence() { if (g_ctx.bar) { g_ctx.bar->arrive_and_wait(); } }
 template <int N> inline void yield_issue_slots() {}

@@ -85,6 +85,11 @@ def set_stream(num_cus: int = 256, rows: int = 0):
     lib().hostsim_set_stream(int(num_cus), int(rows))
 
 
+def set_stream_phases(phases: int = 0):
+    """The streaming kernel's pixel phases per block (0 = auto; 2 / 4: fewer channel slices per block, more blocks in y)."""
+    lib().hostsim_set_stream_phases(int(phases))
+
+
 def set_pointwise(channel_tiles: int = 0):
     """The pointwise kernel's 32-channel tiles per block (0 = auto: 1 for the small launches of these tests)."""
     lib().hostsim_set_pointwise(int(channel_tiles))

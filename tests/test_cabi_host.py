@@ -123,8 +123,12 @@ def test_kernel_selection_is_host_side_and_named():
     assert plan.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     plan.set_option("tile", "auto")
     plan.set_option("engine", "auto")
-    # small images share a tile (7x7: two whole images per 128-pixel tile)
+    # 512 input channels at batch 256 (round 4): the streaming kernel with the K dimension split over wave pairs, whole 7x7
+    # images per segment, pixel blocks cut across the four images of a block
     small = amd.Bconv2dPlan(amd.ConvParams(256, 7, 7, 512, 3, 3, 512, padding=amd.PADDING_SAME, pad_values=1))
+    assert small.kernel_name() == "bconv2d_stream<f32,3x3x512,rows7>"
+    # ... and on the block GEMM small images share a tile (7x7: two whole images per 128-pixel tile)
+    small.set_option("engine", "direct")
     assert small.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     # 2048 input channels: the LDS halo of any tile is too big -> workspace GEMM
     deep = amd.Bconv2dPlan(amd.ConvParams(8, 28, 28, 2048, 3, 3, 256, padding=amd.PADDING_SAME, pad_values=1))
@@ -176,10 +180,11 @@ def test_empty_batch_is_legal_and_a_no_op():
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
     (28, 128, "F32", "bconv2d_mfma_direct<f32,128x128>"),
     (14, 256, "F32", "bconv2d_stream<f32,3x3x256,rows14>"),
-    (7, 512, "F32", "bconv2d_mfma_direct<f32,128x128>"),           # two whole images per tile
+    (7, 512, "F32", "bconv2d_stream<f32,3x3x512,rows7>"),          # round 4: K split over wave pairs, blocks cut across 4 images
+    (7, 512, "I8", "bconv2d_stream<i8,3x3x512,rows7>"),
 ])
 def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
-    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v8.jsonl, profiles/r03/stream_vs_block_gemm.txt); this pins what it
+    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v8.jsonl, profiles/r03/stream_vs_block_gemm.txt, profiles/r04/ksplit_vs_block_gemm.txt); this pins what it
     picks for the BASELINE.json layers at batch 256 so that a planner edit shows up as a diff."""
     p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=getattr(amd, dst))
     assert amd.Bconv2dPlan(p).kernel_name() == want

@@ -672,7 +672,10 @@ def test_streaming_kernel_run_dual(shape):
 
 STREAM_GPU_SHAPES = [(3, 19, 23, 64, 64, (1, 1), "ONE"), (2, 14, 14, 256, 256, (1, 1), "ONE"), (5, 7, 7, 96, 320, (1, 1), "SAME"),
                      (2, 30, 9, 40, 96, (1, 1), "VALID"), (4, 28, 28, 128, 128, (1, 1), "ONE"), (3, 21, 17, 200, 304, (2, 2), "ONE"),
-                     (2, 16, 40, 256, 192, (1, 2), "ONE"), (300, 7, 7, 256, 256, (1, 1), "ONE"), (2, 56, 56, 200, 64, (2, 1), "VALID")]
+                     (2, 16, 40, 256, 192, (1, 2), "ONE"), (300, 7, 7, 256, 256, (1, 1), "ONE"), (2, 56, 56, 200, 64, (2, 1), "VALID"),
+                     # round 4: 512 input channels (K split over wave pairs), pixel blocks cut across small images
+                     (300, 7, 7, 512, 512, (1, 1), "ONE"), (5, 7, 7, 512, 128, (1, 1), "ONE"), (2, 9, 11, 480, 192, (1, 1), "SAME"),
+                     (3, 12, 10, 512, 64, (2, 2), "ONE"), (37, 6, 5, 512, 320, (1, 1), "VALID"), (70, 14, 14, 512, 256, (1, 1), "ONE")]
 
 
 @pytest.mark.parametrize("rows", [0, 1])

@@ -564,12 +564,79 @@ def test_stream_kernel(shape):
         H.set_stream(256, 0)
 
 
+@pytest.mark.parametrize("phases,cout,cus", [(2, 256, 4), (4, 256, 8), (2, 320, 4), (4, 128, 4)])
+def test_stream_kernel_with_forced_pixel_phases(phases, cout, cus):
+    """stream_pixel_phases: a block's four waves as 2 slices x 2 pixel blocks (or 1 x 4) also when there are >= 3 channel
+    slices -- half (a quarter) of the filter bank per block, grid.y picks the slices.  Same results, all output types;
+    the first block step takes its weights as they arrive (round 4), whatever the mapping."""
+    spec = O.ConvSpec(5, 14, 14, 256, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1)
+    H.set_stream(cus, 0)
+    H.set_stream_phases(phases)
+    try:
+        names = _run_all_dst_mfma(spec, seed=11 + phases + cout, max_batch=0, engine="stream")
+        assert all(n.startswith("bconv2d_stream<") and ",phases%d>" % phases in n for n in names), names
+    finally:
+        H.set_stream(256, 0)
+        H.set_stream_phases(0)
+
+
+KSPLIT_SHAPES = [
+    # batch, h, w, cin, cout, stride, padding, activation, compute units
+    (5, 7, 7, 512, 512, (1, 1), "ONE", O.ACT_NONE, 2),        # QuickNet's last section: 49-pixel images, blocks cut across images
+    (3, 7, 7, 512, 128, (1, 1), "ONE", O.ACT_RELU, 1),        # one block, both slices, one grid row
+    (2, 9, 11, 480, 192, (1, 1), "SAME", O.ACT_NONE, 2),      # a partial last chunk, exact SAME-zero, three slices: an idle wave pair
+    (2, 12, 10, 512, 64, (2, 2), "ONE", O.ACT_NONE, 1),       # one slice: the second pair of every block idles; strides
+    (3, 8, 8, 512, 320, (1, 1), "VALID", O.ACT_RELU6, 3),     # 64 pixels per image: whole blocks, no flat cut
+    (7, 6, 5, 512, 256, (1, 1), "ONE", O.ACT_NONE, 2),        # 30-pixel images, uneven runs (4 + 3 images)
+]
+
+
+@pytest.mark.parametrize("shape", KSPLIT_SHAPES, ids=lambda s: "%dx%dx%d_%d-%d_cu%d" % (s[0], s[1], s[2], s[3], s[4], s[8]))
+def test_stream_kernel_k_split_over_wave_pairs(shape):
+    """512 input channels on the streaming kernel (round 4): the K dimension split over a pair of waves, partial sums
+    swapped through LDS before a halved epilogue; pixel blocks cut from the block's images laid end to end where an
+    image does not fill 32-pixel blocks.  All three output types against the oracle, with batch chunking."""
+    b, h, w_, cin, cout, st, pad, act, cus = shape
+    padding, pad_values = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, act, O.SEM_REFERENCE)
+    H.set_stream(cus, 0)
+    try:
+        for mb in (0, 3):
+            names = _run_all_dst_mfma(spec, seed=cin + 3 * cout + b, max_batch=mb, engine="stream")
+            assert all(n.startswith("bconv2d_stream<") and "3x3x512" in n for n in names), names
+    finally:
+        H.set_stream(256, 0)
+
+
+@pytest.mark.parametrize("cin,cout", [(512, 256), (256, 256), (64, 128)])
+def test_stream_flat_pixel_blocks_second_output(cin, cout):
+    """Blocks cut across 7x7 images + the second (sign) output + int8: rows of two images in one pixel block."""
+    spec = O.ConvSpec(6, 7, 7, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_NONE)
+    x, w, mul, bias = synth.conv_inputs(spec, 5 + cin, negative_mul_fraction=0.3)
+    bias = (bias - np.median(O.bconv2d(spec, O.DST_F32, x, w, mul, bias), axis=(0, 1, 2))).astype(np.float32)
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    H.set_stream(2, 0)
+    try:
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="stream", sign_words=words)
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        assert name.startswith("bconv2d_stream<f32"), name
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+        assert np.array_equal(words, O.bitpack(want)), name
+        words[:] = 0x5A5A5A5A
+        got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=8.0, out_zero_point=2, engine="stream", sign_words=words)
+        want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=8.0, out_zero_point=2)
+        assert np.array_equal(got, want), name
+        assert np.array_equal(words, O.bitpack(want, 2)), name
+    finally:
+        H.set_stream(256, 0)
+
+
 def test_stream_kernel_refuses_what_it_cannot_run():
     x, w, mul, bias = synth.conv_inputs(O.ConvSpec(1, 6, 6, 64, 3, 3, 64), 1)
     for spec, why in [
         (O.ConvSpec(1, 6, 6, 64, 3, 3, 70, padding=O.PADDING_SAME, pad_values=1), "16-byte groups"),      # float: Cout % 4
         (O.ConvSpec(1, 6, 6, 64, 1, 1, 64), "3x3"),
-        (O.ConvSpec(1, 6, 6, 320, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "256 input"),
+        (O.ConvSpec(1, 6, 6, 320, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "256 after padding"),
         (O.ConvSpec(1, 8, 8, 64, 3, 3, 64, 1, 1, 1, 2, 2, O.PADDING_SAME, 1), "dilation"),
         (O.ConvSpec(1, 6, 6, 128, 3, 3, 128, 2, padding=O.PADDING_SAME, pad_values=1), "ungrouped"),
     ]:

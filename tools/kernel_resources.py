@@ -4,9 +4,15 @@ import re
 import subprocess
 import sys
 
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Icompute-engine_amd/csrc",
-       "-Rpass-analysis=kernel-resource-usage", "-c", "compute-engine_amd/csrc/lce_hip_api.hip", "-o", "/dev/null"]
-txt = subprocess.run(cmd, capture_output=True, text=True).stderr
+# one translation unit per kernel family (csrc/Makefile); only the streaming kernel's is built with -amdgpu-mfma-vgpr-form
+#   usage: kernel_resources.py [name filter] [tu ...]     (default: every translation unit)
+TUS = {"lce_tu_valu": [], "lce_tu_mfma_ws": [], "lce_tu_mfma_direct": [], "lce_tu_mfma_2d": [], "lce_tu_pointwise": [],
+       "lce_tu_stream": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+txt = ""
+for tu in (sys.argv[2:] or TUS):
+    cmd = ["hipcc", "-DLCE_PRODUCT_BUILD", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", *TUS[tu], "-Icompute-engine_amd/csrc",
+           "-Rpass-analysis=kernel-resource-usage", "-c", "compute-engine_amd/csrc/%s.hip" % tu, "-o", "/dev/null"]
+    txt += subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}
 for line in txt.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
