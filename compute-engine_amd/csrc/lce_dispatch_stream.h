@@ -10,7 +10,9 @@ namespace lce {
 // 3x3 filters over 64 / 128 / 256 / 512 (padded) input channels; FAST = every padded word exists and padding is +1;
 // CLAMP = the float transform's clamp is not the identity; SIGN = the epilogue also writes the output's LceQuantize
 template <int DST, bool FAST, bool CLAMP, bool SIGN>
-stream_fn stream_by_kch(int kch) {
+stream_fn stream_by_kch(int kch, bool strips) {
+  if (strips)     // column strips of wide images: built for the 256-channel bank (the north star's 224 x 224 x 256 maps)
+    return kch == 4 ? bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN, false, true> : nullptr;
   switch (kch) {
     case 8: return bconv2d_stream<DST, 3, 3, 8, FAST, CLAMP, SIGN, true>;     // 512 input channels: K split over wave pairs
     case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN>;
@@ -20,17 +22,17 @@ stream_fn stream_by_kch(int kch) {
   }
 }
 template <int DST, bool CLAMP, bool SIGN>
-stream_fn stream_by_fast(int kch, bool fast) {
-  return fast ? stream_by_kch<DST, true, CLAMP, SIGN>(kch) : stream_by_kch<DST, false, CLAMP, SIGN>(kch);
+stream_fn stream_by_fast(int kch, bool fast, bool strips) {
+  return fast ? stream_by_kch<DST, true, CLAMP, SIGN>(kch, strips) : stream_by_kch<DST, false, CLAMP, SIGN>(kch, strips);
 }
-inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign) {
+inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips = false) {
   switch (dst) {
     case LCE_HIP_F32:
-      if (clamp) return sign ? stream_by_fast<kDstFloat, true, true>(kch, fast) : stream_by_fast<kDstFloat, true, false>(kch, fast);
-      return sign ? stream_by_fast<kDstFloat, false, true>(kch, fast) : stream_by_fast<kDstFloat, false, false>(kch, fast);
+      if (clamp) return sign ? stream_by_fast<kDstFloat, true, true>(kch, fast, strips) : stream_by_fast<kDstFloat, true, false>(kch, fast, strips);
+      return sign ? stream_by_fast<kDstFloat, false, true>(kch, fast, strips) : stream_by_fast<kDstFloat, false, false>(kch, fast, strips);
     case LCE_HIP_I8:
-      return sign ? stream_by_fast<kDstInt8, false, true>(kch, fast) : stream_by_fast<kDstInt8, false, false>(kch, fast);
-    default: return stream_by_fast<kDstBitpacked, false, false>(kch, fast);
+      return sign ? stream_by_fast<kDstInt8, false, true>(kch, fast, strips) : stream_by_fast<kDstInt8, false, false>(kch, fast, strips);
+    default: return stream_by_fast<kDstBitpacked, false, false>(kch, fast, strips);
   }
 }
 

@@ -516,6 +516,14 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     plan->device_current = false;
     return LCE_HIP_OK;
   }
+  if (!strcmp(key, "stream_strip")) {      // testing aid for the streaming kernel: -1 auto, 0 never, else the column strip's width
+    const int v = atoi(value);
+    if (v < -1 || (v == 0 && strcmp(value, "0"))) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_strip must be -1 (auto), 0 (whole rows) or a strip width");
+    h.stream_strip_pref = v;
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "stream_flat")) {       // testing aid for the streaming kernel: 0 = never cut pixel blocks across a block's images
     if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_flat must be 0 or 1");
     h.stream_noflat = value[0] == '0';
@@ -641,7 +649,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       if (lce_hip_status s = mfma_selftest_once(plan->device, 1)) return s;
       const lce::StreamArgs G = lce::make_stream_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
-      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign);
+      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign, G.NSTRIP > 1);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::stream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {

@@ -152,6 +152,10 @@ struct StreamArgs {
   int32_t S;                   // segments of this launch = B * SPI
   int32_t SPB;                 // segments per block
   int32_t pph_log;             // log2 of the pixel blocks per block step: 4 waves = (4 >> pph_log) channel slices x that
+  // STRIPS (images too wide for a whole padded row per ring slot): a segment is RS output rows x WSo output COLUMNS; segments are
+  // numbered (image, strip, row segment), a block's run stays inside one strip.  A ring row then holds the strip's Wp = (WSo-1)*SW+KW
+  // input columns, halo included; columns outside the image read as padding like rows do.  NSTRIP = 1: off (WSo = OW, RSEG = SPI).
+  int32_t NSTRIP, RSEG, WSo, XS0;   // strips per image, row segments per image (SPI = NSTRIP * RSEG), output columns per strip, left padding of the image
   int32_t flat;                // 1: pixel blocks are cut from the block's segments laid end to end (NPX pixels each)
   int32_t NPX;                 // output pixels per segment = RS * OW
   int32_t NQ;                  // pixel blocks of a full block's stream = rows of the context table
@@ -160,9 +164,10 @@ struct StreamArgs {
   // last real row); ctx: 16 bytes per (pixel block, lane) = {tap-row LDS addresses 0..2, output byte offset}
   // sgn (float / int8 plans): one dword per (pixel block, lane): the pixel row's byte offset in the sign-word tensor
   uint32_t tab_bytes, tab_lim, tab_ctx, tab_sgn;
+  uint32_t tab_seg;                        // STRIPS: one dword per pixel block: the local segment it lies in
   uint32_t sign_bytes;                     // bytes of the second output of this launch (B * OH * OW * Wout * 4)
   float a_bt, cmin, cmax, bit_thr;
-  FastDiv div_ipr, div_qg, div_srs, div_spi, div_r;
+  FastDiv div_ipr, div_qg, div_srs, div_spi, div_r, div_rseg;
 };
 
 }  // namespace lce

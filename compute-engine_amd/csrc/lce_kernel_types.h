@@ -36,7 +36,7 @@ int launch_expand_fp4(unsigned grid_x, void* stream, const uint32_t* in, void* w
 // lce_tu_pointwise.hip
 pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided);
 // lce_tu_stream.hip
-stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign);
+stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips);
 // known-answer test of the unscaled FP4 MFMA as each of those two translation units compiled it (lce_mfma_selftest.h):
 // 0 = as assumed, 1 = wrong products, < 0 = -(hipError_t)
 int mfma_selftest_pointwise();

@@ -84,7 +84,10 @@ constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 // transforms and stores ITS 32 channels.  A-fragment traffic stays at one 1-KiB read per two MFMAs.  So that all register
 // indices are static, a wave's LOCAL tile 0 is the one it finalises: the K-half-1 wave holds the slice's two channel
 // tiles in swapped order.  Block = 2 channel slices x 2 K-halves, one pixel block per block step.
-template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false>
+// STRIPS (round 4; wide images): a segment is a run of output rows of ONE column strip of an image (StreamArgs), so that a ring
+// row is a strip's width + halo instead of the whole padded row (224 x 144 B x 9-12 slots do not fit LDS).  Only the production's
+// address arithmetic and the block's first output pixel differ; a strip is a multiple of 32 columns, so a pixel block never wraps.
+template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false, bool STRIPS = false>
 LCE_KERNEL void __launch_bounds__(256, 1)
 bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
                const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
@@ -148,8 +151,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // in the K loop a chunk rides behind one MFMA.
   const rsrc_t rin = make_rsrc(xin, G.in_bytes);
   struct Issue {
-    uint32_t s, rem, x, gl, g, img, slot, t;
-    int c0, iy, cseg;
+    uint32_t s, rem, x, gl, g, img, slot, t, strip;
+    int c0, iy, ix, cseg;
     bool on, inside;
   };
   constexpr int kIssueChunks = 12;
@@ -170,9 +173,17 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     } else if constexpr (c == 4) {
       I.cseg = (int)(I.g - I.img * (uint32_t)G.SPI);
       I.iy = (int)(I.s - I.gl * (uint32_t)G.SRS) - G.PH;
+      if constexpr (STRIPS) I.strip = fastdiv_nb((uint32_t)I.cseg, G.div_rseg);      // segment in image = (strip, row segment)
     } else if constexpr (c == 5) {
-      I.iy += I.cseg * (G.RS * G.SH);
-      I.inside = I.on && (uint32_t)I.iy < (uint32_t)G.H && I.img < (uint32_t)G.B;
+      if constexpr (STRIPS) {
+        I.cseg -= (int)I.strip * G.RSEG;
+        I.ix = (int)I.x + (int)I.strip * (G.WSo * G.SW) - G.XS0;                      // the strip's column in the image
+        I.iy += I.cseg * (G.RS * G.SH);
+        I.inside = I.on && (uint32_t)I.iy < (uint32_t)G.H && (uint32_t)I.ix < (uint32_t)G.W && I.img < (uint32_t)G.B;
+      } else {
+        I.iy += I.cseg * (G.RS * G.SH);
+        I.inside = I.on && (uint32_t)I.iy < (uint32_t)G.H && I.img < (uint32_t)G.B;
+      }
     } else if constexpr (c == 6) {
       I.slot = I.s - fastdiv_nb(I.s, G.div_r) * (uint32_t)G.R;
     } else if constexpr (c == 7) {
@@ -183,7 +194,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     } else if constexpr (c == 9) {
       I.t = (uint32_t)((int)I.img * G.H + I.iy) * (uint32_t)G.W;
     } else if constexpr (c == 10) {
-      I.t = (I.t + I.x) * (uint32_t)G.Cw * 4u + (uint32_t)I.c0 * 4u;
+      I.t = (I.t + (STRIPS ? (uint32_t)I.ix : I.x)) * (uint32_t)G.Cw * 4u + (uint32_t)I.c0 * 4u;
     } else {
       const uint32_t off = I.t;
       if constexpr (FAST && KCH == 1) {
@@ -313,7 +324,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // The ring's padding COLUMNS (pixels left of PW and right of PW + W in every row slot) are +1 codes, or zeros for
   // exact SAME-zero, for good: production only ever writes pixels PW .. PW + W - 1 of a slot (padding ROWS are
   // produced like any other row, from out-of-range loads).
-  {
+  if constexpr (!STRIPS) {      // (a strip's ring row has no constant columns: its halo is produced like everything else)
     const uint32_t code = G.zero_border ? 0u : 0x22222222u;
     const u32x4 v = {code, code, code, code};
     const int padc = G.Wp - G.W;                               // padding pixels per slot
@@ -422,7 +433,23 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   } else {
     chan_off = lane < 32 ? (uint32_t)(n0 >> 5) * 4u : kOobOffset;      // lane p owns pixel row p: two words
   }
-  chan_off += (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * row_bytes;      // < 2^31 with the whole output
+  // the block's first output pixel: segments are RS whole rows apart.  STRIPS: a run may pass from one strip (or image) to the
+  // next, so every local segment's first pixel is worked out here, once, into a small LDS table (segbase: byte offsets into the
+  // output and into the sign words); the context table's offsets are then relative to the pixel block's SEGMENT
+  const uint32_t first_px = STRIPS ? 0u : (uint32_t)g0 * (uint32_t)(G.RS * G.OW);
+  uint32_t* const segbase = (uint32_t*)(lds0 + G.ring_bytes + 4 * SCRB + 4096);      // [SPB][2]
+  if constexpr (STRIPS) {
+    for (int gl = tid; gl < G.SPB; gl += 256) {
+      const uint32_t g = (uint32_t)(g0 + gl);
+      const uint32_t img = fastdiv_nb(g, G.div_spi), rem = g - img * (uint32_t)G.SPI;
+      const uint32_t strip = fastdiv_nb(rem, G.div_rseg), rowseg = rem - strip * (uint32_t)G.RSEG;
+      const uint32_t px = (img * (uint32_t)G.OH + rowseg * (uint32_t)G.RS) * (uint32_t)G.OW + strip * (uint32_t)G.WSo;
+      segbase[2 * gl + 0] = px * row_bytes;
+      segbase[2 * gl + 1] = px * (uint32_t)G.Wout * 4u;
+    }
+    block_barrier_keep_vm();
+  }
+  chan_off += first_px * row_bytes;      // < 2^31 with the whole output
   const int nq = G.NQ;
   auto load_ctx = [&](int u, Ctx& cx) LCE_LAMBDA_INLINE {
     int q = (u << G.pph_log) + pp;
@@ -440,11 +467,16 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     const uint32_t mark = (u << G.pph_log) + pp == dyn_last ? 0x80000000u : 0u;
     cx.t[3] |= mark;
     if constexpr (SIGN) cx.s |= mark;
+    if constexpr (STRIPS) {            // the segment's place in the output (a strip run may cross strips and images)
+      const int gl = (int)tabs[G.tab_seg / 4 + q];
+      cx.t[3] += segbase[2 * gl + 0];
+      if constexpr (SIGN) cx.s += segbase[2 * gl + 1];
+    }
   };
   // second output: lane p (< 32) owns pixel row p's two sign words of this wave's 64 channels
   const rsrc_t rsgn = make_rsrc(sign_words, SIGN ? G.sign_bytes : 0u);
   const uint32_t sign_chan_off = lane < 32 && (!KSPLIT || (nown >> 5) < G.Wout)
-                                     ? (uint32_t)((KSPLIT ? nown : n0) >> 5) * 4u + (uint32_t)g0 * (uint32_t)(G.RS * G.OW) * (uint32_t)G.Wout * 4u
+                                     ? (uint32_t)((KSPLIT ? nown : n0) >> 5) * 4u + first_px * (uint32_t)G.Wout * 4u
                                      : kOobOffset;
   auto sign_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
     const int q = (u << G.pph_log) + pp;

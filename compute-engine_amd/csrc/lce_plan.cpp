@@ -346,12 +346,13 @@ bool stream_supported(const HostPlan& p) {
 // it, and the ring rows that keep every row a tile step reads apart from every row it writes.
 // flat: pixel blocks are cut from the CONCATENATED pixels of the block's segments (whole images whose pixel count is not a
 // multiple of 32 -- 7x7: 49 pixels would fill 77 % of two blocks): a block may then read rows of two segments.
-static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, bool flat, int* ring_rows, std::vector<uint32_t>* sched) {
+// ow / in_w: output columns and input columns (halo included) of a segment -- the whole row, or one column strip of it.
+static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, bool flat, int ow, int in_w, int* ring_rows, std::vector<uint32_t>* sched) {
   const lce_hip_bconv2d_desc& d = p.d;
-  const int ow = p.out_w, kh = d.filter_height, sh = d.stride_height;
+  const int kh = d.filter_height, sh = d.stride_height;
   const int srs = (rs - 1) * sh + kh, pbs = ceil_div(rs * ow, 32);
   const int cpw = ceil_div(d.channels_in, 64) * 2, qg = ceil_div(cpw, 4);
-  const int64_t ipr = (int64_t)d.in_width * qg;
+  const int64_t ipr = (int64_t)in_w * qg;
   const int pph = 1 << pph_log;
   const int64_t npx = (int64_t)rs * ow;
   const int64_t nblk = flat ? (spb * npx + 31) / 32 : (int64_t)spb * pbs;
@@ -405,6 +406,8 @@ static uint32_t stream_row_bytes(const HostPlan& p) {
   return p.d.dst_type == LCE_HIP_BITPACKED ? (uint32_t)p.wout * 4u : (uint32_t)p.d.channels_out * (p.d.dst_type == LCE_HIP_I8 ? 1u : 4u);
 }
 
+static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::string* why);
+
 std::string plan_stream(HostPlan& p, int batch_chunk) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!stream_supported(p))
@@ -414,6 +417,34 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   const uint32_t row_bytes = stream_row_bytes(p);
   if ((int64_t)batch_chunk * p.out_h * p.out_w * row_bytes >= (1ll << 31))
     return "bconv2d: the streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
+  // Whole rows first; an image too wide for that (the ring holds 9-12 padded rows: 224 x 144 B x 12 does not fit) is cut into
+  // column strips of 64 or 32 output columns (round 4; instances exist for the 256-channel bank).
+  std::vector<int> widths;
+  if (p.stream_strip_pref <= 0) widths.push_back(0);
+  if (ceil_div(d.channels_in, 64) == 4 && p.stream_strip_pref != 0) {
+    if (p.stream_strip_pref > 0) {
+      if (p.stream_strip_pref % 32 != 0 || p.out_w % p.stream_strip_pref != 0)
+        return "bconv2d: stream_strip must be a multiple of 32 that divides the output width";
+      widths.push_back(p.stream_strip_pref);
+    } else if (p.out_w % 32 == 0 && p.out_w > 64) {
+      if (p.out_w % 64 == 0) widths.push_back(64);
+      widths.push_back(32);
+    }
+  }
+  std::string why = "bconv2d: the streaming kernel's row ring does not fit LDS for this layer";
+  for (int wso : widths)
+    if (plan_stream_geometry(p, batch_chunk, wso, &why)) return "";
+  return why;
+}
+
+// One attempt: segments of whole rows (wso == 0) or of column strips `wso` output columns wide.
+static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::string* why) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const uint32_t row_bytes = stream_row_bytes(p);
+  const bool strips = wso > 0;
+  const int nstrip = strips ? p.out_w / wso : 1;
+  const int ow_seg = strips ? wso : p.out_w;                                                  // output columns of a segment
+  const int in_w_seg = strips ? (wso - 1) * d.stride_width + d.filter_width : d.in_width;     // input columns a ring row holds
   const int nsl = ceil_div(d.channels_out, 64);
   // waves of a block = (64-channel slices) x (pixel phases).  By default all four waves take slices when there are >= 3 of
   // them; `stream_pixel_phases` forces the split (256 channels as 2 slices x 2 phases puts half the filter bank on a CU and
@@ -423,7 +454,8 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   const bool ksplit = stream_ksplit(p);     // 512 input channels: waves = 2 slices x 2 K-halves, one pixel block per step
   if (ksplit) pph_log = 0;
   const int nslb = ksplit ? 2 : 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
-  const int wp = (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
+  const int wp = strips ? in_w_seg
+                        : (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
   const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16;
   // Ring row pitch.  An A-fragment read is one 16-byte piece per lane, lane = pixel; the LDS serves 16 lanes per pass without
   // conflicts when their 16-byte units differ mod 16.  Along a row consecutive pixels are ps / 16 (odd) units apart: fine.
@@ -432,7 +464,7 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   // PMC: 21 % of the LDS pipe's cycles on L0, 39 % on 14x14x256).  A skew of < 256 bytes per row makes the sequence continue
   // across the wrap: SH * pitch / 16 = OW * SW * ps / 16 (mod 16).  (Solvable when SH is odd; otherwise no skew.)
   int skew16 = 0;
-  if (d.stride_height % 2 == 1) {
+  if (d.stride_height % 2 == 1 && !strips) {     // (a strip is a multiple of 32 columns: a pixel block never wraps)
     const int want = (int)(((int64_t)p.out_w * d.stride_width * (ps / 16)) % 16);
     for (int k = 0; k < 16; ++k)
       if (((int64_t)d.stride_height * ((int64_t)wp * (ps / 16) + k)) % 16 == want) { skew16 = k; break; }
@@ -444,38 +476,49 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   const int cus = std::max(1, p.num_cus / ny);
   // segment size (a divisor of the output height: every segment is whole): the fewest block steps on the busiest
   // block (ties: the longer segment, whose halo is re-expanded less)
+  // segments per block: as many as spread the launch over the CUs (a strip run may pass into the next strip or image: the
+  // kernel works out every segment's place in the output)
+  auto run_length = [&](int rseg) -> int64_t {
+    const int64_t s = (int64_t)batch_chunk * nstrip * rseg, gx = std::min<int64_t>(s, cus);
+    const int64_t spb = (s + gx - 1) / gx;
+    return strips ? std::min<int64_t>(spb, 128) : spb;      // (the kernel's per-run segment table holds 128 entries)
+  };
   struct Cand { int rs; int64_t cost; };
   std::vector<Cand> cands;
   for (int rs = p.out_h; rs >= 1; --rs) {
     if (p.out_h % rs) continue;
     if (p.stream_rows_pref > 0 && rs != p.stream_rows_pref) continue;
-    const int64_t s = (int64_t)batch_chunk * (p.out_h / rs), gx = std::min<int64_t>(s, cus), spb = (s + gx - 1) / gx;
-    const bool flat_c = rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
-    const int64_t blocks = flat_c ? (spb * rs * p.out_w + 31) / 32 : spb * ceil_div(rs * p.out_w, 32);
+    const int64_t spb = run_length(p.out_h / rs), s = (int64_t)batch_chunk * nstrip * (p.out_h / rs);
+    const bool flat_c = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
+    const int64_t blocks = flat_c ? (spb * rs * p.out_w + 31) / 32 : spb * ceil_div(rs * ow_seg, 32);
+    const int64_t rounds = (ceil_div((int)s, (int)spb) + cus - 1) / cus;      // (strips: more blocks than CUs run in rounds)
     const int64_t steps = (blocks + pph - 1) / pph;
-    cands.push_back(Cand{rs, steps + 4});
+    // (ties, strips: segments of about 14 rows -- 224x224x256 measured 0.194 ms with 14-row segments, 0.201 with 28 / 56 / 112,
+    //  profiles/r04/strips_224.txt; whole rows: the longer one, whose halo rows are re-expanded less)
+    cands.push_back(Cand{rs, (steps + 4) * rounds * 4096 + (strips ? std::abs(rs - 14) : 0)});
   }
-  if (cands.empty()) return "bconv2d: stream_rows must divide the output height";
+  if (cands.empty()) { *why = "bconv2d: stream_rows must divide the output height"; return false; }
   std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.cost < b.cost; });
   for (const Cand& c : cands) {
-    const int rs = c.rs, spi = p.out_h / rs;
-    const int64_t s = (int64_t)batch_chunk * spi, gx = std::min<int64_t>(s, cus), spb = (s + gx - 1) / gx;
+    const int rs = c.rs, rseg = p.out_h / rs, spi = nstrip * rseg;
+    const int64_t s = (int64_t)batch_chunk * spi, spb = run_length(rseg);
     int rows = 0;
     std::vector<uint32_t> sched;
     // whole small images whose pixels do not fill 32-pixel blocks: cut the blocks from the block's images laid end to end
     // (the output tensor is laid out that way: NHWC with nothing between images)
-    const bool flat = rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
-    if (!simulate_stream(p, rs, (int)spb, pph_log, flat, &rows, &sched)) continue;
+    const bool flat = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
+    if (!simulate_stream(p, rs, (int)spb, pph_log, flat, ow_seg, in_w_seg, &rows, &sched)) continue;
     const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
     if (ring + stream_lds_extra(p) > 160 * 1024) continue;
-    const int pbs = ceil_div(rs * p.out_w, 32);
+    const int pbs = ceil_div(rs * ow_seg, 32);
     const int64_t nq = flat ? (spb * (int64_t)rs * p.out_w + 31) / 32 : spb * pbs;
     p.st_flat = flat ? 1 : 0;
     p.st_nq = (int)nq;
     if (nq * 1024 > (64ll << 20)) continue;               // the context table: 1 KiB per pixel block
     p.st_rs = rs; p.st_spi = spi; p.st_srs = (rs - 1) * d.stride_height + d.filter_height;
     p.st_pbs = pbs; p.st_pph_log = pph_log; p.st_ny = ny;
-    p.st_qg = ceil_div(kch * 2, 4); p.st_ipr = d.in_width * p.st_qg;
+    p.st_qg = ceil_div(kch * 2, 4); p.st_ipr = in_w_seg * p.st_qg;
+    p.st_nstrip = nstrip; p.st_rseg = rseg; p.st_wso = ow_seg;
     p.st_spb = (int)spb; p.st_gx = (int)ceil_div((int)s, (int)spb); p.st_rows = rows; p.st_ring_bytes = (int)ring;
     p.st_batch = batch_chunk;
     p.wp = wp;
@@ -483,13 +526,15 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     // ---- the tables: [sched | lim | ctx] ----
     const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
     const size_t n_sgn = d.dst_type == LCE_HIP_BITPACKED ? 0 : (size_t)nq * 64;
+    const size_t n_seg = strips ? ((size_t)nq + 3) / 4 * 4 : 0;
     p.st_tab_lim = (uint32_t)(n_sched * 4);
     p.st_tab_ctx = (uint32_t)((n_sched + n_lim) * 4);
     p.st_tab_sgn = (uint32_t)((n_sched + n_lim + (size_t)nq * 256) * 4);
-    p.st_tabs.assign(n_sched + n_lim + (size_t)nq * 256 + n_sgn, 0u);
+    p.st_tab_seg = (uint32_t)((n_sched + n_lim + (size_t)nq * 256 + n_sgn) * 4);
+    p.st_tabs.assign(n_sched + n_lim + (size_t)nq * 256 + n_sgn + n_seg, 0u);
     std::copy(sched.begin(), sched.end(), p.st_tabs.begin());
     for (size_t i = sched.size(); i < n_sched; ++i) p.st_tabs[i] = sched.back();
-    const int npx = rs * p.out_w, sh = d.stride_height, sw = d.stride_width;
+    const int npx = rs * ow_seg, sh = d.stride_height, sw = d.stride_width;
     const int64_t total_px = spb * (int64_t)npx;                             // flat: pixels of a full block's stream
     const bool ragged = flat ? total_px % 32 != 0 : npx % 32 != 0;
     // lanes that share a stored pixel row (lce_kernels_stream.h, LPR): the K-split kernel stores 32 channels per wave
@@ -505,24 +550,29 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
         int64_t pix = std::min<int64_t>(pb * 32 + l31, seg_px - 1);          // rows past the segment re-read its last pixel
         const int64_t sg_ = flat ? pix / npx : gl;                           // the segment the pixel lies in
         if (flat) pix %= npx;
-        const int64_t r = pix / p.out_w, ox = pix % p.out_w;
+        const int64_t r = pix / ow_seg, ox = pix % ow_seg;
         const int64_t s0 = sg_ * p.st_srs + r * sh;
         uint32_t* e = &p.st_tabs[n_sched + n_lim + ((size_t)q * 64 + lane) * 4];
         for (int fy = 0; fy < 3; ++fy)
           e[fy] = (uint32_t)(((s0 + fy) % rows) * pitch + ox * sw * ps + half * 16);
         const int rowl = lpr ? lane / lpr : l31;
-        e[3] = (uint32_t)((gl * npx + pb * 32 + rowl) * (int64_t)row_bytes);
+        // output pixel of the lane's first stored row, relative to the run's first pixel: segments and their pixels follow each
+        // other in memory -- or (strips) a segment's rows are OW pixels apart and a pixel block lies inside one of them
+        // (strips: relative to the SEGMENT's first pixel; the kernel adds the segment's place)
+        const int64_t blk_px = strips ? ((pb * 32) / ow_seg) * (int64_t)p.out_w + (pb * 32) % ow_seg : gl * npx + pb * 32;
+        e[3] = (uint32_t)((blk_px + rowl) * (int64_t)row_bytes);
         if (partial) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
+        if (strips) p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + n_sgn + q] = (uint32_t)gl;
         if (n_sgn) {
           uint32_t& sg = p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + (size_t)q * 64 + lane];
-          sg = (uint32_t)((gl * npx + pb * 32 + l31) * (int64_t)p.wout * 4);
+          sg = (uint32_t)((blk_px + l31) * (int64_t)p.wout * 4);
           if (partial) sg |= 0x80000000u;
         }
       }
     }
-    return "";
+    return true;
   }
-  return "bconv2d: the streaming kernel's row ring does not fit LDS for this layer";
+  return false;
 }
 
 StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
@@ -530,7 +580,9 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   StreamArgs G{};
   G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
   G.OH = p.out_h; G.OW = p.out_w; G.N = d.channels_out; G.Npad = p.npad; G.Wout = p.wout;
-  G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h; G.PW = p.pad_w;
+  G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h;
+  G.PW = p.st_nstrip > 1 ? 0 : p.pad_w;      // (a strip's ring row starts at its first input column, halo or padding)
+  G.NSTRIP = p.st_nstrip; G.RSEG = p.st_rseg; G.WSo = p.st_wso; G.XS0 = p.pad_w;
   G.B = batch_chunk;
   G.Wp = p.wp; G.pitch = p.st_pitch; G.R = p.st_rows; G.ring_bytes = p.st_ring_bytes;
   G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
@@ -553,6 +605,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.tab_lim = p.st_tab_lim;
   G.tab_ctx = p.st_tab_ctx;
   G.tab_sgn = p.st_tab_sgn;
+  G.tab_seg = p.st_tab_seg;
   G.sign_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * p.wout * 4);
   G.bit_thr = p.bit_thr;
   G.a_bt = (float)p.backtransform_add;
@@ -563,6 +616,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.div_srs = make_fastdiv((uint32_t)G.SRS);
   G.div_spi = make_fastdiv((uint32_t)G.SPI);
   G.div_r = make_fastdiv((uint32_t)G.R);
+  G.div_rseg = make_fastdiv((uint32_t)std::max(1, G.RSEG));
   return G;
 }
 
@@ -879,8 +933,9 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height, (int64_t)(p.out_h - 1) * d.stride_height + d.filter_height);
       if (repack && p.have_weights) pack_for_mfma(p);
       char nm[96];
-      char ph[16] = "";
+      char ph[40] = "";
       if ((4 >> p.st_pph_log) < std::min(4, ceil_div(d.channels_out, 64))) snprintf(ph, sizeof ph, ",phases%d", 1 << p.st_pph_log);
+      if (p.st_nstrip > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",strips%d", p.st_wso);
       snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d%s>",
                d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.st_rs, ph);
       p.kernel_name = nm;

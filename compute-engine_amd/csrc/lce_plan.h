@@ -95,11 +95,13 @@ struct HostPlan {
   int stream_phases_pref = 0;              // tuning aid: pixel phases per block (0 = auto, else 1, 2 or 4: 4 / phases channel slices)
   int st_rs = 0, st_spi = 0, st_srs = 0, st_pbs = 0, st_pph_log = 0, st_ny = 1, st_qg = 0, st_ipr = 0;
   int st_pitch = 0;                          // bytes per ring row slot
+  int st_nstrip = 1, st_rseg = 0, st_wso = 0;   // column strips of wide images: strips per image, row segments per image, output columns per strip
+  int stream_strip_pref = -1;                // testing aid: -1 auto, 0 never, else the strip width (a multiple of 32 that divides the output width)
   int st_flat = 0;                           // 1: 32-pixel blocks are cut from the concatenated pixels of a block's segments (whole small images)
   int st_nq = 0;                             // pixel blocks of a full block's stream (rows of the context table)
   int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images
   std::vector<uint32_t> st_tabs;           // [sched | lim | ctx]: the kernel's tables (lce_kernel_args.h, StreamArgs)
-  uint32_t st_tab_lim = 0, st_tab_ctx = 0, st_tab_sgn = 0;   // byte offsets of lim / ctx / sgn inside st_tabs
+  uint32_t st_tab_lim = 0, st_tab_ctx = 0, st_tab_sgn = 0, st_tab_seg = 0;   // byte offsets of lim / ctx / sgn inside st_tabs
 
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
@@ -156,7 +158,7 @@ constexpr int kStreamLdsExtra = 4 * 8192 + 4096;   // four waves' epilogue scrat
 // slots per wave for the pair's partial sums
 constexpr int kStreamLdsExtraKsplit = 4 * 4096 + 4096 + 4 * 8192;
 inline bool stream_ksplit(const HostPlan& p) { return (p.d.channels_in + 63) / 64 > 4; }
-inline int stream_lds_extra(const HostPlan& p) { return stream_ksplit(p) ? kStreamLdsExtraKsplit : kStreamLdsExtra; }
+inline int stream_lds_extra(const HostPlan& p) { return stream_ksplit(p) ? kStreamLdsExtraKsplit : kStreamLdsExtra + 1024; }   // (+ the strips' segment table)
 inline int stream_lds_bytes(const HostPlan& p) { return p.st_ring_bytes + stream_lds_extra(p); }
 
 }  // namespace lce

@@ -91,6 +91,7 @@ void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call 
 int g_num_cus = 256;          // what the streaming kernel's planner takes for the device's CU count
 int g_stream_rows = 0;        // its segment size (0 = auto)
 int g_stream_phases = 0;      // its pixel phases per block (0 = auto)
+int g_stream_strip = -1;      // its column strips (-1 auto, 0 never, else the width)
 int g_pw_nj = 0;              // the pointwise kernel's 32-channel tiles per block (0 = auto)
 
 }  // namespace
@@ -102,6 +103,7 @@ float hostsim_int8_below_threshold(int32_t zero_point) { return int8_below_thres
 void hostsim_set_sign_output(void* words) { g_sign_out = words; }
 void hostsim_set_stream(int num_cus, int rows) { g_num_cus = num_cus; g_stream_rows = rows; }
 void hostsim_set_stream_phases(int phases) { g_stream_phases = phases; }
+void hostsim_set_stream_strip(int width) { g_stream_strip = width; }
 void hostsim_set_pointwise(int channel_tiles) { g_pw_nj = channel_tiles; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
@@ -119,6 +121,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   h.num_cus = g_num_cus;
   h.stream_rows_pref = g_stream_rows;
   h.stream_phases_pref = g_stream_phases;
+  h.stream_strip_pref = g_stream_strip;
   h.pw_nj_pref = g_pw_nj;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};
@@ -146,7 +149,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     if (h.use_mfma && h.use_stream) {
       const StreamArgs G = make_stream_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr);
+      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);

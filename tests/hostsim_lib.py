@@ -90,6 +90,11 @@ def set_stream_phases(phases: int = 0):
     lib().hostsim_set_stream_phases(int(phases))
 
 
+def set_stream_strip(width: int = -1):
+    """The streaming kernel's column strips for wide images: -1 auto, 0 never, else the strip's width in output columns."""
+    lib().hostsim_set_stream_strip(int(width))
+
+
 def set_pointwise(channel_tiles: int = 0):
     """The pointwise kernel's 32-channel tiles per block (0 = auto: 1 for the small launches of these tests)."""
     lib().hostsim_set_pointwise(int(channel_tiles))

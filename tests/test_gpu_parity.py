@@ -316,6 +316,46 @@ def test_direct_variant_2d_tiles_on_wide_images(shape):
     assert np.array_equal(y.cpu().numpy().view(np.int32), want.view(np.int32))
 
 
+@pytest.mark.parametrize("shape,opts", [((16, 224, 224, 256, 256, (1, 1), "ONE"), ()),                   # the north star's map: the planner's own choice
+                                        ((3, 224, 224, 256, 192, (1, 1), "SAME"), ()),                  # exact SAME-zero, 192 channels
+                                        ((2, 40, 128, 256, 256, (1, 2), "ONE"), (("stream_strip", "32"),)),   # column stride 2, forced
+                                        ((2, 64, 128, 200, 192, (2, 1), "VALID"), (("stream_strip", "64"),)), # VALID is 126 wide: refused
+                                        ((4, 30, 256, 256, 320, (1, 1), "ONE"), (("stream_strip", "64"),))])
+def test_streaming_kernel_column_strips_on_wide_images(shape, opts):
+    """224 x 224 x 256 (the north star's feature map) on the streaming kernel: the image is cut into column strips of 32 output
+    columns (a ring row = the strip + its halo), all three output types against the oracle on every image; the float layer's
+    second output from the same epilogue."""
+    b, h, w_, cin, cout, st, pad = shape
+    padding, pv = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pv, O.ACT_RELU if b == 3 else O.ACT_NONE, O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, h + w_ + cout, negative_mul_fraction=0.2)
+    if pad == "VALID":
+        with pytest.raises(amd.LceHipError, match="stream_strip"):
+            _gpu_conv(spec, amd.F32, x, w, mul, bias, engine="stream", opts=opts)
+        return
+    want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias, threads=NTHREADS)
+    # (16 images fill the chip: the planner takes the strips by itself; the smaller cases are forced)
+    got, n = _gpu_conv(spec, amd.F32, x, w, mul, bias, engine="auto" if b == 16 else "stream", opts=opts)
+    assert n.startswith("bconv2d_stream<f32") and ",strips" in n, n
+    assert np.array_equal(got.view(np.int32), want.view(np.int32)), n
+    scale, zp = synth.int8_quant_params(cout)
+    want8 = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=float(scale), out_zero_point=zp, threads=NTHREADS)
+    got, n = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=zp, engine="stream", opts=opts)
+    assert ",strips" in n and np.array_equal(got, want8), n
+    thr = O.thresholds_converter(spec, mul, bias)
+    wantb = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, threads=NTHREADS)
+    got, n = _gpu_conv(spec, amd.BITPACKED, x, w, thr=thr, engine="stream", opts=opts)
+    assert ",strips" in n and np.array_equal(got, wantb), n
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    plan.set_option("engine", "stream")
+    for k_, v_ in opts:
+        plan.set_option(k_, v_)
+    y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(bits, amd.bitpack(y)) and np.array_equal(y.cpu().numpy().view(np.int32), want.view(np.int32))
+
+
 @pytest.mark.parametrize("engine,kernel,k", [("auto", "auto", 3), ("direct", "auto", 3), ("mfma", "auto", 3), ("valu", "auto", 3),
                                              ("valu", "general", 3), ("auto", "auto", 1), ("direct", "auto", 1),
                                              ("stream", "auto", 3)])

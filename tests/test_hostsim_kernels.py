@@ -631,6 +631,42 @@ def test_stream_flat_pixel_blocks_second_output(cin, cout):
         H.set_stream(256, 0)
 
 
+STRIP_SHAPES = [
+    # batch, h, w, cin, cout, stride, padding, activation, compute units, strip width
+    (2, 10, 64, 256, 256, (1, 1), "ONE", O.ACT_NONE, 3, 32),       # two strips per image, runs inside a strip
+    (1, 12, 96, 256, 192, (1, 1), "SAME", O.ACT_RELU, 2, 32),      # exact SAME-zero: columns AND rows outside the image are zeros
+    (2, 9, 128, 200, 192, (1, 2), "ONE", O.ACT_NONE, 2, 32),       # column stride 2 (64 outputs), partial word planes (200 channels)
+    (1, 16, 128, 256, 128, (2, 1), "ONE", O.ACT_NONE, 4, 64),      # 64-wide strips, row stride 2
+    (1, 8, 66, 256, 64, (1, 1), "VALID", O.ACT_NONE, 1, 32),       # VALID: 64 outputs from 66 columns
+    (1, 16, 128, 256, 256, (2, 1), "VALID", O.ACT_NONE, 4, 64),    # 126 outputs: not a multiple of the strip -> refused
+    (3, 6, 64, 256, 320, (1, 1), "ONE", O.ACT_RELU6, 2, 32),       # more blocks than compute units; five channel slices (grid.y)
+]
+
+
+@pytest.mark.parametrize("shape", STRIP_SHAPES, ids=lambda s: "%dx%dx%d_%d-%d_w%d" % (s[0], s[1], s[2], s[3], s[4], s[9]))
+def test_stream_kernel_column_strips(shape):
+    """Wide images on the streaming kernel (round 4): segments are runs of rows of ONE column strip, a ring row holds the
+    strip + its halo columns, columns outside the image are produced as padding.  Forced on small images here; shapes
+    whose output width the strip does not divide are refused (the planner then stays with whole rows / the block GEMM)."""
+    b, h, w_, cin, cout, st, pad, act, cus, wso = shape
+    padding, pad_values = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, act, O.SEM_REFERENCE)
+    H.set_stream(cus, 0)
+    H.set_stream_strip(wso)
+    try:
+        if spec.out_w % wso:
+            x, w, mul, bias = synth.conv_inputs(spec, 1)
+            with pytest.raises(RuntimeError, match="stream_strip"):
+                H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="stream")
+            return
+        for mb in (0, 2):
+            names = _run_all_dst_mfma(spec, seed=cin + cout + w_, max_batch=mb, engine="stream")
+            assert all(n.startswith("bconv2d_stream<") and ",strips%d>" % wso in n for n in names), names
+    finally:
+        H.set_stream(256, 0)
+        H.set_stream_strip(-1)
+
+
 def test_stream_kernel_refuses_what_it_cannot_run():
     x, w, mul, bias = synth.conv_inputs(O.ConvSpec(1, 6, 6, 64, 3, 3, 64), 1)
     for spec, why in [
