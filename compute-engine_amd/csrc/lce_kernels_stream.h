@@ -94,6 +94,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
                const uint32_t* __restrict__ tabs, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
   static_assert(!SIGN || DST != kDstBitpacked, "a bitpacked-output plan already writes bits");
   constexpr int KCHW = KSPLIT ? KCH / 2 : KCH; // 64-channel chunks per tap that ONE wave multiplies
+  // FLATC: instances whose planner may cut pixel blocks across a block's images (StreamArgs::flat).  Only the K-split instances:
+  // the handful of per-step instructions it costs (a run that ends in mid-block marks its last block itself) are ~1 % of an L0
+  // block step, and the layers that gain from it -- 7x7 images, several per block -- are the 512-channel ones.
+  constexpr bool FLATC = KSPLIT;
   constexpr int KS = KH * KW * KCHW;           // K-steps of one pixel block (per wave)
   constexpr int PS = KCH * 32 + 16;            // LDS bytes per ring pixel (the +16 staggers the banks)
   static_assert(!KSPLIT || KCH % 2 == 0, "the K split halves the chunks of a tap");
@@ -130,13 +134,13 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   nseg = nseg < 0 ? 0 : (nseg > G.SPB ? G.SPB : nseg);
   // pixel blocks of this block's stream: per segment, or (flat) cut from its segments' pixels laid end to end -- a short last
   // block's spare lanes then hold pixels past the launch, whose stores fall outside the output's buffer resource
-  const int nblk_all = G.flat ? (nseg * G.NPX + 31) >> 5 : nseg * G.PBS;
+  const int nblk_all = FLATC && G.flat ? (nseg * G.NPX + 31) >> 5 : nseg * G.PBS;
   const int nblk = slice_ok ? nblk_all : 0;            // ... that produce output
   const int usteps = (nblk_all + (1 << G.pph_log) - 1) >> G.pph_log;   // block steps (2^pph_log pixel blocks each)
   // flat: the pixel block at which this block's run ends in mid-block (-1: none, or the table says so itself), and the last
   // real row of that block -- ONE scalar each for the K loop, which has no scalar registers to spare
   // (kept per lane: the K loop has no scalar registers to spare)
-  int dyn_last = G.flat && ((nseg * G.NPX) & 31) != 0 ? nblk_all - 1 : -1;
+  int dyn_last = FLATC && G.flat && ((nseg * G.NPX) & 31) != 0 ? nblk_all - 1 : -1;
   int dyn_lim = nseg * G.NPX - (nblk_all - 1) * 32 - 1;
   keep_in_vgpr(dyn_last);
   keep_in_vgpr(dyn_lim);
@@ -414,6 +418,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   struct Ctx {
     u32x4 t;
     uint32_t s;            // SIGN: byte offset of the lane's pixel row in the sign-word tensor (same marker bit)
+    // What the kernel adds to the table's entry -- kept apart and applied where t[3] / s are CONSUMED (a block step later):
+    // touching the loaded values right behind the load would make the wave wait for it on the spot (the first build of
+    // round 4 did: L0 bitpacked +5.5 %, float +1.2 %, profiles/r04/ab_r03_kernels.txt)
+    uint32_t m;            // the partial-block marker of a flat run that ends in mid-block (else 0)
+    uint32_t bo, bs;       // STRIPS: the segment's place in the output / in the sign words
   };
   const uint32_t row_bytes = DST == kDstBitpacked ? (uint32_t)G.Wout * 4u : (uint32_t)G.N * (DST == kDstInt8 ? 1u : 4u);
   const rsrc_t rout = make_rsrc(out, G.out_bytes);
@@ -455,22 +464,17 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     int q = (u << G.pph_log) + pp;
     q = q < nq ? q : nq - 1;
     cx.t = buf_load(rtab, (uint32_t)G.tab_ctx + (uint32_t)(q * 64 + lane) * 16u, (u32x4*)nullptr);
-    if constexpr (KSPLIT) {            // this wave's half of a pixel's channels: KCHW chunks of 32 bytes further on
-      const uint32_t koff = (uint32_t)khalf * (uint32_t)(KCHW * 32);
-      cx.t[0] += koff; cx.t[1] += koff; cx.t[2] += koff;
-    }
     if constexpr (SIGN) cx.s = buf_load(rtab, (uint32_t)G.tab_sgn + (uint32_t)(q * 64 + lane) * 4u, (uint32_t*)nullptr);
     else cx.s = 0u;
     // flat: the last block of a run that is SHORTER than the planned one is partial where the table does not say so (its
     // rows past the run are pixels of images beyond the launch; a store's uniform row offset is not range-checked): it
     // gets the table's marker here
-    const uint32_t mark = (u << G.pph_log) + pp == dyn_last ? 0x80000000u : 0u;
-    cx.t[3] |= mark;
-    if constexpr (SIGN) cx.s |= mark;
+    cx.m = FLATC && (u << G.pph_log) + pp == dyn_last ? 0x80000000u : 0u;
+    cx.bo = cx.bs = 0u;
     if constexpr (STRIPS) {            // the segment's place in the output (a strip run may cross strips and images)
       const int gl = (int)tabs[G.tab_seg / 4 + q];
-      cx.t[3] += segbase[2 * gl + 0];
-      if constexpr (SIGN) cx.s += segbase[2 * gl + 1];
+      cx.bo = segbase[2 * gl + 0];
+      if constexpr (SIGN) cx.bs = segbase[2 * gl + 1];
     }
   };
   // second output: lane p (< 32) owns pixel row p's two sign words of this wave's 64 channels
@@ -480,7 +484,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
                                      : kOobOffset;
   auto sign_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
     const int q = (u << G.pph_log) + pp;
-    return sat_add_u32(cx.s, q < nblk ? sign_chan_off : kOobOffset);
+    return sat_add_u32((cx.s | cx.m) + cx.bs, q < nblk ? sign_chan_off : kOobOffset);
   };
   // per lane: channels past the last one never set a bit (padding bits of the last word are 0, bitpack.h:248-308)
   float bit_thrv[2];
@@ -489,7 +493,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // the store offset of a context: out of range for pixel blocks past the stream and for partial blocks
   auto out_base = [&](int u, const Ctx& cx) LCE_LAMBDA_INLINE -> uint32_t {
     const int q = (u << G.pph_log) + pp;
-    return sat_add_u32(cx.t[3], q < nblk ? chan_off : kOobOffset);   // saturating: two markers must not wrap around
+    return sat_add_u32((cx.t[3] | cx.m) + cx.bo, q < nblk ? chan_off : kOobOffset);   // saturating: two markers must not wrap around
   };
 
   // ---- the epilogue of one pixel block, cut into units that ride between the next block's MFMAs ----
@@ -691,6 +695,15 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   Ctx epi_cx = cur;
   u32x4 af[2][GA];
 
+  // KSPLIT: this wave's half of a pixel's channels lies KCHW chunks of 32 bytes further on; added to a context's tap-row
+  // addresses once it has arrived (the first one here, the others late in the block step that loaded them)
+  auto ctx_khalf = [&](Ctx& cx) LCE_LAMBDA_INLINE {
+    if constexpr (KSPLIT) {
+      const uint32_t koff = (uint32_t)khalf * (uint32_t)(KCHW * 32);
+      cx.t[0] += koff; cx.t[1] += koff; cx.t[2] += koff;
+    }
+  };
+  ctx_khalf(cur);
   auto frag_addr = [&](const Ctx& cx, int ks) LCE_LAMBDA_INLINE -> uint32_t {
     const int fy = ks / (KW * KCHW), fx = (ks / KCHW) % KW, kc = ks % KCHW;
     return cx.t[fy] + (uint32_t)(fx * PS + kc * 32);
@@ -771,7 +784,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         if constexpr (ks == 1) {       // what the NEXT step's drain of this block needs
           next_ob = out_base(u, cur);
           if constexpr (SIGN) next_sob = sign_base(u, cur);
-          next_part = (int)(uniform(cur.t[3]) >> 31) != 0;
+          next_part = (int)(uniform(cur.t[3] | cur.m) >> 31) != 0;
         }
         sched_fence();
         // ---------------- MFMA 1 ----------------
@@ -811,6 +824,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         if constexpr (SIGN && !FIRST && ks == SA) sign_store(epi_sob);      // phase A is complete: the drained block's sign words
         if constexpr (ks == SA) load_ctx(u + 1, nxt);
+        if constexpr (KSPLIT && ks == (NG - 1) * GA - 1) ctx_khalf(nxt);     // (in front of the last group, whose reads use it)
 #ifndef LCE_ST_NOPROD   // timing ablation (results are wrong): no production between the MFMAs
         // production: block step 0 expands item A (16 chunks), block step 1 issues the next one (12 chunks; its load
         // has three block steps to arrive)
@@ -867,6 +881,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 
   using TagFirst = IntC<1>;
   using TagSteady = IntC<0>;
+  // (The first tile step is its own copy of all four block steps, not just of the peeled one: with ONE copy of steps 1-3 behind
+  // a branch the float kernel measured +1.5-2 % on L0 -- register allocation --, profiles/r04/ab_r03_kernels.txt.)
   auto tile_step = [&](auto first_, int T) LCE_LAMBDA_INLINE {
     const uint32_t sch1 = sched[T + 1], sch2 = sched[T + 2];
     // (the last tile step may be short: block steps past the stream are skipped, not computed and masked)

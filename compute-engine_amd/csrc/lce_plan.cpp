@@ -489,7 +489,7 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     if (p.out_h % rs) continue;
     if (p.stream_rows_pref > 0 && rs != p.stream_rows_pref) continue;
     const int64_t spb = run_length(p.out_h / rs), s = (int64_t)batch_chunk * nstrip * (p.out_h / rs);
-    const bool flat_c = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
+    const bool flat_c = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat && ksplit;   // (the K-split instances are the ones built for it)
     const int64_t blocks = flat_c ? (spb * rs * p.out_w + 31) / 32 : spb * ceil_div(rs * ow_seg, 32);
     const int64_t rounds = (ceil_div((int)s, (int)spb) + cus - 1) / cus;      // (strips: more blocks than CUs run in rounds)
     const int64_t steps = (blocks + pph - 1) / pph;
@@ -506,7 +506,7 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     std::vector<uint32_t> sched;
     // whole small images whose pixels do not fill 32-pixel blocks: cut the blocks from the block's images laid end to end
     // (the output tensor is laid out that way: NHWC with nothing between images)
-    const bool flat = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat;
+    const bool flat = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat && ksplit;   // (the K-split instances are the ones built for it)
     if (!simulate_stream(p, rs, (int)spb, pph_log, flat, ow_seg, in_w_seg, &rows, &sched)) continue;
     const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
     if (ring + stream_lds_extra(p) > 160 * 1024) continue;
