@@ -900,7 +900,10 @@ static bool stream_worthwhile(const HostPlan& p) {
 #ifndef LCE_STREAM_MIN_STEPS
 #define LCE_STREAM_MIN_STEPS 6
 #endif
-  return p.st_gx * 4 >= cus * 3 && steps >= LCE_STREAM_MIN_STEPS && (p.st_rs >= 4 || p.st_rs == p.out_h);
+  // (512 input channels: the block GEMM is bound by its LDS traffic there -- 1 KiB of fragment reads per MFMA -- and loses even on
+  //  the shortest launches: 7x7x512 stride 2, two block steps per block, 9.8 vs 17.9 us, profiles/r04/ksplit_vs_block_gemm.txt)
+  const int64_t min_steps = stream_ksplit(p) ? 2 : LCE_STREAM_MIN_STEPS;
+  return p.st_gx * 4 >= cus * 3 && steps >= min_steps && (p.st_rs >= 4 || p.st_rs == p.out_h);
 }
 
 std::string select_kernel(HostPlan& p, int64_t pixels) {
