@@ -890,6 +890,9 @@ static bool stream_candidate(const HostPlan& p) {
 #ifdef LCE_STREAM_AUTO_STRIDED   // (A/B aid: strided 3x3 layers of 128 / 256 input channels, any width of output)
   if ((p.d.stride_height > 1 || p.d.stride_width > 1) && (kch == 2 || kch == 4) && p.d.channels_out >= 128) return true;
 #endif
+#ifdef LCE_STREAM_AUTO_LOWK      // (A/B aid: int8 layers of 64 / 128 input channels)
+  if ((kch == 1 || kch == 2) && p.d.dst_type == LCE_HIP_I8 && p.d.channels_out >= 64) return true;
+#endif
   if (kch == 8) return p.d.channels_out >= 128;
   return kch == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
 }
