@@ -884,17 +884,38 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
 //   449..512 input channels (K split over wave pairs), >= 128 output channels: 7x7x512 1.1-1.25x, 7x7x512 -> 128 / 256 1.3-1.7x,
 //   7x7x512 stride 2 1.8x, 14x14x512 1.0-1.1x;
 //   64 / 128 input channels: slower (18 / 36 MFMAs per pixel block do not carry the epilogue) -- not tried.
-static bool stream_candidate(const HostPlan& p) {
+static bool stream_candidate(const HostPlan& p, bool want_sign) {
   if (!stream_supported(p)) return false;
   const int kch = ceil_div(p.d.channels_in, 64);
 #ifdef LCE_STREAM_AUTO_STRIDED   // (A/B aid: strided 3x3 layers of 128 / 256 input channels, any width of output)
   if ((p.d.stride_height > 1 || p.d.stride_width > 1) && (kch == 2 || kch == 4) && p.d.channels_out >= 128) return true;
 #endif
-#ifdef LCE_STREAM_AUTO_LOWK      // (A/B aid: int8 layers of 64 / 128 input channels)
+#ifdef LCE_STREAM_AUTO_LOWK      // (A/B aid: int8 layers of 64 / 128 input channels, whatever outputs are asked for)
   if ((kch == 1 || kch == 2) && p.d.dst_type == LCE_HIP_I8 && p.d.channels_out >= 64) return true;
 #endif
+  // 64 / 128 input channels (18 / 36 MFMAs per pixel block: the epilogue is exposed).  Since the first block step takes its weights as
+  // they arrive (round 4) the streaming kernel is ahead of the block GEMM on these layers in some cases (batch 256, two boxes,
+  // profiles/r04/low_k_on_the_streaming_kernel.txt; us, streaming kernel vs block GEMM):
+  //   int8 WITHOUT the second output: 56x56x64 28.2 vs 30.1, 28x28x128 19.8 vs 22.0, stride 2: 19.1 vs 22.2 and 12.8 vs 14.8; WITH it the sign
+  //     gather costs the one-wave-per-SIMD kernel 5-10 us, the block GEMM 2-5: behind or level (37.9 vs 35.0, 24.6 vs 24.2) -> only without;
+  //   float, stride 2: 24.6 vs 26.4 and 15.0 vs 18.1 (with the second output 24.8 vs 28.6, 15.4 vs 18.3) -> both ways;
+  //   float 28x28x128: 25.4 vs 25.8, with the second output 26.1 vs 28.2 -> both ways;
+  //   float 56x56x64 (store-bound): 35.9 vs 39.9 on one box, 45.5 vs 40.0 on the next (one block per image, row by row: the store
+  //     pattern whose rate is a property of the box) -> not taken; bitpacked output: a tie -> not taken;
+  //   images wider than 64 pixels (112 / 224): 5-15 % behind the block GEMM's strips / 2-D tiles -> not taken.
+  if ((kch == 1 || kch == 2) && p.d.channels_out >= 64 && p.d.in_width <= 64) {
+    const bool strided = p.d.stride_height > 1 || p.d.stride_width > 1;
+    if (p.d.dst_type == LCE_HIP_I8 && !want_sign) return true;
+    if (p.d.dst_type == LCE_HIP_F32 && (strided || kch == 2)) return true;
+  }
   if (kch == 8) return p.d.channels_out >= 128;
   return kch == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
+}
+// true when the auto rule above answers differently for the two kinds of call (with / without the second output): the C ABI then keeps
+// one selection per kind (lce_hip_api.hip, run_dual), so a plan that is driven both ways never re-plans or re-uploads
+bool auto_choice_depends_on_second_output(const HostPlan& p) {
+  if (p.engine_pref != 0 || p.kernel_pref != 0 || p.tile_pref.tm != 0) return false;
+  return stream_candidate(p, false) != stream_candidate(p, true);
 }
 static bool stream_worthwhile(const HostPlan& p) {
   const int cus = std::max(1, p.num_cus / p.st_ny);
@@ -923,7 +944,7 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   p.use_stream = false;
-  if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_candidate(p))) {
+  if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_candidate(p, p.want_sign))) {
     // weight-stationary streaming kernel: the planner's FP4 weight image with 64-channel granularity
     const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
     const std::string err = plan_stream(p, batch_chunk);

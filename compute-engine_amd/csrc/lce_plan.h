@@ -49,6 +49,7 @@ struct HostPlan {
 
   // OneTimeSetup results (bconv2d.cc:324-392)
   bool have_weights = false;
+  bool want_sign = false;                  // the call asks for the second (LceQuantize) output too: lce_hip_bconv2d_run_dual (the planner's auto rule looks at it)
   std::vector<float> mul, bias;            // channels_out entries
   int32_t clamp_min = 0, clamp_max = 0;
   float bit_thr = 0.0f;                    // LceQuantize of the output as a compare: bit = value < bit_thr
@@ -127,6 +128,7 @@ bool tiled_supports(const HostPlan& p, int tn);
 // Choose kernel + tile for `pixels` output pixels per launch and (re)build the packed
 // operands.  Returns "" or an error message (e.g. a forced variant that cannot run).
 std::string select_kernel(HostPlan& p, int64_t pixels);
+bool auto_choice_depends_on_second_output(const HostPlan& p);   // lce_plan.cpp, behind stream_candidate
 
 // Largest batch chunk one launch may take (buffer resources bind < 2 GiB).
 int max_batch_per_launch(const HostPlan& p);

@@ -190,6 +190,9 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
                                                const char* value);
 /* Name of the kernel variant the next run will launch (static string owned by the plan). */
 const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan);
+/* The same for lce_hip_bconv2d_run_dual: on a few layers (int8 output, 64 / 128 input channels) the best kernel depends on
+ * whether the call asks for the second output, and the plan keeps one selection for each kind of call. */
+const char* lce_hip_bconv2d_plan_kernel_name_dual(lce_hip_bconv2d_plan* plan);
 
 /* Replaces bconv2d::Eval (bconv2d.cc:550-564) -> BConv2DReference /
  * BConv2DOptimizedBGEMM / BConv2DOptimizedIndirectBGEMM (core/bconv2d/ headers) with

@@ -133,8 +133,14 @@ def test_kernel_selection_is_host_side_and_named():
     # 2048 input channels: the LDS halo of any tile is too big -> workspace GEMM
     deep = amd.Bconv2dPlan(amd.ConvParams(8, 28, 28, 2048, 3, 3, 256, padding=amd.PADDING_SAME, pad_values=1))
     assert deep.kernel_name().startswith("bconv2d_mfma<f32,")
+    # 128 input channels, float, batch 256: the streaming kernel since round 4 (it was behind the block GEMM before the first block step
+    # took its weights as they arrive); the block GEMM when asked for, and for a bitpacked output
     mid = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1))
+    assert mid.kernel_name() == "bconv2d_stream<f32,3x3x128,rows28>"
+    mid.set_option("engine", "direct")
     assert mid.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
+    midb = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.BITPACKED))
+    assert midb.kernel_name() == "bconv2d_mfma_direct<bitpacked,128x128>"
     grouped = amd.Bconv2dPlan(amd.ConvParams(1, 8, 8, 128, 3, 3, 64, groups=2))
     grouped.set_option("engine", "mfma")
     assert grouped.kernel_name() == ""                              # refused: grouped convolution
@@ -178,7 +184,9 @@ def test_empty_batch_is_legal_and_a_no_op():
     (14, 256, "I8", "bconv2d_stream<i8,3x3x256,rows14>"),
     (56, 256, "BITPACKED", "bconv2d_stream<bitpacked,3x3x256,rows56>"),
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
-    (28, 128, "F32", "bconv2d_mfma_direct<f32,128x128>"),
+    (28, 128, "F32", "bconv2d_stream<f32,3x3x128,rows28>"),        # round 4 (profiles/r04/low_k_on_the_streaming_kernel.txt)
+    (56, 64, "I8", "bconv2d_stream<i8,3x3x64,rows56>"),            # int8 without the second output; with it (run_dual) the block GEMM
+    (28, 128, "BITPACKED", "bconv2d_mfma_direct<bitpacked,128x128>"),
     (14, 256, "F32", "bconv2d_stream<f32,3x3x256,rows14>"),
     (7, 512, "F32", "bconv2d_stream<f32,3x3x512,rows7>"),          # round 4: K split over wave pairs, blocks cut across 4 images
     (7, 512, "I8", "bconv2d_stream<i8,3x3x512,rows7>"),
@@ -188,6 +196,21 @@ def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
     picks for the BASELINE.json layers at batch 256 so that a planner edit shows up as a diff."""
     p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=getattr(amd, dst))
     assert amd.Bconv2dPlan(p).kernel_name() == want
+
+
+def test_planner_keeps_one_choice_per_kind_of_call():
+    """int8, 64 / 128 input channels: the streaming kernel wins without the second output, the block GEMM with it
+    (profiles/r04/low_k_on_the_streaming_kernel.txt).  run_dual drives a twin plan, so both names stay valid side by side."""
+    p = amd.ConvParams(256, 56, 56, 64, 3, 3, 64, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.I8)
+    plan = amd.Bconv2dPlan(p)
+    assert plan.kernel_name() == "bconv2d_stream<i8,3x3x64,rows56>"
+    assert plan.kernel_name(dual=True) == "bconv2d_mfma_direct<i8,256x64>"
+    assert plan.kernel_name() == "bconv2d_stream<i8,3x3x64,rows56>"
+    plan.set_option("engine", "mfma")                       # a forced engine holds for both kinds of call
+    assert plan.kernel_name(dual=True) == plan.kernel_name()
+    p = amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.F32)
+    plan = amd.Bconv2dPlan(p)                               # float: the same kernel either way
+    assert plan.kernel_name(dual=True) == plan.kernel_name() == "bconv2d_stream<f32,3x3x128,rows28>"
 
 
 def test_planner_fallbacks():

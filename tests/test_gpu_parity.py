@@ -394,6 +394,37 @@ def test_run_dual_on_an_int8_plan_is_run_followed_by_lcequantize(engine, kernel,
             assert (want < zp).any() and (want >= zp).any()
 
 
+def test_a_plan_driven_both_ways_keeps_both_selections():
+    """int8, 128 input channels: run takes the streaming kernel, run_dual the block GEMM (lce_plan.cpp, stream_candidate) -- the
+    plan holds a twin for the second kind of call; alternating the two gives the same tensors every time."""
+    spec = O.ConvSpec(256, 28, 28, 128, 3, 3, 128, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    x, w, mul, bias = synth.conv_inputs(spec, 77, negative_mul_fraction=0.3)
+    plan = amd.Bconv2dPlan(_params(spec, amd.I8, out_scale=9.0, out_zero_point=-3))
+    plan.set_weights(w, mul, bias)
+    assert plan.kernel_name().startswith("bconv2d_stream<i8") and plan.kernel_name(dual=True).startswith("bconv2d_mfma_direct<i8")
+    xd = torch.from_numpy(x).to(DEV)
+    x4 = x[:4]
+    spec4 = O.ConvSpec(4, 28, 28, 128, 3, 3, 128, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_RELU)
+    want = O.bconv2d(spec4, O.DST_I8, x4, w, mul, bias, out_scale=9.0, out_zero_point=-3)
+    first = None
+    for turn in range(3):
+        y = plan.run(xd)
+        y2 = torch.full_like(y, 0x5A)
+        bits = torch.full((256, 28, 28, 4), 0x5A5A5A5A, dtype=torch.int32, device=DEV)
+        plan.run_dual(xd, y2, bits)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2) and torch.equal(bits, amd.bitpack(y, -3)), turn
+        assert np.array_equal(y[:4].cpu().numpy(), want), turn
+        first = y if first is None else first
+        assert torch.equal(first, y)
+    plan.set_weights(w, -mul, bias)                  # new weights reach both
+    y = plan.run(xd)
+    y2, bits = torch.empty_like(y), torch.empty((256, 28, 28, 4), dtype=torch.int32, device=DEV)
+    plan.run_dual(xd, y2, bits)
+    assert torch.equal(y, y2) and not torch.equal(y, first)
+    assert np.array_equal(y[:4].cpu().numpy(), O.bconv2d(spec4, O.DST_I8, x4, w, -mul, bias, out_scale=9.0, out_zero_point=-3))
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32), (128, 512),
                                       (512, 512), (480, 64), (512, 96)])
 def test_pointwise_streaming_kernel(cin, cout):

@@ -65,5 +65,5 @@ class LayerChain:
                 p.run(x, self.y[k])
                 amd.bitpack(self.y[k], self.quant[k][1], out=self.bits[k])
 
-    def kernel_names(self):
-        return [p.kernel_name() for p in self.plans]
+    def kernel_names(self, fused=False):
+        return [p.kernel_name(dual=fused) for p in self.plans]
