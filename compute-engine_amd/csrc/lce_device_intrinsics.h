@@ -382,4 +382,22 @@ LCE_DEVICE uint32_t pack4_u8(int q0, int q1, int q2, int q3) {
   return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// Eight floats -> the low bytes of their truncated integers, in two dwords.  v_cvt_i32_f32 with an SDWA destination byte converts AND
+// packs (four v_cvt + three v_perm per dword otherwise).  gfx940+: a VALU read of a register needs one wait state behind a dst_sel
+// write of it (LLVM's DstSelForwardingHazard -- its recognizer cannot see into inline asm; UNUSED_PRESERVE reads the destination): the
+// two dwords' conversions alternate and an s_nop ends the block.
+LCE_DEVICE void cvt_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint32_t& hi) {
+  asm("v_cvt_i32_f32_sdwa %0, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %1, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %0, %3 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %1, %7 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %0, %4 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %1, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %0, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_i32_f32_sdwa %1, %9 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+
 }  // namespace lce_dev

@@ -64,6 +64,17 @@ LCE_DEVICE void round_i8_clamped2(float c0, float c1, int& q0, int& q1) {
   q1 = (int)s[1];
 }
 
+// Eight values that are already inside [-128, 127] -> eight int8 in two dwords: the same rounding, the truncating conversion packs
+// as it goes (cvt_pack8_i8, lce_device_intrinsics.h).
+LCE_DEVICE void round_pack8_i8_clamped(f32x4 a, f32x4 b, uint32_t& lo, uint32_t& hi) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = a[i] + __builtin_copysignf(0x1.fffffep-2f, a[i]);
+    b[i] = b[i] + __builtin_copysignf(0x1.fffffep-2f, b[i]);
+  }
+  cvt_pack8_i8(a, b, lo, hi);
+}
+
 // :17-27,31-44,133-143 -- std::round (half away from zero), saturate to int8.
 LCE_DEVICE int ot_int8(int acc, int cmin, int cmax, float mul, float bias) {
   return round_sat_i8(ot_float(acc, cmin, cmax, mul, bias));

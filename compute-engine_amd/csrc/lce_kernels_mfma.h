@@ -796,9 +796,15 @@ bconv2d_mfma(const ConvArgs A, const MfmaArgs G, const uint8_t* __restrict__ xp,
         for (int k = 0; k < KB; ++k) {
           u32x4 pk;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            pk[q] = pack4_u8(round_sat_i8(y[k][q][0]), round_sat_i8(y[k][q][1]), round_sat_i8(y[k][q][2]),
-                             round_sat_i8(y[k][q][3]));
+          for (int q = 0; q < 4; q += 2) {
+            f32x4 a = y[k][q], b = y[k][q + 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = med3(a[i], -128.0f, 127.0f); b[i] = med3(b[i], -128.0f, 127.0f); }
+            uint32_t lo, hi;
+            round_pack8_i8_clamped(a, b, lo, hi);
+            pk[q] = lo;
+            pk[q + 1] = hi;
+          }
           buf_store(ro8, lane_off8 + blk_off8 + (uint32_t)((k0 + k) * RPI) * (uint32_t)A.N, pk);
         }
       }

@@ -269,12 +269,11 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
         for (int k = 0; k < NK; ++k) {
           const f32x4* src = (const f32x4*)(scratch + (rr + k * RPI) * RW + g * 16);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = src[q];             // already inside [-128, 127]
-            int q0, q1, q2, q3;
-            round_i8_clamped2(v[0], v[1], q0, q1);
-            round_i8_clamped2(v[2], v[3], q2, q3);
-            hold[S][k][q] = pack4_u8(q0, q1, q2, q3);
+          for (int q = 0; q < 4; q += 2) {       // (values already inside [-128, 127])
+            uint32_t lo, hi;
+            round_pack8_i8_clamped(src[q], src[q + 1], lo, hi);
+            hold[S][k][q] = lo;
+            hold[S][k][q + 1] = hi;
           }
           const uint32_t row = row0 + (uint32_t)(rr + k * RPI);
 #ifdef LCE_PW_NOSTORE   // timing ablation (results are wrong)

@@ -597,8 +597,15 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     } else if constexpr (DST == kDstInt8) {
       // round half away from zero on values already clamped to [-128, 127] (lce_kernels.h, round_sat_i8); scalar adds:
       // a packed-f32 add beside the MFMA stream costs a dozen cycles more than its issue slot
-      auto rnd = [](float c) LCE_LAMBDA_INLINE -> int { return (int)(c + __builtin_copysignf(0x1.fffffep-2f, c)); };
-      pk[k >> 2][k & 3] = pack4_u8(rnd(yb[k][0]), rnd(yb[k][1]), rnd(yb[k][2]), rnd(yb[k][3]));
+      // (the conversion, which truncates, packs as it goes -- two dwords at a time: cvt_pack8_i8)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yb[k][i] = yb[k][i] + __builtin_copysignf(0x1.fffffep-2f, yb[k][i]);
+      if constexpr ((k & 1) == 1) {
+        uint32_t lo, hi;
+        cvt_pack8_i8(yb[k - 1], yb[k], lo, hi);
+        pk[k >> 2][(k & 3) - 1] = lo;
+        pk[k >> 2][k & 3] = hi;
+      }
       if constexpr ((k & 3) == 3) buf_store_so(rout, ob, (uint32_t)(RPI * (k >> 2)) * row_bytes, pk[k >> 2]);
     } else {
       if constexpr (k == 0) {

@@ -229,4 +229,9 @@ inline uint32_t pack4_u8(int q0, int q1, int q2, int q3) {
   return (uint32_t)(q0 & 0xff) | ((uint32_t)(q1 & 0xff) << 8) | ((uint32_t)(q2 & 0xff) << 16) | ((uint32_t)(q3 & 0xff) << 24);
 }
 
+inline void cvt_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint32_t& hi) {
+  lo = pack4_u8((int)a[0], (int)a[1], (int)a[2], (int)a[3]);
+  hi = pack4_u8((int)b[0], (int)b[1], (int)b[2], (int)b[3]);
+}
+
 }  // namespace lce_dev
