@@ -801,7 +801,10 @@ lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_
                 "plan already writes bits)");
   if (plan->host.d.batch == 0) return LCE_HIP_OK;
   if (!output_bits_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: null argument");
-  plan = plan_for_second_output(plan);
+  if (lce_hip_status s = check_device(plan)) return s;   // (the plan and its twin are bound to the same device)
+  lce_hip_bconv2d_plan* const target = plan_for_second_output(plan);
+  target->device = plan->device;
+  plan = target;
   return run_images(plan, input_dev, output_dev, output_bits_dev, 0, plan->host.d.batch, (hipStream_t)stream);
 }
 

@@ -98,14 +98,17 @@ __global__ __launch_bounds__(256) void fill_tile(float* out, int tiles) {
 // SLAB > 0 (with IMAGE): the block's steps come in runs of SLAB consecutive pixel blocks (one segment of the streaming
 // kernel: 14 pixel blocks = 8 rows of a 56-wide image), run k of block b = segment k * 256 + b -- at any moment the 256
 // blocks write 256 consecutive segments (a 117 MB window) instead of 256 different images (822 MB)
-template <bool IMAGE, bool NT, int LPR = 16, int SLAB = 0>
+// ROT > 0 (with IMAGE): block b starts ROT * b steps into its own image and wraps -- the lock-step writers are then at
+// different offsets of their images (round 4: does that make the rate independent of the box?)
+template <bool IMAGE, bool NT, int LPR = 16, int SLAB = 0, int ROT = 0>
 __global__ __launch_bounds__(256) void fill_stream_pattern(float* out, int steps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const v4f v = {1.f, 2.f, 3.f, (float)lane};
   constexpr int RPI = 64 / LPR;            // rows per instruction
   constexpr int WPR = 64 / LPR;            // waves side by side in a row (4, 2, 1)
   const int wcol = wave % WPR, wrow = wave / WPR;
-  for (int s = 0; s < steps; ++s) {
+  for (int s0 = 0; s0 < steps; ++s0) {
+    const int s = ROT > 0 ? (s0 + (int)blockIdx.x * ROT) % steps : s0;
     size_t pb = IMAGE ? (size_t)blockIdx.x * steps + s : (size_t)s * gridDim.x + blockIdx.x;
     if (SLAB > 0) pb = ((size_t)(s / SLAB) * gridDim.x + blockIdx.x) * SLAB + s % SLAB;
     float* base = out + pb * 32 * kCh + wcol * (LPR * 4) + (lane % LPR) * 4;
@@ -231,6 +234,10 @@ int main() {
   }
   TIME("stream_pattern_image_blocked_nt", 0.0, (fill_stream_pattern<true, true><<<256, 256>>>(out, 98)));
   TIME("stream_pattern_interleaved_nt", 0.0, (fill_stream_pattern<false, true><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_rot1_nt", 0.0, (fill_stream_pattern<true, true, 16, 0, 1><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_rot7_nt", 0.0, (fill_stream_pattern<true, true, 16, 0, 7><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_rot37_nt", 0.0, (fill_stream_pattern<true, true, 16, 0, 37><<<256, 256>>>(out, 98)));
+  TIME("stream_pattern_image_blocked_nt_again", 0.0, (fill_stream_pattern<true, true><<<256, 256>>>(out, 98)));
   TIME("stream_pattern_slab14_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 14><<<256, 256>>>(out, 98)));
   TIME("stream_pattern_slab7_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 7><<<256, 256>>>(out, 98)));
   TIME("stream_pattern_slab2_strided_nt", 0.0, (fill_stream_pattern<true, true, 16, 2><<<256, 256>>>(out, 98)));
