@@ -332,7 +332,11 @@ def main():
     if torch.cuda.device_count() < (local_rank + 1 if world > 1 and not args.share_gpu else 1):
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, the node has {torch.cuda.device_count()}")
     dist = None
-    if world > 1:
+    # LCE_BENCH_RCCL_WITH_ONE_RANK=1 (under the launcher, WORLD_SIZE=1): the N > 1 code path -- RCCL process group, self-check,
+    # gathers, the sharded config-4 chain -- with a single rank, so that every collective call of this file has run against
+    # the real RCCL on a one-GPU box (tests/test_gpu_multi.py); the line it prints is a one-GPU line all the same
+    one_rank_rccl = world == 1 and os.environ.get("LCE_BENCH_RCCL_WITH_ONE_RANK") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or one_rank_rccl:
         import torch.distributed as dist
         if args.share_gpu:
             dist.init_process_group("gloo")
@@ -392,7 +396,7 @@ def main():
     # the 32 binary convolutions at batch 256 as one device-resident chain -- in the same barrier-bracketed way; the
     # global batch is 256 x N (2048 on 8 GPUs).  Every rank takes part in the barriers and the gather whatever happens to it.
     config4 = None
-    if world > 1 and not args.no_extra:
+    if dist is not None and not args.no_extra:
         chain4, local4 = None, float("nan")
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -500,7 +504,7 @@ def main():
             result["compute"] = {"bound": "valu", "achieved": spec.binary_macs / k_sec, "peak": VALU_BMAC_PEAK,
                                  "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
                                  "model": "v_xor_b32 + v_bcnt_u32_b32 per 32 bMAC, measured pair ceiling"}
-        if not args.no_extra and world == 1:
+        if not args.no_extra and world == 1 and not one_rank_rccl:
             result["extra"] = extra_measurements(amd, torch, spec, args, dev)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()

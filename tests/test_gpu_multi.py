@@ -16,6 +16,7 @@ import importlib
 import json
 import os
 import socket
+import time
 import subprocess
 import sys
 
@@ -95,7 +96,14 @@ def _run_sharded(world, backend, global_batch, dst_name):
     procs = [ctx.Process(target=_shard_worker, args=(r, world, port, backend, global_batch, dst_name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in range(world)]
+    results, deadline = [], time.monotonic() + 600
+    while len(results) < world:                       # (a worker that died is reported at once, not after the timeout)
+        try:
+            results.append(q.get(timeout=2))
+        except Exception:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a rank exited with {dead}"
+            assert time.monotonic() < deadline, "ranks did not report within 600 s"
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -201,6 +209,35 @@ def test_bench_on_every_gpu_of_the_node_over_rccl():
     # BASELINE config 4 as stated: 2048 images over the node (on fewer than 8 GPUs: the same per-GPU share)
     r = _bench("--gpus", str(n), "--global-batch", str(256 * n))
     assert r["scaling"] == "strong" and r["config"]["global_batch"] == 256 * n and r["rccl_world_size"] == n
+
+
+def test_bench_collectives_against_the_real_rccl_with_one_rank():
+    """Every collective call of bench.py's N > 1 path -- RCCL process group bound to the device, all_gather_object, the
+    self-check's all_gather_batch of device tensors, max / gather over ranks, barriers with device_ids, the sharded config-4 chain --
+    executed against the real RCCL on a box with ONE GPU: torch.distributed.run with one rank and LCE_BENCH_RCCL_WITH_ONE_RANK=1.
+    (What a one-GPU box cannot show is the transport between devices; test_bench_on_every_gpu_of_the_node_over_rccl does.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LCE_BENCH_RCCL_WITH_ONE_RANK"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = lines[0]
+    assert r["n_gpus"] == 1 and r["rccl_world_size"] == 1 and r["collective_backend"] == "nccl (RCCL)"
+    chk = r["multi_gpu_self_check"]
+    assert chk["sharded_equals_single_gpu_on_every_rank"] and chk["rccl_version"] and chk["distinct_devices"] == 1
+    c4 = r["config4_quicknet_large_sharded"]
+    assert c4["global_batch"] == 256 and len(c4["per_rank_chain_ms"]) == 1 and 0.3 < c4["chain_ms"] < 5
+
+
+@pytest.mark.parametrize("dst", ["f32", "bp"])
+def test_sharded_hip_run_over_rccl_with_one_rank(dst):
+    """The sharded run's collective leg (all_gather_batch on device tensors) against the real RCCL, world size 1."""
+    results = _run_sharded(1, "nccl", 19, dst)
+    assert len(results) == 1
 
 
 def test_bench_multi_rank_path_with_two_ranks_sharing_one_gpu():
