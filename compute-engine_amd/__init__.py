@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "lce_hip_malloc", "lce_hip_free", "lce_hip_memcpy_h2d", "lce_hip_memcpy_d2h", "lce_hip_memset",
     "lce_hip_host_register", "lce_hip_host_unregister",
     "lce_hip_stream_create", "lce_hip_stream_destroy", "lce_hip_stream_synchronize",
+    "lce_hip_graph_begin_capture", "lce_hip_graph_end_capture", "lce_hip_graph_launch", "lce_hip_graph_destroy",
     "lce_hip_bitpacked_size", "lce_hip_bitpack", "lce_hip_unpack",
     "lce_hip_bconv2d_plan_create", "lce_hip_bconv2d_plan_destroy", "lce_hip_bconv2d_plan_output_shape",
     "lce_hip_bconv2d_plan_padding", "lce_hip_bconv2d_plan_set_weights", "lce_hip_bconv2d_plan_folded",

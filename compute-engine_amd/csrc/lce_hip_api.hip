@@ -329,6 +329,36 @@ lce_hip_status lce_hip_stream_synchronize(void* stream) {
   return LCE_HIP_OK;
 }
 
+// ---- HIP graphs behind the C ABI (include/lce_hip.h) ----
+lce_hip_status lce_hip_graph_begin_capture(void* stream) {
+  if (!stream) return fail(LCE_HIP_ERR_INVALID, "lce_hip_graph_begin_capture: the null stream cannot be captured (lce_hip_stream_create)");
+  // thread-local mode: other threads of the host may go on calling the runtime while this one records
+  LCE_HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_graph_end_capture(void* stream, void** graph) {
+  if (!stream || !graph) return fail(LCE_HIP_ERR_INVALID, "lce_hip_graph_end_capture: null argument");
+  *graph = nullptr;
+  hipGraph_t g = nullptr;
+  LCE_HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &g));
+  if (!g) return fail(LCE_HIP_ERR_RUNTIME, "lce_hip_graph_end_capture: the capture was invalidated");
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return fail(LCE_HIP_ERR_RUNTIME, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  *graph = (void*)exec;
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_graph_launch(void* graph, void* stream) {
+  if (!graph) return fail(LCE_HIP_ERR_INVALID, "lce_hip_graph_launch: null graph");
+  LCE_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)stream));
+  return LCE_HIP_OK;
+}
+lce_hip_status lce_hip_graph_destroy(void* graph) {
+  if (graph) LCE_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph));
+  return LCE_HIP_OK;
+}
+
 int32_t lce_hip_bitpacked_size(int32_t n) { return (n + 31) / 32; }
 
 // ------------------------------------------------------------------------------------

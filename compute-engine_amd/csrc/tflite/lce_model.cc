@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -28,7 +29,28 @@ struct lce_tflite_model {
   struct DevBuf { void* ptr = nullptr; size_t bytes = 0; };
   std::map<int32_t, DevBuf> scratch;                                    // intermediate tensors of a section, grow-only
   int32_t last_run_fused = 0;                                           // LceQuantize launches the last run folded into a convolution
+  // ---- HIP graphs (lce_tflite_model_use_hip_graphs): a section's launches recorded once per (section, batch, semantics,
+  // stream, tensor pointers) and replayed as one launch.  The first call with a key runs eagerly (plans are made, weights
+  // uploaded, intermediate buffers sized), the second records, later ones replay.  Recorded launches hold the model's
+  // intermediate buffers: when one of those is reallocated every graph is dropped.
+  struct GraphKey {
+    int32_t section, batch, semantics;
+    void* stream;
+    std::vector<const void*> ptrs;
+    bool operator<(const GraphKey& o) const {
+      return std::tie(section, batch, semantics, stream, ptrs) < std::tie(o.section, o.batch, o.semantics, o.stream, o.ptrs);
+    }
+  };
+  struct GraphEntry { int32_t eager_runs = 0; void* graph = nullptr; bool unrecordable = false; int32_t fused = 0; };
+  std::map<GraphKey, GraphEntry> graphs;
+  bool use_graphs = false;
+  int32_t graph_captures = 0, graph_replays = 0;
+  void DropGraphs() {
+    for (auto& kv : graphs) if (kv.second.graph) lce_hip_graph_destroy(kv.second.graph);
+    graphs.clear();
+  }
   ~lce_tflite_model() {
+    DropGraphs();
     for (auto& kv : plans) lce_hip_bconv2d_plan_destroy(kv.second);
     for (auto& kv : scratch) if (kv.second.ptr) lce_hip_free(kv.second.ptr);
   }
@@ -390,6 +412,7 @@ lce_hip_status WalkSection(lce_tflite_model* model, const lce_tflite_section& se
     if (b.bytes < bytes) {
       // (a buffer a previous run's kernels may still use: the free below is ordered behind them by the runtime)
       if (b.ptr) lce_hip_free(b.ptr);
+      model->DropGraphs();          // (recorded launches may hold the old pointer; the free above has drained the device)
       b.ptr = nullptr;
       b.bytes = 0;
       if (lce_hip_status s = lce_hip_malloc(&b.ptr, bytes ? bytes : 1)) return s;
@@ -526,7 +549,63 @@ lce_hip_status lce_tflite_model_run_section(lce_tflite_model* model, int32_t sec
     ptr[sec.outputs[k]] = outputs_dev[k];
   }
   model->last_run_fused = 0;
-  return WalkSection(model, sec, batch, semantics, &shapes, &ptr, true, stream);
+  if (!model->use_graphs || !stream) return WalkSection(model, sec, batch, semantics, &shapes, &ptr, true, stream);
+
+  lce_tflite_model::GraphKey key{section, batch, semantics, stream, {}};
+  for (size_t k = 0; k < sec.inputs.size(); ++k) key.ptrs.push_back(inputs_dev[k]);
+  for (size_t k = 0; k < sec.outputs.size(); ++k) key.ptrs.push_back(outputs_dev[k]);
+  {
+    lce_tflite_model::GraphEntry& e = model->graphs[key];
+    if (e.graph) {
+      model->last_run_fused = e.fused;
+      ++model->graph_replays;
+      return lce_hip_graph_launch(e.graph, stream);
+    }
+    if (e.eager_runs >= 1 && !e.unrecordable) {
+      // record: the same walk, on a capturing stream (nothing executes); whatever goes wrong, the section then runs eagerly
+      bool recorded = false;
+      void* g = nullptr;
+      int32_t fused = 0;
+      if (lce_hip_graph_begin_capture(stream) == LCE_HIP_OK) {
+        std::map<int32_t, Shape> shapes_c;
+        std::map<int32_t, void*> ptr_c = ptr;
+        const lce_hip_status walked = WalkSection(model, sec, batch, semantics, &shapes_c, &ptr_c, true, stream);
+        const lce_hip_status ended = lce_hip_graph_end_capture(stream, &g);
+        recorded = walked == LCE_HIP_OK && ended == LCE_HIP_OK && g != nullptr;
+        fused = model->last_run_fused;
+        if (!recorded && g) { lce_hip_graph_destroy(g); g = nullptr; }
+      }
+      g_model_error.clear();
+      lce_tflite_model::GraphEntry& e2 = model->graphs[key];     // (the walk may have dropped the table)
+      if (recorded) {
+        e2.graph = g;
+        e2.fused = fused;
+        e2.eager_runs = 1;
+        ++model->graph_captures;
+        ++model->graph_replays;
+        return lce_hip_graph_launch(g, stream);
+      }
+      e2.unrecordable = true;
+      model->last_run_fused = 0;
+    }
+  }
+  const lce_hip_status s = WalkSection(model, sec, batch, semantics, &shapes, &ptr, true, stream);
+  if (s == LCE_HIP_OK) ++model->graphs[key].eager_runs;
+  return s;
+}
+
+void lce_tflite_model_use_hip_graphs(lce_tflite_model* model, int32_t on) {
+  if (!model) return;
+  std::lock_guard<std::mutex> lock(model->run_mu);
+  model->use_graphs = on != 0;
+  if (!on) model->DropGraphs();
+}
+
+void lce_tflite_model_graph_stats(lce_tflite_model* model, int32_t* recorded, int32_t* replays) {
+  if (!model) return;
+  std::lock_guard<std::mutex> lock(model->run_mu);
+  if (recorded) *recorded = model->graph_captures;
+  if (replays) *replays = model->graph_replays;
 }
 
 void lce_tflite_model_run_stats(lce_tflite_model* model, int32_t* cached_plans, int32_t* fused_quantize_ops, size_t* scratch_bytes) {

@@ -90,6 +90,10 @@ def tflite_lib() -> C.CDLL:
                                                    C.POINTER(C.c_void_p), C.c_void_p]
         l.lce_tflite_model_run_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         l.lce_tflite_model_run_stats.restype = None
+        l.lce_tflite_model_use_hip_graphs.argtypes = [C.c_void_p, C.c_int32]
+        l.lce_tflite_model_use_hip_graphs.restype = None
+        l.lce_tflite_model_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.lce_tflite_model_graph_stats.restype = None
         l.lce_tflite_model_section_tensor_shape.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                             C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         _tfl = l
@@ -182,6 +186,17 @@ class LceModel:
         a, b, c = C.c_int32(), C.c_int32(), C.c_size_t()
         tflite_lib().lce_tflite_model_run_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
         return int(a.value), int(b.value), int(c.value)
+
+    def use_hip_graphs(self, on: bool = True):
+        """``lce_tflite_model_use_hip_graphs``: run_section records a section's launches once per (batch, stream, tensor
+        pointers) and replays them as one launch; needs a stream of its own (not the null stream)."""
+        tflite_lib().lce_tflite_model_use_hip_graphs(self._h, 1 if on else 0)
+
+    def graph_stats(self):
+        """(recordings made, run_section calls served by one)."""
+        a, b = C.c_int32(), C.c_int32()
+        tflite_lib().lce_tflite_model_graph_stats(self._h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def bconv2d_plan(self, op_index: int, batch: int, semantics: int = _amd.SEM_OPTIMIZED) -> "_amd.Bconv2dPlan":
         """A ready plan (weights set) for LceBconv2d operator ``op_index`` at the given batch size."""

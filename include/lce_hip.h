@@ -92,6 +92,16 @@ lce_hip_status lce_hip_host_unregister(void* host_ptr);
 lce_hip_status lce_hip_stream_create(void** stream);
 lce_hip_status lce_hip_stream_destroy(void* stream);
 lce_hip_status lce_hip_stream_synchronize(void* stream);
+/* HIP graphs for hosts without a HIP binding: everything launched on `stream` (a stream from lce_hip_stream_create, not the
+ * null stream) between begin and end is recorded instead of executed -- lce_hip_bconv2d_run / _run_dual of plans that have
+ * run once before, lce_hip_bitpack / _unpack / _bmaxpool -- and comes back as ONE launchable object: a chain of short layers
+ * replays without a host call per kernel.  The recorded launches keep the device pointers they were given.  A plan's first run
+ * (uploads, a known-answer check) cannot be recorded: run the sequence once eagerly first.  end_capture returns the error of
+ * a failed recording and leaves the stream usable. */
+lce_hip_status lce_hip_graph_begin_capture(void* stream);
+lce_hip_status lce_hip_graph_end_capture(void* stream, void** graph);
+lce_hip_status lce_hip_graph_launch(void* graph, void* stream);
+lce_hip_status lce_hip_graph_destroy(void* graph);
 
 /* ------------------------------------------------------------------------------------
  * LceQuantize / LceDequantize

@@ -110,6 +110,16 @@ lce_hip_status lce_tflite_model_section_tensor_shape(lce_tflite_model* model, in
  * be NULL. */
 void lce_tflite_model_run_stats(lce_tflite_model* model, int32_t* cached_plans, int32_t* fused_quantize_ops, size_t* scratch_bytes);
 
+/* HIP graphs for lce_tflite_model_run_section (off by default).  A binary section is a chain of short kernels -- QuickNet's
+ * last layers take 10-17 us each -- and a host call per kernel leaves gaps between them.  With graphs on, the launches of a
+ * section are recorded once per (section, batch, semantics, stream, tensor pointers) and replayed as ONE launch: the first call
+ * with such a key runs eagerly (plans, uploads, buffers), the second records and launches, later ones replay.  Needs a stream
+ * of its own (not NULL: the null stream cannot be recorded; lce_hip_stream_create).  The recording holds the device pointers it
+ * was given: call with the same tensors to replay, with others to get another recording; turning graphs off drops them all.
+ * If a section cannot be recorded it simply keeps running eagerly.  graph_stats: recordings made / launches served by one. */
+void lce_tflite_model_use_hip_graphs(lce_tflite_model* model, int32_t on);
+void lce_tflite_model_graph_stats(lce_tflite_model* model, int32_t* recorded, int32_t* replays);
+
 /* Builds a ready-to-run plan for operator `index`, which must be an LceBconv2d: descriptor
  * from the op's option map + tensor shapes / types / output quantization exactly as
  * bconv2d::Init + Prepare collect them (tflite/kernels/bconv2d.cc:85-131,137-300), weights

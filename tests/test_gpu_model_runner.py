@@ -140,3 +140,73 @@ def test_run_section_through_the_c_abi_alone():
         model.run_section(5, 1, [0], [0])
     with pytest.raises(amd.LceHipError):
         model.run_section(0, 1, [0] * len(sec.inputs), outs)     # null input pointer
+
+
+def test_run_section_replays_a_recorded_hip_graph():
+    """lce_tflite_model_use_hip_graphs: on a stream of its own the section runs eagerly once, is recorded at the second call and
+    replayed afterwards -- same bytes as the eager run and as the oracle every time, new inputs in the same buffers included; other
+    tensor pointers get their own recording; a larger batch (which reallocates the model's intermediates) drops the recordings; the
+    null stream is never recorded.  No torch: lce_hip_* only."""
+    import ctypes as C
+    data, p = small_model(24)
+    model = mr.LceModel(data)
+    sec = model.sections[0]
+    lib = amd.lib()
+    stream = C.c_void_p()
+    amd.check(lib.lce_hip_stream_create(C.byref(stream)))
+
+    def buffers(n):
+        ins, outs, host = [], [], []
+        for t in sec.inputs:
+            _, nbytes = model.section_tensor_shape(0, t, n)
+            d = C.c_void_p()
+            amd.check(lib.lce_hip_malloc(C.byref(d), C.c_size_t(nbytes)))
+            ins.append(d.value)
+        for t in sec.outputs:
+            dims, nbytes = model.section_tensor_shape(0, t, n)
+            d = C.c_void_p()
+            amd.check(lib.lce_hip_malloc(C.byref(d), C.c_size_t(nbytes)))
+            outs.append(d.value)
+            host.append(np.empty(dims, mr._NP[model.tensors[t].type]))
+        return ins, outs, host
+
+    def run_and_check(n, seed, ins, outs, host, st):
+        x = synth.rng(seed).uniform(-1.5, 1.5, (n, 12, 12, 64)).astype(np.float32)
+        want = dict(zip(model.outputs, oracle_forward(x, p)))
+        amd.check(lib.lce_hip_memcpy_h2d(C.c_void_p(ins[0]), x.ctypes.data_as(C.c_void_p), C.c_size_t(x.nbytes), st))
+        for d, h in zip(outs, host):
+            amd.check(lib.lce_hip_memset(C.c_void_p(d), 0x5A, C.c_size_t(h.nbytes), st))
+        model.run_section(0, n, ins, outs, stream=st.value or 0)
+        for d, h in zip(outs, host):
+            amd.check(lib.lce_hip_memcpy_d2h(h.ctypes.data_as(C.c_void_p), C.c_void_p(d), C.c_size_t(h.nbytes), st))
+        amd.check(lib.lce_hip_stream_synchronize(st))
+        for t, h in zip(sec.outputs, host):
+            assert np.array_equal(h.view(np.uint8), want[t].view(np.uint8)), (n, seed, t)
+
+    model.use_hip_graphs(True)
+    a = buffers(6)
+    for k in range(4):                                     # eager, record + launch, replay, replay
+        run_and_check(6, 50 + k, *a, stream)
+        assert model.graph_stats() == [(0, 0), (1, 1), (1, 2), (1, 3)][k], k
+    assert model.run_stats()[1] == 1                       # (the fused LceQuantize is counted for replays too)
+    b = buffers(6)                                         # other tensors: their own recording
+    for k in range(3):
+        run_and_check(6, 60 + k, *b, stream)
+    assert model.graph_stats() == (2, 5)
+    run_and_check(6, 70, *a, stream)                       # the first recording is still good
+    assert model.graph_stats() == (2, 6)
+    run_and_check(6, 71, *a, C.c_void_p(None))             # the null stream: eager, nothing recorded
+    assert model.graph_stats() == (2, 6)
+    c = buffers(9)                                         # larger batch: intermediates reallocated, recordings dropped
+    for k in range(3):
+        run_and_check(9, 80 + k, *c, stream)
+    assert model.graph_stats() == (3, 8)
+    for k in range(3):                                     # ... so the first key records again (eager, record, replay)
+        run_and_check(6, 90 + k, *a, stream)
+    assert model.graph_stats() == (4, 10)
+    model.use_hip_graphs(False)
+    run_and_check(6, 99, *a, stream)
+    assert model.graph_stats() == (4, 10)
+    for d in a[0] + a[1] + b[0] + b[1] + c[0] + c[1]:
+        amd.check(lib.lce_hip_free(C.c_void_p(d)))
+    amd.check(lib.lce_hip_stream_destroy(stream))
