@@ -35,6 +35,17 @@ inline FastDiv make_fastdiv(uint32_t d) {
   f.shift = l - 1;
   return f;
 }
+// The streaming kernel's form: branch-free, (mulhi(n, magic) >> shift) + (n & pass), pass = all ones for a divisor <= 1 -- one scalar
+// register per divisor where `magic == 0 ? n : ...` keeps a 64-bit lane mask of the comparison live through the K loop.
+struct FastDivNB {
+  uint32_t magic;
+  uint32_t shift;
+  uint32_t pass;
+};
+inline FastDivNB make_fastdiv_nb(uint32_t d) {
+  const FastDiv f = make_fastdiv(d);
+  return FastDivNB{f.magic, f.shift, f.magic == 0u ? 0xffffffffu : 0u};
+}
 
 struct ConvArgs {
   // geometry of this launch
@@ -167,7 +178,7 @@ struct StreamArgs {
   uint32_t tab_seg;                        // STRIPS: one dword per pixel block: the local segment it lies in
   uint32_t sign_bytes;                     // bytes of the second output of this launch (B * OH * OW * Wout * 4)
   float a_bt, cmin, cmax, bit_thr;
-  FastDiv div_ipr, div_qg, div_srs, div_spi, div_r, div_rseg;
+  FastDivNB div_ipr, div_qg, div_srs, div_spi, div_r, div_rseg;
 };
 
 }  // namespace lce

@@ -53,9 +53,8 @@ __device__ unsigned long long lce_stream_tl[512 * 64];
 
 // fastdiv without the divisor-1 branch: a divisor of 1 has magic 0, so the multiply-high contributes 0 and the
 // masked addend is n itself.
-LCE_DEVICE uint32_t fastdiv_nb(uint32_t n, FastDiv d) {
-  const uint32_t one = 0u - (uint32_t)(d.magic == 0u);
-  return (mulhi_u32(n, d.magic) >> d.shift) + (n & one);
+LCE_DEVICE uint32_t fastdiv_nb(uint32_t n, FastDivNB d) {
+  return (mulhi_u32(n, d.magic) >> d.shift) + (n & d.pass);
 }
 
 // Dword DD of fp4_of_full_word (lce_kernels_mfma.h): byte DD of the word as eight FP4 codes, 4 VALU.

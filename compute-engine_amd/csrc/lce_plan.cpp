@@ -611,12 +611,12 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.a_bt = (float)p.backtransform_add;
   G.cmin = (float)p.clamp_min;
   G.cmax = (float)p.clamp_max;
-  G.div_ipr = make_fastdiv((uint32_t)G.IPR);
-  G.div_qg = make_fastdiv((uint32_t)G.QG);
-  G.div_srs = make_fastdiv((uint32_t)G.SRS);
-  G.div_spi = make_fastdiv((uint32_t)G.SPI);
-  G.div_r = make_fastdiv((uint32_t)G.R);
-  G.div_rseg = make_fastdiv((uint32_t)std::max(1, G.RSEG));
+  G.div_ipr = make_fastdiv_nb((uint32_t)G.IPR);
+  G.div_qg = make_fastdiv_nb((uint32_t)G.QG);
+  G.div_srs = make_fastdiv_nb((uint32_t)G.SRS);
+  G.div_spi = make_fastdiv_nb((uint32_t)G.SPI);
+  G.div_r = make_fastdiv_nb((uint32_t)G.R);
+  G.div_rseg = make_fastdiv_nb((uint32_t)std::max(1, G.RSEG));
   return G;
 }
 
