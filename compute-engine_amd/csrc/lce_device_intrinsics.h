@@ -84,6 +84,10 @@ LCE_DEVICE void settle_ballots(unsigned long long (&b)[N]) {
   else if constexpr (N == 3) asm("s_nop 4" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]));
   else asm("s_nop 4" : "+s"(b[0]), "+s"(b[1]), "+s"(b[2]), "+s"(b[3]));
 }
+// Ordering aids for ballots that are written to their lanes one K-step AFTER the compares (lce_kernels_stream.h: the MFMAs and the
+// next unit's work in between are the wait states): `held` cannot be consumed before the values on the right exist.
+LCE_DEVICE void hold_until(unsigned long long& held, unsigned long long a, unsigned long long b) { asm("" : "+s"(held) : "s"(a), "s"(b)); }
+LCE_DEVICE void hold_until(unsigned long long& held, float a, float b) { asm("" : "+s"(held) : "v"(a), "v"(b)); }
 LCE_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
 
 // a * b + c with TWO roundings, as the reference's portable C++ computes it

@@ -516,26 +516,65 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // (KSPLIT: only local tile 0, the wave's own 32 channels -- 8 units for float / int8, 16 single-word units for bits;
   //  the scratch is [32 pixel rows][32 channels])
   constexpr int NUA = (KSPLIT && DST != kDstBitpacked) ? 8 : 16;   // phase A units
-  auto epi_a = [&](auto tc, f32x16 (&acc)[2]) LCE_LAMBDA_INLINE {
+  // Ballots -> lanes.  A v_writelane must not read an SGPR a VALU compare wrote less than 4 wait states ago (settle_ballots: an s_nop 4,
+  // ~8 cycles of a lone wave, per unit).  Where ONE unit rides per K-step (the 256-channel bank and the K-split kernel) the K loop
+  // writes a unit's ballots one K-step LATER instead (PIPE): two MFMAs and the next unit's own work lie in between, no padding.
+  constexpr bool kPipeBallots = KSPLIT || KS * 4 / 9 >= 16;
+  unsigned long long pend[2] = {0ull, 0ull};
+  // the lanes of unit T's ballots (pend as unit T left it)
+  auto flush_ballots = [&](auto Tc) LCE_LAMBDA_INLINE {
+    constexpr int T = decltype(Tc)::value;
+    if constexpr (DST == kDstBitpacked) {
+      constexpr int q = (T & 3) + 8 * (T >> 2);
+#pragma unroll
+      for (int j = 0; j < (KSPLIT ? 1 : 2); ++j) {
+        bw[j] = write_lane_settled<q>((uint32_t)pend[j], bw[j]);
+        bw[j] = write_lane_settled<q + 4>((uint32_t)(pend[j] >> 32), bw[j]);
+      }
+    } else {
+      constexpr int j = KSPLIT ? 0 : T >> 3, r0 = (T & 7) * 2, q0 = (r0 & 3) + 8 * (r0 >> 2);
+      bw[j] = write_lane_settled<q0>((uint32_t)pend[0], bw[j]);
+      bw[j] = write_lane_settled<q0 + 4>((uint32_t)(pend[0] >> 32), bw[j]);
+      bw[j] = write_lane_settled<q0 + 1>((uint32_t)pend[1], bw[j]);
+      bw[j] = write_lane_settled<q0 + 5>((uint32_t)(pend[1] >> 32), bw[j]);
+    }
+  };
+  auto epi_a = [&](auto tc, f32x16 (&acc)[2], auto pipe_) LCE_LAMBDA_INLINE {
     constexpr int t = decltype(tc)::value;
+    constexpr bool PIPE = decltype(pipe_)::value != 0 && kPipeBallots;
     if constexpr (DST == kDstBitpacked && KSPLIT) {
       constexpr int r = t, q = (r & 3) + 8 * (r >> 2);
       unsigned long long bits[1];
       bits[0] = wave_ballot(acc[0][r] > tj[0]);
-      settle_ballots(bits);
-      bw[0] = write_lane_settled<q>((uint32_t)bits[0], bw[0]);
-      bw[0] = write_lane_settled<q + 4>((uint32_t)(bits[0] >> 32), bw[0]);
+      if constexpr (PIPE) {
+        if constexpr (t > 0) { hold_until(pend[0], bits[0], bits[0]); flush_ballots(IntC<(t > 0 ? t - 1 : 0)>{}); }
+        pend[0] = bits[0];
+      } else {
+        settle_ballots(bits);
+        bw[0] = write_lane_settled<q>((uint32_t)bits[0], bw[0]);
+        bw[0] = write_lane_settled<q + 4>((uint32_t)(bits[0] >> 32), bw[0]);
+      }
     } else if constexpr (DST == kDstBitpacked) {
       // unit t = register r: the 32 channel bits of rows q and q + 4, dropped into the lanes that will store them
       constexpr int r = t, q = (r & 3) + 8 * (r >> 2);
       unsigned long long bits[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) bits[j] = wave_ballot(acc[j][r] > tj[j]);
-      settle_ballots(bits);
+      if constexpr (PIPE) {
+        if constexpr (t > 0) {
+          hold_until(pend[0], bits[0], bits[1]);
+          hold_until(pend[1], bits[0], bits[1]);
+          flush_ballots(IntC<(t > 0 ? t - 1 : 0)>{});
+        }
+        pend[0] = bits[0];
+        pend[1] = bits[1];
+      } else {
+        settle_ballots(bits);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bw[j] = write_lane_settled<q>((uint32_t)bits[j], bw[j]);
-        bw[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), bw[j]);
+        for (int j = 0; j < 2; ++j) {
+          bw[j] = write_lane_settled<q>((uint32_t)bits[j], bw[j]);
+          bw[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), bw[j]);
+        }
       }
     } else {
       constexpr int j = KSPLIT ? 0 : t >> 3, r0 = (t & 7) * 2;          // registers r0, r0 + 1: pixel rows row0, row0 + 1
@@ -558,12 +597,22 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         unsigned long long bits[2];
         bits[0] = wave_ballot(y[0] < bit_thrv[j]);
         bits[1] = wave_ballot(y[1] < bit_thrv[j]);
-        settle_ballots(bits);
-        constexpr int q0 = (r0 & 3) + 8 * (r0 >> 2);
-        bw[j] = write_lane_settled<q0>((uint32_t)bits[0], bw[j]);
-        bw[j] = write_lane_settled<q0 + 4>((uint32_t)(bits[0] >> 32), bw[j]);
-        bw[j] = write_lane_settled<q0 + 1>((uint32_t)bits[1], bw[j]);
-        bw[j] = write_lane_settled<q0 + 5>((uint32_t)(bits[1] >> 32), bw[j]);
+        if constexpr (PIPE) {
+          if constexpr (t > 0) {
+            hold_until(pend[0], bits[0], bits[1]);      // behind this unit's compares ...
+            hold_until(pend[1], y[0], y[1]);            // ... and its transform
+            flush_ballots(IntC<(t > 0 ? t - 1 : 0)>{});
+          }
+          pend[0] = bits[0];
+          pend[1] = bits[1];
+        } else {
+          settle_ballots(bits);
+          constexpr int q0 = (r0 & 3) + 8 * (r0 >> 2);
+          bw[j] = write_lane_settled<q0>((uint32_t)bits[0], bw[j]);
+          bw[j] = write_lane_settled<q0 + 4>((uint32_t)(bits[0] >> 32), bw[j]);
+          bw[j] = write_lane_settled<q0 + 1>((uint32_t)bits[1], bw[j]);
+          bw[j] = write_lane_settled<q0 + 5>((uint32_t)(bits[1] >> 32), bw[j]);
+        }
       }
     }
   };
@@ -811,10 +860,10 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
           constexpr int lo = stream_unit_lo(NUA, ks - SA0, SA - SA0), hi = stream_unit_lo(NUA, ks - SA0 + 1, SA - SA0);
           if constexpr (lo == 0) wave_lds_order();     // the scratch's previous readers are done (in-order LDS)
 #ifndef LCE_ST_NOEPI_A
-          if constexpr (lo + 0 < hi) epi_a(IntC<lo + 0>{}, acc[PAR ^ 1]);
-          if constexpr (lo + 1 < hi) epi_a(IntC<lo + 1>{}, acc[PAR ^ 1]);
-          if constexpr (lo + 2 < hi) epi_a(IntC<lo + 2>{}, acc[PAR ^ 1]);
-          if constexpr (lo + 3 < hi) epi_a(IntC<lo + 3>{}, acc[PAR ^ 1]);
+          if constexpr (lo + 0 < hi) epi_a(IntC<lo + 0>{}, acc[PAR ^ 1], IntC<1>{});
+          if constexpr (lo + 1 < hi) epi_a(IntC<lo + 1>{}, acc[PAR ^ 1], IntC<1>{});
+          if constexpr (lo + 2 < hi) epi_a(IntC<lo + 2>{}, acc[PAR ^ 1], IntC<1>{});
+          if constexpr (lo + 3 < hi) epi_a(IntC<lo + 3>{}, acc[PAR ^ 1], IntC<1>{});
 #endif
           static_assert(hi - lo <= 4, "units per gap");
         }
@@ -828,6 +877,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         }
 #endif
+        if constexpr (kPipeBallots && (SIGN || DST == kDstBitpacked) && !FIRST && ks == SA) flush_ballots(IntC<NUA - 1>{});   // the last unit's
         if constexpr (SIGN && !FIRST && ks == SA) sign_store(epi_sob);      // phase A is complete: the drained block's sign words
         if constexpr (ks == SA) load_ctx(u + 1, nxt);
         if constexpr (KSPLIT && ks == (NG - 1) * GA - 1) ctx_khalf(nxt);     // (in front of the last group, whose reads use it)
@@ -920,7 +970,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     }
     wave_lds_order();
     auto drain_a = [&](auto tc) LCE_LAMBDA_INLINE {
-      if constexpr (decltype(tc)::value < NUA) epi_a(tc, last);
+      if constexpr (decltype(tc)::value < NUA) epi_a(tc, last, IntC<0>{});
     };
     drain_a(IntC<0>{}); drain_a(IntC<1>{}); drain_a(IntC<2>{}); drain_a(IntC<3>{});
     drain_a(IntC<4>{}); drain_a(IntC<5>{}); drain_a(IntC<6>{}); drain_a(IntC<7>{});

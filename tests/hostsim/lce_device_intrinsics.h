@@ -101,6 +101,8 @@ inline uint32_t write_lane(uint32_t value, uint32_t old) {
 }
 template <int LANE> inline uint32_t write_lane_settled(uint32_t value, uint32_t old) { return write_lane<LANE>(value, old); }
 template <int N> inline void settle_ballots(unsigned long long (&)[N]) {}
+inline void hold_until(unsigned long long&, unsigned long long, unsigned long long) {}
+inline void hold_until(unsigned long long&, float, float) {}
 inline uint32_t shfl_xor(uint32_t v, int mask) {
   const int lane = g_ctx.tid_x & 63;
   g_ctx.xchg[lane] = v;
