@@ -517,9 +517,12 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   //  the scratch is [32 pixel rows][32 channels])
   constexpr int NUA = (KSPLIT && DST != kDstBitpacked) ? 8 : 16;   // phase A units
   // Ballots -> lanes.  A v_writelane must not read an SGPR a VALU compare wrote less than 4 wait states ago (settle_ballots: an s_nop 4,
-  // ~8 cycles of a lone wave, per unit).  Where ONE unit rides per K-step (the 256-channel bank and the K-split kernel) the K loop
-  // writes a unit's ballots one K-step LATER instead (PIPE): two MFMAs and the next unit's own work lie in between, no padding.
-  constexpr bool kPipeBallots = KSPLIT || KS * 4 / 9 >= 16;
+  // ~8 cycles of a lone wave, per unit).  The K loop writes a unit's ballots one unit LATER instead (PIPE), no padding: unit t's lane
+  // writes of unit t - 1 are held behind unit t's own compares and transform (hold_until) and behind unit t - 1's lane writes of unit
+  // t - 2 (the chain through bw[]), so at least six instructions -- with one unit per K-step also two MFMAs -- lie in between.
+  // (Float kernels with several units per K-step -- 64 / 128 input channels -- keep the padded form: store-bound, they measured equal
+  //  or 3 % slower with it, profiles/r04/ballots_one_kstep_late.txt.)
+  constexpr bool kPipeBallots = KSPLIT || KS * 4 / 9 >= 16 || DST != kDstFloat;
   unsigned long long pend[2] = {0ull, 0ull};
   // the lanes of unit T's ballots (pend as unit T left it)
   auto flush_ballots = [&](auto Tc) LCE_LAMBDA_INLINE {

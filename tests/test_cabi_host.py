@@ -134,13 +134,16 @@ def test_kernel_selection_is_host_side_and_named():
     deep = amd.Bconv2dPlan(amd.ConvParams(8, 28, 28, 2048, 3, 3, 256, padding=amd.PADDING_SAME, pad_values=1))
     assert deep.kernel_name().startswith("bconv2d_mfma<f32,")
     # 128 input channels, float, batch 256: the streaming kernel since round 4 (it was behind the block GEMM before the first block step
-    # took its weights as they arrive); the block GEMM when asked for, and for a bitpacked output
+    # took its weights as they arrive); the block GEMM when asked for
     mid = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1))
     assert mid.kernel_name() == "bconv2d_stream<f32,3x3x128,rows28>"
     mid.set_option("engine", "direct")
     assert mid.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     midb = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.BITPACKED))
-    assert midb.kernel_name() == "bconv2d_mfma_direct<bitpacked,128x128>"
+    assert midb.kernel_name() == "bconv2d_stream<bitpacked,3x3x128,rows28>"      # (stride 1; strided bitpacked layers: block GEMM)
+    mids = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 256, stride_height=2, stride_width=2, padding=amd.PADDING_SAME,
+                                          pad_values=1, dst_type=amd.BITPACKED))
+    assert mids.kernel_name().startswith("bconv2d_mfma_direct<bitpacked")
     grouped = amd.Bconv2dPlan(amd.ConvParams(1, 8, 8, 128, 3, 3, 64, groups=2))
     grouped.set_option("engine", "mfma")
     assert grouped.kernel_name() == ""                              # refused: grouped convolution
@@ -185,8 +188,8 @@ def test_empty_batch_is_legal_and_a_no_op():
     (56, 256, "BITPACKED", "bconv2d_stream<bitpacked,3x3x256,rows56>"),
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
     (28, 128, "F32", "bconv2d_stream<f32,3x3x128,rows28>"),        # round 4 (profiles/r04/low_k_on_the_streaming_kernel.txt)
-    (56, 64, "I8", "bconv2d_stream<i8,3x3x64,rows56>"),            # int8 without the second output; with it (run_dual) the block GEMM
-    (28, 128, "BITPACKED", "bconv2d_mfma_direct<bitpacked,128x128>"),
+    (56, 64, "I8", "bconv2d_stream<i8,3x3x64,rows56>"),            # int8: with and without the second output
+    (28, 128, "BITPACKED", "bconv2d_stream<bitpacked,3x3x128,rows28>"),   # since the ballots lost their padding
     (14, 256, "F32", "bconv2d_stream<f32,3x3x256,rows14>"),
     (7, 512, "F32", "bconv2d_stream<f32,3x3x512,rows7>"),          # round 4: K split over wave pairs, blocks cut across 4 images
     (7, 512, "I8", "bconv2d_stream<i8,3x3x512,rows7>"),
@@ -198,19 +201,16 @@ def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
     assert amd.Bconv2dPlan(p).kernel_name() == want
 
 
-def test_planner_keeps_one_choice_per_kind_of_call():
-    """int8, 64 / 128 input channels: the streaming kernel wins without the second output, the block GEMM with it
-    (profiles/r04/low_k_on_the_streaming_kernel.txt).  run_dual drives a twin plan, so both names stay valid side by side."""
-    p = amd.ConvParams(256, 56, 56, 64, 3, 3, 64, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.I8)
-    plan = amd.Bconv2dPlan(p)
-    assert plan.kernel_name() == "bconv2d_stream<i8,3x3x64,rows56>"
-    assert plan.kernel_name(dual=True) == "bconv2d_mfma_direct<i8,256x64>"
-    assert plan.kernel_name() == "bconv2d_stream<i8,3x3x64,rows56>"
+def test_planner_choice_for_run_dual():
+    """lce_hip_bconv2d_plan_kernel_name_dual names the kernel run_dual launches.  The C ABI keeps one selection per kind of call
+    where the auto rule depends on the second output (a twin plan, lce_hip_api.hip); since the ballots of the second output lost
+    their padding the streaming kernel wins both ways on every measured layer, so the two names agree."""
+    for hw, c, dst in ((56, 64, amd.I8), (28, 128, amd.I8), (28, 128, amd.F32), (56, 256, amd.F32)):
+        p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst)
+        plan = amd.Bconv2dPlan(p)
+        assert plan.kernel_name(dual=True) == plan.kernel_name() and plan.kernel_name().startswith("bconv2d_stream<")
     plan.set_option("engine", "mfma")                       # a forced engine holds for both kinds of call
-    assert plan.kernel_name(dual=True) == plan.kernel_name()
-    p = amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.F32)
-    plan = amd.Bconv2dPlan(p)                               # float: the same kernel either way
-    assert plan.kernel_name(dual=True) == plan.kernel_name() == "bconv2d_stream<f32,3x3x128,rows28>"
+    assert plan.kernel_name(dual=True) == plan.kernel_name() and plan.kernel_name().startswith("bconv2d_mfma")
 
 
 def test_planner_fallbacks():
