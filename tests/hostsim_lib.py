@@ -35,7 +35,10 @@ def make_desc(spec: O.ConvSpec, dst_type: int, out_scale: float = 1.0, out_zero_
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        subprocess.run(["make", "-C", _DIR], check=True, capture_output=True)
+        import fcntl
+        with open(os.path.join(_DIR, ".build.lock"), "w") as lock:       # (pytest-xdist workers: one of them builds, the others wait)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.run(["make", "-C", _DIR], check=True, capture_output=True)
         _lib = C.CDLL(os.path.join(_DIR, "liblce_hostsim.so"))
         _lib.hostsim_last_error.restype = C.c_char_p
         _lib.hostsim_fastdiv.restype = C.c_uint32
