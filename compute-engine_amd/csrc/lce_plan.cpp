@@ -906,12 +906,12 @@ static bool stream_candidate(const HostPlan& p, bool want_sign) {
   // Later in round 4 the ballots of the second / bitpacked output lost their padding nops (lce_kernels_stream.h, kPipeBallots) and the picture
   // changed (one box, profiles/r04/ballots_one_kstep_late.txt, us, streaming kernel vs block GEMM): int8 WITH the second output 22.9 vs 24.3
   // (28x28x128), 34.2 vs 34.7 (56x56x64), stride 2: 22.8 vs 25.0 and 14.9 vs 16.2 -> int8 both ways; bitpacked output, stride 1: 16.1 vs 17.5
-  // and 21.8 vs 23.9 -> taken (strided bitpacked layers were not measured and stay on the block GEMM).
+  // and 21.8 vs 23.9, stride 2 (tools/strided_bp_check.py): 15.5 vs 18.3 (56x56x64 -> 128) and 10.8 vs 12.2 (28x28x128 -> 256) -> taken.
   (void)want_sign;     // (no layer's answer depends on it any more; the C ABI's twin plan for run_dual stays for rules that do)
   if ((kch == 1 || kch == 2) && p.d.channels_out >= 64 && p.d.in_width <= 64) {
     const bool strided = p.d.stride_height > 1 || p.d.stride_width > 1;
     if (p.d.dst_type == LCE_HIP_I8) return true;
-    if (p.d.dst_type == LCE_HIP_BITPACKED && !strided) return true;
+    if (p.d.dst_type == LCE_HIP_BITPACKED) return true;
     if (p.d.dst_type == LCE_HIP_F32 && (strided || kch == 2)) return true;
   }
   if (kch == 8) return p.d.channels_out >= 128;

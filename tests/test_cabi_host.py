@@ -140,10 +140,10 @@ def test_kernel_selection_is_host_side_and_named():
     mid.set_option("engine", "direct")
     assert mid.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     midb = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.BITPACKED))
-    assert midb.kernel_name() == "bconv2d_stream<bitpacked,3x3x128,rows28>"      # (stride 1; strided bitpacked layers: block GEMM)
+    assert midb.kernel_name() == "bconv2d_stream<bitpacked,3x3x128,rows28>"      # (strided ones too)
     mids = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 256, stride_height=2, stride_width=2, padding=amd.PADDING_SAME,
                                           pad_values=1, dst_type=amd.BITPACKED))
-    assert mids.kernel_name().startswith("bconv2d_mfma_direct<bitpacked")
+    assert mids.kernel_name() == "bconv2d_stream<bitpacked,3x3x128,rows14>"
     grouped = amd.Bconv2dPlan(amd.ConvParams(1, 8, 8, 128, 3, 3, 64, groups=2))
     grouped.set_option("engine", "mfma")
     assert grouped.kernel_name() == ""                              # refused: grouped convolution
