@@ -564,6 +564,13 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     plan->device_current = false;
     return LCE_HIP_OK;
   }
+  if (!strcmp(key, "stream_interleave")) {   // the streaming kernel's segment -> block map: 1 = block b owns segments b, b + grid, ... (a compact write window), 0 = consecutive ones
+    if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_interleave must be 0 or 1");
+    h.stream_interleave_pref = value[0] == '1';
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "stream_flat")) {       // testing aid for the streaming kernel: 0 = never cut pixel blocks across a block's images
     if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_flat must be 0 or 1");
     h.stream_noflat = value[0] == '0';
@@ -715,7 +722,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
         LCE_HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         plan->lds_opt_in = (void*)fn;
       }
-      const dim3 grid((unsigned)((G.S + G.SPB - 1) / G.SPB), (unsigned)h.st_ny);
+      const dim3 grid((unsigned)G.GX, (unsigned)h.st_ny);
       hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, G, (const uint8_t*)in, plan->d_wq.ptr, plan->d_mul.ptr,
                          plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_sched.ptr, out, with_sign ? sgn : nullptr);
       LCE_HIP_TRY(hipGetLastError());

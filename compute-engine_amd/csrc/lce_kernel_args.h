@@ -162,6 +162,11 @@ struct StreamArgs {
   int32_t PBS;                 // pixel blocks per segment = ceil(RS * OW / 32)
   int32_t S;                   // segments of this launch = B * SPI
   int32_t SPB;                 // segments per block
+  // Which segments a block owns (round 5).  GSTR == 1: block b the SPB CONSECUTIVE segments from b * SPB (G0M = SPB) -- with whole
+  // images as segments, block b writes image b row by row, 256 write streams megabytes apart.  GSTR == GX > 1 ("interleaved"): block b
+  // the segments b, b + GX, b + 2 GX, ... (G0M = 1): at any moment the launch's blocks write GX consecutive segments, one compact
+  // window that moves through the output (profiles/r05/store_window.txt).  The context table's output offsets carry gl * GSTR.
+  int32_t GSTR, G0M, GX;       // segment stride inside a block's run, block index -> first segment, blocks of this launch (grid.x)
   int32_t pph_log;             // log2 of the pixel blocks per block step: 4 waves = (4 >> pph_log) channel slices x that
   // STRIPS (images too wide for a whole padded row per ring slot): a segment is RS output rows x WSo output COLUMNS; segments are
   // numbered (image, strip, row segment), a block's run stays inside one strip.  A ring row then holds the strip's Wp = (WSo-1)*SW+KW
@@ -178,7 +183,7 @@ struct StreamArgs {
   uint32_t tab_seg;                        // STRIPS: one dword per pixel block: the local segment it lies in
   uint32_t sign_bytes;                     // bytes of the second output of this launch (B * OH * OW * Wout * 4)
   float a_bt, cmin, cmax, bit_thr;
-  FastDivNB div_ipr, div_qg, div_srs, div_spi, div_r, div_rseg;
+  FastDivNB div_ipr, div_qg, div_srs, div_spi, div_r, div_rseg, div_gstr;
 };
 
 }  // namespace lce

@@ -128,9 +128,12 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 
   LCE_SPH(0);
   // ---- this block's run of segments ----
-  const int g0 = block_idx_x() * G.SPB;
+  // (segments g0, g0 + GSTR, g0 + 2 GSTR, ... below S, at most SPB of them: consecutive ones with GSTR = 1, G0M = SPB; with
+  //  GSTR = the launch's block count and G0M = 1 the blocks' runs interleave, StreamArgs)
+  const int g0 = block_idx_x() * G.G0M;
   int nseg = G.S - g0;
-  nseg = nseg < 0 ? 0 : (nseg > G.SPB ? G.SPB : nseg);
+  nseg = nseg <= 0 ? 0 : (int)fastdiv_nb((uint32_t)(nseg + G.GSTR - 1), G.div_gstr);
+  nseg = nseg > G.SPB ? G.SPB : nseg;
   // pixel blocks of this block's stream: per segment, or (flat) cut from its segments' pixels laid end to end -- a short last
   // block's spare lanes then hold pixels past the launch, whose stores fall outside the output's buffer resource
   const int nblk_all = FLATC && G.flat ? (nseg * G.NPX + 31) >> 5 : nseg * G.PBS;
@@ -171,7 +174,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       I.c0 = (int)(I.rem - I.x * (uint32_t)G.QG) * 4;
       I.gl = fastdiv_nb(I.s, G.div_srs);
     } else if constexpr (c == 3) {
-      I.g = (uint32_t)g0 + I.gl;
+      I.g = (uint32_t)g0 + I.gl * (uint32_t)G.GSTR;
       I.img = fastdiv_nb(I.g, G.div_spi);
     } else if constexpr (c == 4) {
       I.cseg = (int)(I.g - I.img * (uint32_t)G.SPI);
@@ -448,7 +451,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   uint32_t* const segbase = (uint32_t*)(lds0 + G.ring_bytes + 4 * SCRB + 4096);      // [SPB][2]
   if constexpr (STRIPS) {
     for (int gl = tid; gl < G.SPB; gl += 256) {
-      const uint32_t g = (uint32_t)(g0 + gl);
+      const uint32_t g = (uint32_t)(g0 + gl * G.GSTR);
       const uint32_t img = fastdiv_nb(g, G.div_spi), rem = g - img * (uint32_t)G.SPI;
       const uint32_t strip = fastdiv_nb(rem, G.div_rseg), rowseg = rem - strip * (uint32_t)G.RSEG;
       const uint32_t px = (img * (uint32_t)G.OH + rowseg * (uint32_t)G.RS) * (uint32_t)G.OW + strip * (uint32_t)G.WSo;

@@ -514,6 +514,13 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     const int64_t nq = flat ? (spb * (int64_t)rs * p.out_w + 31) / 32 : spb * pbs;
     p.st_flat = flat ? 1 : 0;
     p.st_nq = (int)nq;
+    // Interleaved runs (round 5): block b owns segments b, b + gx, b + 2 gx, ... instead of spb consecutive ones, so that at any
+    // moment the launch writes gx CONSECUTIVE segments -- one window of gx * rs * OW pixels moving through the output -- instead
+    // of gx streams a whole run apart.  Same segments, same ring schedule, same tables but for the output offsets.  (Flat runs
+    // cut pixel blocks across consecutive images: they stay consecutive.)
+    const int64_t gx_plan = ceil_div((int)s, (int)spb);
+    const int64_t gstr = (p.stream_interleave_pref > 0 && !flat && spb > 1) ? gx_plan : 1;
+    p.st_gstr = (int)gstr;
     if (nq * 1024 > (64ll << 20)) continue;               // the context table: 1 KiB per pixel block
     p.st_rs = rs; p.st_spi = spi; p.st_srs = (rs - 1) * d.stride_height + d.filter_height;
     p.st_pbs = pbs; p.st_pph_log = pph_log; p.st_ny = ny;
@@ -559,7 +566,8 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
         // output pixel of the lane's first stored row, relative to the run's first pixel: segments and their pixels follow each
         // other in memory -- or (strips) a segment's rows are OW pixels apart and a pixel block lies inside one of them
         // (strips: relative to the SEGMENT's first pixel; the kernel adds the segment's place)
-        const int64_t blk_px = strips ? ((pb * 32) / ow_seg) * (int64_t)p.out_w + (pb * 32) % ow_seg : gl * npx + pb * 32;
+        // (interleaved runs: the block's local segment gl is segment g0 + gl * gstr of the launch)
+        const int64_t blk_px = strips ? ((pb * 32) / ow_seg) * (int64_t)p.out_w + (pb * 32) % ow_seg : gl * gstr * npx + pb * 32;
         e[3] = (uint32_t)((blk_px + rowl) * (int64_t)row_bytes);
         if (partial) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
         if (strips) p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + n_sgn + q] = (uint32_t)gl;
@@ -594,6 +602,12 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   // (flat pixel blocks are cut for runs of exactly st_spb segments: a shorter run's last block would spill into the next
   //  block's pixels, so a smaller launch keeps the planned run length and uses fewer blocks)
   if (p.st_flat) G.SPB = p.st_spb;
+  G.GSTR = 1; G.G0M = G.SPB; G.GX = ceil_div(G.S, std::max(1, G.SPB));
+  if (p.st_gstr > 1) {
+    // interleaved runs: the tables' output offsets carry the PLANNED stride, so a smaller launch keeps it and its blocks' runs
+    // end earlier (block b: segments b, b + gstr, ... below S)
+    G.GSTR = p.st_gstr; G.G0M = 1; G.SPB = p.st_spb; G.GX = std::min(G.S, p.st_gstr);
+  }
   G.pph_log = p.st_pph_log;
   G.flat = p.st_flat;
   G.NPX = p.st_rs * p.out_w;
@@ -617,6 +631,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.div_spi = make_fastdiv_nb((uint32_t)G.SPI);
   G.div_r = make_fastdiv_nb((uint32_t)G.R);
   G.div_rseg = make_fastdiv_nb((uint32_t)std::max(1, G.RSEG));
+  G.div_gstr = make_fastdiv_nb((uint32_t)G.GSTR);
   return G;
 }
 
@@ -969,6 +984,7 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       char ph[40] = "";
       if ((4 >> p.st_pph_log) < std::min(4, ceil_div(d.channels_out, 64))) snprintf(ph, sizeof ph, ",phases%d", 1 << p.st_pph_log);
       if (p.st_nstrip > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",strips%d", p.st_wso);
+      if (p.st_gstr > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",il");
       snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d%s>",
                d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.st_rs, ph);
       p.kernel_name = nm;

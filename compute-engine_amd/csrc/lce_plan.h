@@ -98,6 +98,8 @@ struct HostPlan {
   int st_pitch = 0;                          // bytes per ring row slot
   int st_nstrip = 1, st_rseg = 0, st_wso = 0;   // column strips of wide images: strips per image, row segments per image, output columns per strip
   int stream_strip_pref = -1;                // testing aid: -1 auto, 0 never, else the strip width (a multiple of 32 that divides the output width)
+  int stream_interleave_pref = 0;            // 1: a block's segments are gx apart (interleaved runs: a compact, moving write window), 0: consecutive
+  int st_gstr = 1;                           // the planned segment stride of a block's run (1: consecutive segments)
   int st_flat = 0;                           // 1: 32-pixel blocks are cut from the concatenated pixels of a block's segments (whole small images)
   int st_nq = 0;                             // pixel blocks of a full block's stream (rows of the context table)
   int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images

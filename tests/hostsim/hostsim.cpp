@@ -92,6 +92,7 @@ int g_num_cus = 256;          // what the streaming kernel's planner takes for t
 int g_stream_rows = 0;        // its segment size (0 = auto)
 int g_stream_phases = 0;      // its pixel phases per block (0 = auto)
 int g_stream_strip = -1;      // its column strips (-1 auto, 0 never, else the width)
+int g_stream_interleave = 0;  // its segment -> block map (1: interleaved runs)
 int g_pw_nj = 0;              // the pointwise kernel's 32-channel tiles per block (0 = auto)
 
 }  // namespace
@@ -104,6 +105,7 @@ void hostsim_set_sign_output(void* words) { g_sign_out = words; }
 void hostsim_set_stream(int num_cus, int rows) { g_num_cus = num_cus; g_stream_rows = rows; }
 void hostsim_set_stream_phases(int phases) { g_stream_phases = phases; }
 void hostsim_set_stream_strip(int width) { g_stream_strip = width; }
+void hostsim_set_stream_interleave(int on) { g_stream_interleave = on; }
 void hostsim_set_pointwise(int channel_tiles) { g_pw_nj = channel_tiles; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
@@ -122,6 +124,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   h.stream_rows_pref = g_stream_rows;
   h.stream_phases_pref = g_stream_phases;
   h.stream_strip_pref = g_stream_strip;
+  h.stream_interleave_pref = g_stream_interleave;
   h.pw_nj_pref = g_pw_nj;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};
@@ -155,7 +158,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
       wq.resize(wq.size() + 64, 0);
       std::vector<uint32_t> sched = h.st_tabs;
       sched.resize(sched.size() + 16, 0u);
-      launch_block_lockstep((G.S + G.SPB - 1) / G.SPB, h.st_ny, 256, (size_t)stream_lds_bytes(h), [&] {
+      launch_block_lockstep(G.GX, h.st_ny, 256, (size_t)stream_lds_bytes(h), [&] {
         fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out, sgn);
       });
     } else if (h.use_mfma && h.use_pointwise) {

@@ -98,6 +98,11 @@ def set_stream_strip(width: int = -1):
     lib().hostsim_set_stream_strip(int(width))
 
 
+def set_stream_interleave(on: int = 0):
+    """1: a block of the streaming kernel owns segments b, b + grid, ... (interleaved runs); 0: consecutive ones."""
+    lib().hostsim_set_stream_interleave(int(on))
+
+
 def set_pointwise(channel_tiles: int = 0):
     """The pointwise kernel's 32-channel tiles per block (0 = auto: 1 for the small launches of these tests)."""
     lib().hostsim_set_pointwise(int(channel_tiles))

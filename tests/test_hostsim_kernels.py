@@ -564,6 +564,40 @@ def test_stream_kernel(shape):
         H.set_stream(256, 0)
 
 
+INTERLEAVED_SHAPES = [
+    # batch, h, w, cin, cout, stride, pad, act, compute units, rows per segment, strip width (-1: whole rows), batch chunks
+    (3, 12, 10, 256, 256, (1, 1), "ONE", O.ACT_NONE, 2, 4, -1, (0, 2)),    # 9 segments over 2 blocks: runs of 5 and 4, ragged pixel blocks
+    (5, 8, 8, 128, 128, (1, 1), "ONE", O.ACT_RELU6, 3, 4, -1, (0, 3)),     # two pixel phases; 10 segments over 3 blocks (4 / 3 / 3)
+    (4, 8, 8, 64, 64, (1, 1), "SAME", O.ACT_NONE, 3, 2, -1, (0,)),         # four pixel phases, exact SAME-zero, 16 segments over 3 blocks
+    (3, 11, 9, 200, 304, (2, 2), "ONE", O.ACT_NONE, 4, 3, -1, (0, 2)),     # strides; two channel groups (grid.y: 2 blocks in x), 6 segments
+    (2, 14, 7, 512, 128, (1, 1), "ONE", O.ACT_NONE, 3, 7, -1, (0,)),       # K split over wave pairs, 4 segments over 3 blocks
+    (2, 4, 64, 256, 192, (1, 1), "ONE", O.ACT_NONE, 3, 2, 32, (0,)),       # column strips: 8 segments (image, strip, rows) over 3 blocks
+]
+
+
+@pytest.mark.parametrize("shape", INTERLEAVED_SHAPES, ids=lambda s: "%dx%dx%d_%d-%d_cu%d_rows%d" % (s[0], s[1], s[2], s[3], s[4], s[8], s[9]))
+def test_stream_kernel_interleaved_runs(shape):
+    """Round 5: block b of the streaming kernel owns segments b, b + grid, b + 2 grid, ... instead of consecutive ones (the
+    launch writes one compact window that moves through the output).  Same bytes as the oracle for all three output types,
+    uneven runs, smaller last chunks of a batch (which keep the planned stride), strips, the K-split kernel."""
+    b, h, w_, cin, cout, st, pad, act, cus, rows, wso, chunks = shape
+    padding, pad_values = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, act, O.SEM_REFERENCE)
+    H.set_stream(cus, rows)
+    H.set_stream_strip(wso)
+    H.set_stream_interleave(1)
+    try:
+        for mb in chunks:
+            names = _run_all_dst_mfma(spec, seed=cin + 5 * cout + b, max_batch=mb, engine="stream")
+            assert all(n.startswith("bconv2d_stream<") for n in names), names
+            if mb == 0:     # (a chunk so small that every block owns ONE segment has nothing to interleave)
+                assert all(n.endswith(",il>") for n in names), names
+    finally:
+        H.set_stream(256, 0)
+        H.set_stream_strip(-1)
+        H.set_stream_interleave(0)
+
+
 @pytest.mark.parametrize("phases,cout,cus", [(2, 256, 2), (4, 256, 4)])
 def test_stream_kernel_with_forced_pixel_phases(phases, cout, cus):
     """stream_pixel_phases: a block's four waves as 2 slices x 2 pixel blocks (or 1 x 4) also when there are >= 3 channel
