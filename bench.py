@@ -305,6 +305,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=40.0, help="untimed clock spin-up before the warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--extra-json", default=os.path.join(ROOT, "gpurun_out", "bench_extra.json"),
+                    help="where the full `extra` entries go (the JSON line carries a compact map of them); '' = nowhere")
     ap.add_argument("--launch-selftest", action="store_true", help="CPU-only check of the multi-rank launch path (gloo)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="test aid for boxes with ONE GPU: every rank uses cuda:0 and the ranks meet over gloo, so the N > 1 "
@@ -504,10 +506,23 @@ def main():
             result["compute"] = {"bound": "valu", "achieved": spec.binary_macs / k_sec, "peak": VALU_BMAC_PEAK,
                                  "unit": "binary-MAC/s", "frac": spec.binary_macs / k_sec / VALU_BMAC_PEAK,
                                  "model": "v_xor_b32 + v_bcnt_u32_b32 per 32 bMAC, measured pair ceiling"}
+        full_extra = None
         if not args.no_extra and world == 1 and not one_rank_rccl:
-            result["extra"] = extra_measurements(amd, torch, spec, args, dev)
+            full_extra = extra_measurements(amd, torch, spec, args, dev)
+            # The driver keeps the last 8 KB of stdout: the line carries a COMPACT map of every extra measurement (round 4's
+            # 13 KB line lost five layers from the driver's record); the full entries (kernel names, operand rotation, chain
+            # variants) go to a file beside it.
+            result["extra"] = compact_extra(full_extra)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
+        if full_extra is not None and args.extra_json:
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.extra_json)), exist_ok=True)
+                with open(args.extra_json, "w") as f:
+                    json.dump({**{k: v for k, v in result.items() if k != "extra"}, "extra": full_extra}, f, indent=1)
+                result["extra_detail_file"] = os.path.relpath(os.path.abspath(args.extra_json), ROOT)
+            except OSError as exc:
+                result["extra_detail_file"] = "not written: %r" % (exc,)
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
@@ -549,6 +564,25 @@ def measure_traffic(kname, batch):
     return int(fetch + writes), (f"measured in this run: rocprofv3 --pmc FETCH_SIZE ({got['FETCH_SIZE'][1]} launches, raw "
                                  f"{got['FETCH_SIZE'][0]:.0f} B x2 = {fetch:.0f} B) + --pmc WRITE_SIZE ({got['WRITE_SIZE'][1]} "
                                  f"launches, {writes:.0f} B), separate passes over tools/run_one.py, kernel {kname}")
+
+
+def compact_extra(extra):
+    """{name: [us, fraction of the HBM roofline or null]} for single launches; stacks: [us of the convolutions alone, fraction,
+    us of the device-resident chain].  `_format` says so in the line itself."""
+    out = {"_format": "name: [us, hbm_frac] (stacks: [convolutions_only us, hbm_frac, device_resident_chain us]); full entries in extra_detail_file"}
+    r3 = lambda v: None if v is None else round(float(v), 3)
+    for name, e in extra.items():
+        if not isinstance(e, dict):
+            continue
+        if "error" in e:
+            out[name] = "error"
+        elif "convolutions_only_ms" in e:
+            out[name] = [r3(e["convolutions_only_ms"] * 1e3), r3(e.get("hbm_frac")), r3(e.get("device_resident_chain_ms", 0.0) * 1e3)]
+        elif "ms" in e:
+            out[name] = [r3(e["ms"] * 1e3), r3(e.get("hbm_frac"))]
+        elif "ms_per_invoke_device_resident" in e:
+            out[name] = [r3(e["ms_per_invoke_device_resident"] * 1e3), None]
+    return out
 
 
 def extra_measurements(amd, torch, spec, args, dev):

@@ -54,6 +54,11 @@ LCE_DEVICE u32x2 buf_load(rsrc_t r, uint32_t byte_off, u32x2*) {
 LCE_DEVICE u32x4 buf_load(rsrc_t r, uint32_t byte_off, u32x4*) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
 }
+// ... with a wave-uniform byte offset on top of the per-lane one (an SGPR operand of the instruction: no vector add).  Only the
+// per-lane offset is range-checked, as for the stores below.
+LCE_DEVICE u32x4 buf_load_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, u32x4*) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uniform_off, 0);
+}
 
 LCE_DEVICE uint32_t mulhi_u32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 LCE_DEVICE int popc(uint32_t x) { return __popc(x); }

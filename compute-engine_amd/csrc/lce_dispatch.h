@@ -6,3 +6,4 @@
 #include "lce_dispatch_mfma.h"
 #include "lce_dispatch_pointwise.h"
 #include "lce_dispatch_stream.h"
+#include "lce_dispatch_wstream.h"

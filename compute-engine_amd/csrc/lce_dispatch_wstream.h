@@ -1,0 +1,39 @@
+// Instance table of the weight-streaming kernel (lce_kernels_wstream.h) (one translation unit of the product build instantiates it: see
+// lce_kernel_types.h; the host simulation of the CPU tests includes all tables through lce_dispatch.h).
+#pragma once
+#include "../../include/lce_hip.h"
+#include "lce_kernel_types.h"
+#include "lce_kernels_wstream.h"
+
+namespace lce {
+
+// 3x3 filters over 128 / 256 / 512 (padded) input channels; NB = the most pixel blocks a block owns; SIGN = the epilogue also
+// writes the output's LceQuantize
+template <int DST, int KCH, bool SIGN>
+wstream_fn wstream_by_nb(int nb) {
+  switch (nb) {
+    case 1: return bconv2d_wstream<DST, KCH, 1, SIGN>;
+    case 2: return bconv2d_wstream<DST, KCH, 2, SIGN>;
+    case 3: return bconv2d_wstream<DST, KCH, 3, SIGN>;
+    case 4: return bconv2d_wstream<DST, KCH, 4, SIGN>;
+    default: return nullptr;
+  }
+}
+template <int DST, bool SIGN>
+wstream_fn wstream_by_kch(int kch, int nb) {
+  switch (kch) {
+    case 8: return wstream_by_nb<DST, 8, SIGN>(nb);
+    case 4: return wstream_by_nb<DST, 4, SIGN>(nb);
+    case 2: return wstream_by_nb<DST, 2, SIGN>(nb);
+    default: return nullptr;
+  }
+}
+inline wstream_fn find_wstream(int dst, int kch, int nb, bool sign) {
+  switch (dst) {
+    case LCE_HIP_F32: return sign ? wstream_by_kch<kDstFloat, true>(kch, nb) : wstream_by_kch<kDstFloat, false>(kch, nb);
+    case LCE_HIP_I8: return sign ? wstream_by_kch<kDstInt8, true>(kch, nb) : wstream_by_kch<kDstInt8, false>(kch, nb);
+    default: return wstream_by_kch<kDstBitpacked, false>(kch, nb);
+  }
+}
+
+}  // namespace lce

@@ -150,23 +150,23 @@ using lce::mfma_fn;
 
 size_t out_elem_bytes(int dst) { return dst == LCE_HIP_I8 ? 1 : 4; }
 
-// The unscaled FP4 MFMA's known-answer test (lce_mfma_selftest.h), once per device and kernel family (0: pointwise, 1: stream)
+// The unscaled FP4 MFMA's known-answer test (lce_mfma_selftest.h), once per device and kernel family (0: pointwise, 1: stream, 2: wstream)
 lce_hip_status mfma_selftest_once(int dev, int family) {
   static std::mutex mu;
-  static std::vector<int> state[2];       // -1 unknown, 0 passed, > 0 failed
+  static std::vector<int> state[3];       // -1 unknown, 0 passed, > 0 failed
   std::lock_guard<std::mutex> lock(mu);
   std::vector<int>& st = state[family];
   if (dev < 0) return LCE_HIP_OK;
   if ((size_t)dev >= st.size()) st.resize((size_t)dev + 1, -1);
   if (st[dev] < 0) {
-    const int r = family ? lce::mfma_selftest_stream() : lce::mfma_selftest_pointwise();
+    const int r = family == 2 ? lce::mfma_selftest_wstream() : family ? lce::mfma_selftest_stream() : lce::mfma_selftest_pointwise();
     if (r < 0) return fail(LCE_HIP_ERR_RUNTIME, "the FP4 matrix-core self-test could not run: %s", hipGetErrorString((hipError_t)(-r)));
     st[dev] = r;
   }
   if (st[dev] != 0)
     return fail(LCE_HIP_ERR_RUNTIME, "this build's unscaled FP4 MFMA (v_mfma_f32_32x32x64_f8f6f4 with FP4 operands at scale 1) does not "
                 "compute 3 - 64 = -61 for C = 3, A = +1, B = -1 on device %d: the compiler did not select the unscaled encoding "
-                "(lce_device_intrinsics.h, mfma_fp4_32x32x64_unscaled); refusing to run the %s kernels", dev, family ? "streaming" : "pointwise");
+                "(lce_device_intrinsics.h, mfma_fp4_32x32x64_unscaled); refusing to run the %s kernels", dev, family == 2 ? "weight-streaming" : family ? "streaming" : "pointwise");
   return LCE_HIP_OK;
 }
 
@@ -232,7 +232,7 @@ lce_hip_status ensure_uploaded(lce_hip_bconv2d_plan* plan) {
     LCE_HIP_TRY(plan->d_mul.upload(h.mul_q));
     LCE_HIP_TRY(plan->d_bias.upload(h.bias_q));
     LCE_HIP_TRY(plan->d_thrq.upload(h.thr_q));
-    if (h.use_stream) LCE_HIP_TRY(plan->d_sched.upload(h.st_tabs));
+    if (h.use_stream || h.use_wstream) LCE_HIP_TRY(plan->d_sched.upload(h.st_tabs));
     else plan->d_sched.release();
     plan->d_packed.release();
     plan->d_filter.release();
@@ -603,6 +603,7 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     else if (!strcmp(value, "direct")) h.engine_pref = 3;
     else if (!strcmp(value, "pointwise")) h.engine_pref = 4;
     else if (!strcmp(value, "stream")) h.engine_pref = 5;
+    else if (!strcmp(value, "wstream")) h.engine_pref = 6;
     else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|pointwise|stream");
   } else if (!strcmp(key, "phase")) {
     // profiling aid for the matrix-core engine: time its two kernels separately
@@ -708,6 +709,23 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       const dim3 grid(gx, (unsigned)(h.d.channels_out / (32 * h.pw_nj)));
       hipLaunchKernelGGL(fn, grid, dim3(256), (size_t)(4 * h.pw_nj * 4096), st, P, in, plan->d_wq.ptr, plan->d_mul.ptr,
                          plan->d_bias.ptr, plan->d_thrq.ptr, out, sgn);
+      LCE_HIP_TRY(hipGetLastError());
+      sign_fused = true;   // (also when there is none to write)
+    } else if (h.use_mfma && h.use_wstream) {
+      // weight-streaming kernel: a block per (group of images, part of its pixel blocks), two resident per CU
+      if (lce_hip_status s = mfma_selftest_once(plan->device, 2)) return s;
+      const lce::WsArgs G = lce::make_ws_args(h, nb);
+      const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
+      lce::wstream_fn fn = lce::lookup_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, with_sign);
+      if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
+      const size_t lds = (size_t)lce::wstream_lds_bytes(h);
+      if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
+        LCE_HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        plan->lds_opt_in = (void*)fn;
+      }
+      const dim3 grid((unsigned)(G.GROUPS * G.PARTS), (unsigned)h.ws_ny);
+      hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, G, (const uint8_t*)in, plan->d_wq.ptr, plan->d_mul.ptr,
+                         plan->d_bias.ptr, plan->d_thrq.ptr, plan->d_sched.ptr, out, with_sign ? sgn : nullptr);
       LCE_HIP_TRY(hipGetLastError());
       sign_fused = true;   // (also when there is none to write)
     } else if (h.use_mfma && h.use_stream) {

@@ -186,4 +186,39 @@ struct StreamArgs {
   FastDivNB div_ipr, div_qg, div_srs, div_spi, div_r, div_rseg, div_gstr;
 };
 
+
+// Launch constants of the weight-STREAMING kernel (lce_kernels_wstream.h, round 5): the mirror image of the kernel above for
+// launches that are over after a handful of block steps (14x14 / 7x7 images at one image per CU), where loading a resident
+// filter bank (295 KB per CU, ~5 k cycles of the CU's vector memory path) in FRONT of the matrix work costs a third of the
+// block's life.  Here the ACTIVATIONS are stationary -- a block expands the whole images of its GROUP (IPB consecutive images)
+// into LDS once -- and the weights stream from L2 straight into registers, two fragments per K-step and wave, a few K-steps
+// ahead of their use, while the matrix cores run.  The group's output pixels (NHWC: contiguous) are cut into NQ 32-pixel blocks
+// laid end to end; a block owns up to NB of them (a PART of the group; the parts of a group differ by at most one pixel block),
+// wave w the 64-channel slice w of the block's 256 channels.  Blocks are numbered part-major (block = part * GROUPS + group), so
+// that the two blocks a CU holds at a time are a long and a short part.
+struct WsArgs {
+  int32_t H, W, Cw, Cin;       // source (bitpacked) tensor
+  int32_t OH, OW, N, Npad, Wout;
+  int32_t SH, SW, PH, PW;
+  int32_t B;                   // images of this launch
+  int32_t IPB;                 // images per group
+  int32_t GROUPS;              // ceil(B / IPB)
+  int32_t PARTS;               // blocks per group; grid.x = PARTS * GROUPS
+  int32_t NPXG;                // output pixels per group = IPB * OH * OW
+  int32_t NQ;                  // pixel blocks per group = ceil(NPXG / 32)
+  int32_t Hp, Wp;              // rows / pixels per row of one image in LDS (padding included)
+  int32_t pitch, img_pitch;    // LDS bytes per row (Wp pixels + the bank skew) / per image
+  int32_t QG;                  // 16-byte items per input pixel = ceil(padded words / 4)
+  int32_t items;               // IPB * Hp * Wp * QG: the expansion's work list
+  int32_t zero_border;         // 1: padding is 0 (exact SAME-zero), 0: +1 (one-padding)
+  int32_t noclamp;             // float output: the clamp is the identity on [0, 2 * K_bt]
+  uint32_t lds_images;         // bytes of the group's images in LDS (1 KiB multiple); 4 x 8 KiB of epilogue scratch follow
+  uint32_t in_bytes, w_bytes, out_bytes, sign_bytes, tab_bytes;
+  // the planner's tables (one buffer): part: two dwords per part {first pixel block, pixel blocks}; ctx: 16 bytes per (pixel block
+  // of the group, lane) = {LDS byte address of the lane's pixel in tap rows 0..2 (K-half included), 0}
+  uint32_t tab_part, tab_ctx;
+  float a_bt, cmin, cmax, bit_thr;
+  FastDivNB div_qg, div_wp, div_hp, div_groups;
+};
+
 }  // namespace lce

@@ -20,6 +20,9 @@ typedef void (*pointwise_fn)(const PwArgs, const uint32_t*, const uint8_t*, cons
 typedef void (*stream_fn)(const StreamArgs, const uint8_t*, const uint8_t*, const float*, const float*, const float*,
                           const uint32_t*, void*, uint32_t*);
 
+typedef void (*wstream_fn)(const WsArgs, const uint8_t*, const uint8_t*, const float*, const float*, const float*,
+                           const uint32_t*, void*, uint32_t*);
+
 // lce_tu_valu.hip
 tiled_fn lookup_tiled(int dst, int tm, int tn, int ch);
 general_fn lookup_general(int dst);
@@ -37,6 +40,9 @@ int launch_expand_fp4(unsigned grid_x, void* stream, const uint32_t* in, void* w
 pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided);
 // lce_tu_stream.hip
 stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips);
+// lce_tu_wstream.hip
+wstream_fn lookup_wstream(int dst, int kch, int nb, bool sign);
+int mfma_selftest_wstream();
 // known-answer test of the unscaled FP4 MFMA as each of those two translation units compiled it (lce_mfma_selftest.h):
 // 0 = as assumed, 1 = wrong products, < 0 = -(hipError_t)
 int mfma_selftest_pointwise();

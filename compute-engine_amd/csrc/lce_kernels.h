@@ -28,6 +28,11 @@ using namespace lce_dev;
 LCE_DEVICE uint32_t fastdiv(uint32_t n, FastDiv d) {
   return d.magic == 0u ? n : (mulhi_u32(n, d.magic) >> d.shift);
 }
+// fastdiv without the divisor-1 branch: a divisor of 1 has magic 0, so the multiply-high contributes 0 and the
+// masked addend is n itself.
+LCE_DEVICE uint32_t fastdiv_nb(uint32_t n, FastDivNB d) {
+  return (mulhi_u32(n, d.magic) >> d.shift) + (n & d.pass);
+}
 
 // ---------------------------------------------------------------------------------
 // Output transform pieces (core/bconv2d/output_transform.h).

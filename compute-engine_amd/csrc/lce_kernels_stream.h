@@ -51,12 +51,6 @@ __device__ unsigned long long lce_stream_tl[512 * 64];
 #define LCE_SPH(slot) do {} while (0)
 #endif
 
-// fastdiv without the divisor-1 branch: a divisor of 1 has magic 0, so the multiply-high contributes 0 and the
-// masked addend is n itself.
-LCE_DEVICE uint32_t fastdiv_nb(uint32_t n, FastDivNB d) {
-  return (mulhi_u32(n, d.magic) >> d.shift) + (n & d.pass);
-}
-
 // Dword DD of fp4_of_full_word (lce_kernels_mfma.h): byte DD of the word as eight FP4 codes, 4 VALU.
 template <int DD>
 LCE_DEVICE uint32_t fp4_full_dword(uint32_t word) {

@@ -635,6 +635,134 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   return G;
 }
 
+// ------------------------------------------------------------------------------------
+// weight-streaming kernel (lce_kernels_wstream.h)
+// ------------------------------------------------------------------------------------
+bool wstream_supported(const HostPlan& p) {
+  if (!stream_supported(p)) return false;                     // 3x3, no dilation, no groups, whole 16-byte channel groups, not the correction semantics
+  const int kch = ceil_div(p.d.channels_in, 64);
+  return kch == 2 || kch == 4 || kch == 8;                    // the instantiated K depths (128 / 256 / 512 input channels)
+}
+
+// Cycle model of one launch, used to pick the group size and (select_kernel) to rank this kernel against the weight-stationary
+// one.  Calibrated on profiles/r05/wstream_phases.txt: an MFMA of a K loop costs ~34 cycles of its SIMD whichever of the two
+// resident blocks issues it; a block's prologue (expansion of its group's images: a global round trip + ~70 VALU per item) and
+// epilogue (~450 cycles per pixel block) are hidden by the co-resident block except for the first prologue and the last epilogue.
+static int64_t wstream_cost(int64_t blocks, int cus, int occupancy, const std::vector<int>& nb_of_block, int ks, int items_per_lane) {
+  // blocks are dispatched in index order, round-robin over the CUs
+  std::vector<int64_t> load(cus, 0);
+  int64_t worst = 0, last_nb = 0;
+  for (int64_t b = 0; b < blocks; ++b) {
+    load[b % cus] += nb_of_block[b];
+    worst = std::max(worst, load[b % cus]);
+  }
+  for (int64_t b = std::max<int64_t>(0, blocks - cus); b < blocks; ++b) last_nb = std::max<int64_t>(last_nb, nb_of_block[b]);
+  const int64_t rounds = (blocks + (int64_t)cus * occupancy - 1) / ((int64_t)cus * occupancy);
+  const int64_t prologue = 2200 + 300 * items_per_lane, epilogue = 450 * last_nb;
+  return worst * ks * 2 * 34 + rounds * prologue + epilogue + (occupancy < 2 ? (blocks + cus - 1) / cus * (prologue + epilogue) : 0);
+}
+
+std::string plan_wstream(HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  if (!wstream_supported(p))
+    return "bconv2d: the weight-streaming kernel runs ungrouped 3x3 convolutions without dilation over 128, 256 or 512 input channels "
+           "(after padding to 64) and whole 16-byte groups of output channels (float: a multiple of 4, int8: of 16), and not the "
+           "SAME-zero correction semantics";
+  if ((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p) >= (1ll << 31))
+    return "bconv2d: the weight-streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
+  const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16, ks = 9 * kch;
+  const int hp = (p.out_h - 1) * d.stride_height + d.filter_height, wp = (p.out_w - 1) * d.stride_width + d.filter_width;
+  // row pitch: a skew of < 256 bytes so that a 32-pixel block that wraps to the next output row keeps hitting distinct LDS banks
+  // (the streaming kernel's rule, plan_stream_geometry)
+  int skew16 = 0;
+  if (d.stride_height % 2 == 1) {
+    const int want = (int)(((int64_t)p.out_w * d.stride_width * (ps / 16)) % 16);
+    for (int k = 0; k < 16; ++k)
+      if (((int64_t)d.stride_height * ((int64_t)wp * (ps / 16) + k)) % 16 == want) { skew16 = k; break; }
+  }
+  const int pitch = wp * ps + skew16 * 16, img_pitch = hp * pitch;
+  const int qg = ceil_div(kch * 2, 4), ohw = p.out_h * p.out_w;
+  const int ny = ceil_div(ceil_div(d.channels_out, 64), 4), cus = std::max(1, p.num_cus);
+  int best_ipb = 0;
+  int64_t best_cost = 0;
+  for (int ipb = 1; ipb <= std::min(batch_chunk, 64); ++ipb) {
+    const int64_t lds_images = ((int64_t)ipb * img_pitch + 1023) / 1024 * 1024;
+    if (lds_images + kWsLdsExtra > 160 * 1024) break;
+    const int occupancy = (int)std::min<int64_t>(2, (160 * 1024) / (lds_images + kWsLdsExtra));
+    const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, 4), groups = ceil_div(batch_chunk, ipb);
+    std::vector<int> nb_of_block;
+    for (int y = 0; y < ny; ++y)
+      for (int part = 0; part < parts; ++part)
+        for (int g = 0; g < groups; ++g) nb_of_block.push_back(nq / parts + (part < nq % parts ? 1 : 0));
+    const int items_per_lane = ceil_div(ipb * hp * wp * qg, 256);
+    const int64_t cost = wstream_cost((int64_t)nb_of_block.size(), cus, occupancy, nb_of_block, ks, items_per_lane);
+    if (best_ipb == 0 || cost < best_cost) { best_ipb = ipb; best_cost = cost; }
+  }
+  if (best_ipb == 0) return "bconv2d: one image of this layer does not fit the weight-streaming kernel's LDS (whole images are resident)";
+  const int ipb = best_ipb;
+  const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, 4);
+  p.ws_ipb = ipb; p.ws_parts = parts; p.ws_nq = nq; p.ws_npxg = ipb * ohw; p.ws_nb = ceil_div(nq, parts); p.ws_ny = ny;
+  p.ws_hp = hp; p.ws_wp = wp; p.ws_pitch = pitch; p.ws_img_pitch = img_pitch; p.ws_qg = qg;
+  p.ws_lds_images = (int)(((int64_t)ipb * img_pitch + 1023) / 1024 * 1024);
+  p.ws_occupancy = (int)std::min<int64_t>(2, (160 * 1024) / (p.ws_lds_images + kWsLdsExtra));
+  p.ws_cost = best_cost;
+  p.st_batch = batch_chunk;
+  // ---- the tables: [part | ctx] ----
+  const size_t n_part = ((size_t)parts * 2 + 3) / 4 * 4;
+  p.ws_tab_part = 0;
+  p.ws_tab_ctx = (uint32_t)(n_part * 4);
+  p.st_tabs.assign(n_part + (size_t)nq * 256, 0u);
+  int q0 = 0;
+  for (int part = 0; part < parts; ++part) {
+    const int nb = nq / parts + (part < nq % parts ? 1 : 0);
+    p.st_tabs[2 * part] = (uint32_t)q0;
+    p.st_tabs[2 * part + 1] = (uint32_t)nb;
+    q0 += nb;
+  }
+  for (int q = 0; q < nq; ++q)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int l31 = lane & 31, half = lane >> 5;
+      const int pix = std::min(q * 32 + l31, ipb * ohw - 1);      // rows past the group re-read its last pixel (never stored)
+      const int img = pix / ohw, oy = (pix % ohw) / p.out_w, ox = pix % p.out_w;
+      uint32_t* e = &p.st_tabs[n_part + ((size_t)q * 64 + lane) * 4];
+      for (int fy = 0; fy < 3; ++fy)
+        e[fy] = (uint32_t)((int64_t)img * img_pitch + (int64_t)(oy * d.stride_height + fy) * pitch + (int64_t)ox * d.stride_width * ps + half * 16);
+    }
+  return "";
+}
+
+WsArgs make_ws_args(const HostPlan& p, int batch_chunk) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  WsArgs G{};
+  G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
+  G.OH = p.out_h; G.OW = p.out_w; G.N = d.channels_out; G.Npad = p.npad; G.Wout = p.wout;
+  G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h; G.PW = p.pad_w;
+  G.B = batch_chunk;
+  G.IPB = p.ws_ipb; G.GROUPS = ceil_div(batch_chunk, p.ws_ipb); G.PARTS = p.ws_parts;
+  G.NPXG = p.ws_npxg; G.NQ = p.ws_nq;
+  G.Hp = p.ws_hp; G.Wp = p.ws_wp; G.pitch = p.ws_pitch; G.img_pitch = p.ws_img_pitch;
+  G.QG = p.ws_qg; G.items = p.ws_ipb * p.ws_hp * p.ws_wp * p.ws_qg;
+  G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
+  G.noclamp = (p.clamp_min <= 0 && p.clamp_max >= 2 * p.backtransform_add) ? 1 : 0;
+  G.lds_images = (uint32_t)p.ws_lds_images;
+  G.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
+  G.w_bytes = (uint32_t)p.wq.size();
+  G.out_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p));
+  G.sign_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * p.wout * 4);
+  G.tab_bytes = (uint32_t)(p.st_tabs.size() * 4);
+  G.tab_part = p.ws_tab_part;
+  G.tab_ctx = p.ws_tab_ctx;
+  G.a_bt = (float)p.backtransform_add;
+  G.cmin = (float)p.clamp_min;
+  G.cmax = (float)p.clamp_max;
+  G.bit_thr = p.bit_thr;
+  G.div_qg = make_fastdiv_nb((uint32_t)G.QG);
+  G.div_wp = make_fastdiv_nb((uint32_t)G.Wp);
+  G.div_hp = make_fastdiv_nb((uint32_t)G.Hp);
+  G.div_groups = make_fastdiv_nb((uint32_t)G.GROUPS);
+  return G;
+}
+
 static const MfmaCfg kMfmaCfgs[] = {
     {4, 2, 2, 4},  // 256 x 256, 8 waves
     {4, 2, 2, 2},  // 256 x 128, 8 waves
@@ -951,6 +1079,26 @@ static bool stream_worthwhile(const HostPlan& p) {
   return p.st_gx * 4 >= cus * 3 && steps >= min_steps && (p.st_rs >= 4 || p.st_rs == p.out_h);
 }
 
+// plan_wstream succeeded: the plan runs the weight-streaming kernel
+static void use_wstream_plan(HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
+  const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
+  p.mfma = want;
+  p.use_mfma = true;
+  p.use_wstream = true;
+  p.use_stream = false;
+  p.use_tiled = false;
+  p.cpad = ceil_div(d.channels_in, 64) * 64;
+  p.npad = ceil_div(d.channels_out, 64) * 64;
+  p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height, (int64_t)(p.out_h - 1) * d.stride_height + d.filter_height);
+  if (repack && p.have_weights) pack_for_mfma(p);
+  char nm[96];
+  snprintf(nm, sizeof nm, "bconv2d_wstream<%s,3x3x%d,images%d,blocks%d>",
+           d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.ws_ipb, p.ws_nb);
+  p.kernel_name = nm;
+}
+
 std::string select_kernel(HostPlan& p, int64_t pixels) {
   const lce_hip_bconv2d_desc& d = p.d;
   const bool bp = d.dst_type == LCE_HIP_BITPACKED;
@@ -964,6 +1112,16 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     return "bconv2d: the pointwise kernel runs 1x1 ungrouped convolutions with 64, 128, 256 or 512 input channels (after padding to 64) and a multiple of 32 output channels (pointwise_channels must divide them)";
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
+  p.use_stream = false;
+  p.use_wstream = false;
+  if (p.engine_pref == 6) {
+    // weight-streaming kernel (activations stationary in LDS): the planner's FP4 weight image with 64-channel granularity
+    const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
+    const std::string err = plan_wstream(p, batch_chunk);
+    if (!err.empty()) return err;
+    use_wstream_plan(p);
+    return "";
+  }
   p.use_stream = false;
   if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_candidate(p, p.want_sign))) {
     // weight-stationary streaming kernel: the planner's FP4 weight image with 64-channel granularity

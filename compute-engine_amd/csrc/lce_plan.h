@@ -69,7 +69,8 @@ struct HostPlan {
   // matrix-core engine (lce_kernels_mfma.h)
   int engine_pref = 0;                     // 0 auto, 1 valu (xor-popcount), 2 mfma (FP4 workspace GEMM), 3 direct (LDS halo),
                                            // 4 pointwise (1x1 streaming kernel, lce_kernels_pointwise.h),
-                                           // 5 stream (weight-stationary persistent kernel, lce_kernels_stream.h)
+                                           // 5 stream (weight-stationary persistent kernel, lce_kernels_stream.h),
+                                           // 6 wstream (weight-streaming kernel for short launches, lce_kernels_wstream.h)
   bool use_direct = false;                 // with use_mfma: the LDS-halo variant, no workspace
   int tpi = 0, halo_rows = 0, ps = 0, halo_bytes = 0, ipt = 1;  // direct-variant geometry
   int tile_tx = 0, halo_w = 0;             // ... 2-D tiles: tiles across the image (0 = strip tiles), halo width in pixels
@@ -105,6 +106,14 @@ struct HostPlan {
   int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images
   std::vector<uint32_t> st_tabs;           // [sched | lim | ctx]: the kernel's tables (lce_kernel_args.h, StreamArgs)
   uint32_t st_tab_lim = 0, st_tab_ctx = 0, st_tab_sgn = 0, st_tab_seg = 0;   // byte offsets of lim / ctx / sgn inside st_tabs
+
+  // weight-streaming kernel (lce_kernels_wstream.h); with use_mfma.  Its tables live in st_tabs as the streaming kernel's do.
+  bool use_wstream = false;
+  int ws_ipb = 0, ws_parts = 0, ws_nq = 0, ws_npxg = 0, ws_nb = 0, ws_ny = 1;   // images per group, blocks per group, pixel blocks / pixels per group, most pixel blocks per block, grid.y
+  int ws_hp = 0, ws_wp = 0, ws_pitch = 0, ws_img_pitch = 0, ws_qg = 0, ws_lds_images = 0;   // LDS image geometry
+  int ws_occupancy = 1;                      // blocks that fit a CU's LDS side by side (the kernel is built for two)
+  uint32_t ws_tab_part = 0, ws_tab_ctx = 0;  // byte offsets inside st_tabs
+  int64_t ws_cost = 0;                       // the planner's cycle estimate of a launch (plan_wstream)
 
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
@@ -157,6 +166,13 @@ ConvArgs make_conv_args(const HostPlan& p, int batch_chunk);
 bool stream_supported(const HostPlan& p);
 std::string plan_stream(HostPlan& p, int batch_chunk);
 StreamArgs make_stream_args(const HostPlan& p, int batch_chunk);
+// Weight-streaming kernel: can it run this convolution; groups / parts / LDS images for launches of `batch_chunk` images (fills
+// the ws_* fields and st_tabs; "" or why not); its launch constants.
+bool wstream_supported(const HostPlan& p);
+std::string plan_wstream(HostPlan& p, int batch_chunk);
+WsArgs make_ws_args(const HostPlan& p, int batch_chunk);
+constexpr int kWsLdsExtra = 4 * 8192;      // four waves' epilogue scratch (lce_kernels_wstream.h, kWsScratch)
+inline int wstream_lds_bytes(const HostPlan& p) { return p.ws_lds_images + kWsLdsExtra; }
 constexpr int kStreamLdsExtra = 4 * 8192 + 4096;   // four waves' epilogue scratch + the dump area of idle producer lanes
 // K-split (512 input channels): 4-KiB scratch per wave (it transposes 32 channels, not 64), the dump area, and two 4-KiB inbox
 // slots per wave for the pair's partial sums

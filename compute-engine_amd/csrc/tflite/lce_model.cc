@@ -64,8 +64,8 @@ bool IsLceOp(const lce_tfl::Operator& o) {
 }  // namespace
 
 // The partition a delegate would get (tensorflow/lite/graph_info.cc, PartitionGraphIntoIndependentNodeSubsets, restated from
-// its published description): alternate between epochs of LCE operators and epochs of the others, starting with an LCE
-// epoch; in an epoch every operator of the epoch's kind whose inputs are all ready joins, repeatedly, until nothing more
+// its published description): alternate between epochs of LCE operators and epochs of the others, starting with the kind of
+// the first ready operator; in an epoch every operator of the epoch's kind whose inputs are all ready joins, repeatedly, until nothing more
 // can; the LCE operators of one epoch, sorted by index, are one section.  (On a chain this is "walk the file, cut at
 // every builtin operator"; on a branched graph an LCE op further down the file joins an EARLIER section when nothing it
 // reads depends on a builtin operator in between.)  Linear in operators + tensor uses: per-tensor reader lists and a count
@@ -96,7 +96,11 @@ void lce_tflite_model::Partition() {
   std::vector<int32_t> section_of(n_ops, -1);
   std::vector<char> made(n_t, 0), listed(n_t, 0);
   int remaining = n_ops;
+  // the first epoch has the kind of the first ready operator in execution order (graph_info.cc takes it from there: usually a
+  // builtin stem operator), so an LCE operator that is ready at the start beside a builtin one lands in the same section a
+  // delegate would be handed
   int kind = 1;                                              // 1: LCE epoch
+  if (!queue[0].empty() && (queue[1].empty() || queue[0].front() < queue[1].front())) kind = 0;
   int idle_epochs = 0;
   while (remaining > 0 && idle_epochs < 2) {                 // (a graph with a cycle or a dangling input never finishes)
     std::vector<int32_t>& q = queue[kind];
@@ -394,7 +398,8 @@ std::vector<int32_t> QuantizeConsumers(const lce_tflite_model* model, const lce_
 // does it) and, with `run`, the launches.  `ptr` maps tensor -> device pointer (section inputs and outputs on entry;
 // intermediates are added from the model's scratch buffers).
 lce_hip_status WalkSection(lce_tflite_model* model, const lce_tflite_section& sec, int32_t batch, int32_t semantics,
-                           std::map<int32_t, Shape>* shapes, std::map<int32_t, void*>* ptr, bool run, void* stream) {
+                           std::map<int32_t, Shape>* shapes, std::map<int32_t, void*>* ptr, bool run, void* stream,
+                           bool capturing = false) {
   const lce_tfl::Model& M = model->m;
   for (int32_t t : sec.inputs) {
     const lce_tfl::Tensor& T = M.tensors[t];
@@ -410,6 +415,9 @@ lce_hip_status WalkSection(lce_tflite_model* model, const lce_tflite_section& se
     if (it != ptr->end()) { *out = it->second; return LCE_HIP_OK; }
     lce_tflite_model::DevBuf& b = model->scratch[t];
     if (b.bytes < bytes) {
+      // while `stream` records a graph nothing may be freed or allocated (a hipFree / hipMalloc inside a capture invalidates it and
+      // the pointer would leak): the eager run before the recording sized every buffer, so this only fires if a size changed
+      if (capturing) return Fail(LCE_HIP_ERR_INVALID, "run_section: a scratch buffer would have to grow during graph capture");
       // (a buffer a previous run's kernels may still use: the free below is ordered behind them by the runtime)
       if (b.ptr) lce_hip_free(b.ptr);
       model->DropGraphs();          // (recorded launches may hold the old pointer; the free above has drained the device)
@@ -468,6 +476,7 @@ lce_hip_status WalkSection(lce_tflite_model* model, const lce_tflite_section& se
                                               OT.quantized ? OT.scale : 1.0f, OT.quantized ? (int32_t)OT.zero_point : 0, o, stream)) return s;
       }
     } else if (op.custom_code == "LceBMaxPool2d") {             // bmaxpool.cc:20-91
+      if (in.type != lce_tfl::kTensorInt32) return Fail(LCE_HIP_ERR_INVALID, "LceBMaxPool2d: input must be bitpacked int32");
       const lce_flex::Map fm(op.custom_options, op.custom_options_size);
       if (!fm.valid()) return Fail(LCE_HIP_ERR_INVALID, "LceBMaxPool2d: unreadable options");
       const int32_t fh = fm.AsInt32("filter_height"), fw = fm.AsInt32("filter_width"), sh = fm.AsInt32("stride_height"),
@@ -480,6 +489,17 @@ lce_hip_status WalkSection(lce_tflite_model* model, const lce_tflite_section& se
         if (lce_hip_status s = lce_hip_bmaxpool((const int32_t*)in_dev, in.dims[0], in.dims[1], in.dims[2], in.dims[3], fh, fw, sh, sw, pad, (int32_t*)o, stream)) return s;
       }
     } else if (op.custom_code == "LceBconv2d") {                // bconv2d.cc:137-300,550-564
+      // The plan is built from the FILE's static shape of the input tensor (lce_tflite_model_bconv2d_plan); the buffer it will
+      // read was sized from THIS walk's shape inference.  A model whose declared shapes disagree with what its operators
+      // produce (dynamic / -1 dimensions, a hand-edited file, an int8 tensor wired into a convolution) must fail here, not read
+      // past a scratch buffer on the device: the file is untrusted input.
+      {
+        const lce_tfl::Tensor& IT = M.tensors[op.inputs[0]];
+        if (in.type != lce_tfl::kTensorInt32)
+          return Fail(LCE_HIP_ERR_INVALID, "LceBconv2d: the tensor feeding the convolution is not bitpacked int32");
+        if (IT.shape.size() != 4 || IT.shape[1] != in.dims[1] || IT.shape[2] != in.dims[2] || IT.shape[3] != in.dims[3])
+          return Fail(LCE_HIP_ERR_INVALID, "LceBconv2d: the input tensor's declared shape does not match the shape its producer infers");
+      }
       lce_hip_bconv2d_plan* plan = nullptr;
       if (lce_hip_status s = PlanFor(model, i, batch, semantics, &plan)) return s;
       if (lce_hip_status s = lce_hip_bconv2d_plan_output_shape(plan, out.dims)) return s;
@@ -569,7 +589,7 @@ lce_hip_status lce_tflite_model_run_section(lce_tflite_model* model, int32_t sec
       if (lce_hip_graph_begin_capture(stream) == LCE_HIP_OK) {
         std::map<int32_t, Shape> shapes_c;
         std::map<int32_t, void*> ptr_c = ptr;
-        const lce_hip_status walked = WalkSection(model, sec, batch, semantics, &shapes_c, &ptr_c, true, stream);
+        const lce_hip_status walked = WalkSection(model, sec, batch, semantics, &shapes_c, &ptr_c, true, stream, /*capturing=*/true);
         const lce_hip_status ended = lce_hip_graph_end_capture(stream, &g);
         recorded = walked == LCE_HIP_OK && ended == LCE_HIP_OK && g != nullptr;
         fused = model->last_run_fused;

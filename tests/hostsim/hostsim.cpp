@@ -149,7 +149,19 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     const ConvArgs A = make_conv_args(h, nb);
     const uint32_t* in = (const uint32_t*)input + (size_t)b0 * in_img_words;
     void* out = (char*)output + (size_t)b0 * out_img_bytes;
-    if (h.use_mfma && h.use_stream) {
+    if (h.use_mfma && h.use_wstream) {
+      const WsArgs G = make_ws_args(h, nb);
+      uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
+      wstream_fn fn = find_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, sgn != nullptr);
+      if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
+      std::vector<uint8_t> wq = h.wq;
+      wq.resize(wq.size() + 64, 0);
+      std::vector<uint32_t> tabs = h.st_tabs;
+      tabs.resize(tabs.size() + 16, 0u);
+      launch_block_lockstep(G.GROUPS * G.PARTS, h.ws_ny, 256, (size_t)wstream_lds_bytes(h), [&] {
+        fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), tabs.data(), out, sgn);
+      });
+    } else if (h.use_mfma && h.use_stream) {
       const StreamArgs G = make_stream_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
       stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1);

@@ -72,6 +72,13 @@ inline V buf_load_impl(rsrc_t r, uint32_t off) {
 inline uint32_t buf_load(rsrc_t r, uint32_t off, uint32_t*) { return buf_load_impl<uint32_t>(r, off); }
 inline u32x2 buf_load(rsrc_t r, uint32_t off, u32x2*) { return buf_load_impl<u32x2>(r, off); }
 inline u32x4 buf_load(rsrc_t r, uint32_t off, u32x4*) { return buf_load_impl<u32x4>(r, off); }
+// the scalar offset moves the address but is outside the range check (as on the hardware)
+inline u32x4 buf_load_so(rsrc_t r, uint32_t lane_off, uint32_t uniform_off, u32x4*) {
+  u32x4 v;
+  memset(&v, 0, sizeof v);
+  if ((uint64_t)lane_off + 16 <= (uint64_t)r.bytes) memcpy(&v, r.base + lane_off + uniform_off, 16);
+  return v;
+}
 
 inline uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline int popc(uint32_t x) { return __builtin_popcount(x); }

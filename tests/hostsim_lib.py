@@ -76,7 +76,7 @@ def bconv2d(spec: O.ConvSpec, dst_type: int, inp, filt, post_mul=None, post_bias
     lib().hostsim_set_sign_output(_p(sign_words))
     rc = lib().hostsim_bconv2d(C.byref(d), _p(filt), _p(mul), _p(bias), _p(thr), _p(inp), _p(out),
                                {"auto": 0, "tiled": 1, "general": 2}[kernel], tile[0], tile[1],
-                               max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3, "pointwise": 4, "stream": 5}[engine])
+                               max_batch, name, 128, {"auto": 0, "valu": 1, "mfma": 2, "direct": 3, "pointwise": 4, "stream": 5, "wstream": 6}[engine])
     lib().hostsim_set_sign_output(None)
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())

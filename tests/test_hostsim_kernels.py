@@ -698,6 +698,68 @@ def test_stream_kernel_column_strips(shape):
         H.set_stream_strip(-1)
 
 
+WSTREAM_SHAPES = [
+    # batch, h, w, cin, cout, stride, pad, act, compute units, batch chunks to try
+    (3, 14, 14, 256, 256, (1, 1), "ONE", O.ACT_NONE, 4, (0, 2)),      # QuickNet's 14x14x256: one image per group, parts of 4 + 3 pixel blocks, a partial last block
+    (5, 7, 7, 512, 512, (1, 1), "ONE", O.ACT_RELU, 4, (0, 3)),        # 7x7x512: several images per group, flat pixel blocks, two blocks in y, a short last group
+    (2, 9, 11, 200, 304, (1, 1), "SAME", O.ACT_NONE, 2, (0,)),        # exact SAME-zero, partial word planes (200 channels), 304 channels: a short last slice group
+    (3, 11, 9, 128, 192, (2, 2), "ONE", O.ACT_RELU6, 2, (0, 1)),      # strides, 128 input channels, three of four waves active
+    (2, 10, 12, 256, 192, (1, 2), "VALID", O.ACT_NONE, 3, (0,)),      # VALID padding, column stride 2
+    (1, 4, 4, 512, 256, (1, 1), "ONE", O.ACT_NONE, 8, (0,)),          # a single half-empty pixel block
+]
+
+
+@pytest.mark.parametrize("shape", WSTREAM_SHAPES, ids=lambda s: "%dx%dx%d_%d-%d_cu%d" % (s[0], s[1], s[2], s[3], s[4], s[8]))
+def test_wstream_kernel(shape):
+    """The weight-streaming kernel (lce_kernels_wstream.h, round 5: activations stationary in LDS, weights streamed into registers
+    during the K loop) with the planner's tables, against the oracle: all three output types, groups of several images cut into
+    flat 32-pixel blocks, parts of unequal length, partial last blocks and short last groups, strides, both padding semantics."""
+    b, h, w_, cin, cout, st, pad, act, cus, chunks = shape
+    padding, pad_values = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, act, O.SEM_REFERENCE)
+    H.set_stream(cus, 0)
+    try:
+        for mb in chunks:
+            names = _run_all_dst_mfma(spec, seed=cin + 3 * cout + b, max_batch=mb, engine="wstream")
+            assert all(n.startswith("bconv2d_wstream<") for n in names), names
+    finally:
+        H.set_stream(256, 0)
+
+
+@pytest.mark.parametrize("cin,cout,hw,zp", [(256, 256, 14, 3), (512, 320, 7, -5)])
+def test_wstream_second_output_is_the_lcequantize_of_the_output(cin, cout, hw, zp):
+    """run_dual on the weight-streaming kernel: the sign words are the LceQuantize of the float / int8 values it stores."""
+    spec = O.ConvSpec(3, hw, hw, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=O.ACT_NONE)
+    x, w, mul, bias = synth.conv_inputs(spec, 9 + cin, negative_mul_fraction=0.3)
+    bias = (bias - np.median(O.bconv2d(spec, O.DST_F32, x, w, mul, bias), axis=(0, 1, 2))).astype(np.float32)
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    H.set_stream(4, 0)
+    try:
+        got, name = H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="wstream", sign_words=words)
+        want = O.bconv2d(spec, O.DST_F32, x, w, mul, bias)
+        assert name.startswith("bconv2d_wstream<f32"), name
+        assert np.array_equal(got.view(np.int32), want.view(np.int32)), name
+        assert np.array_equal(words, O.bitpack(want)), name
+        words[:] = 0x5A5A5A5A
+        got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=8.0, out_zero_point=zp, engine="wstream", sign_words=words)
+        want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=8.0, out_zero_point=zp)
+        assert np.array_equal(got, want), name
+        assert np.array_equal(words, O.bitpack(want, zp)), name
+    finally:
+        H.set_stream(256, 0)
+
+
+def test_wstream_kernel_refuses_what_it_cannot_run():
+    for spec, why in [
+        (O.ConvSpec(1, 6, 6, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "128, 256 or 512 input channels"),
+        (O.ConvSpec(1, 6, 6, 256, 1, 1, 64), "3x3"),
+        (O.ConvSpec(1, 120, 120, 256, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "does not fit"),     # one image: 122 x 122 x 144 B
+    ]:
+        x, w, mul, bias = synth.conv_inputs(spec, 2)
+        with pytest.raises(RuntimeError, match=why):
+            H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="wstream")
+
+
 def test_stream_kernel_refuses_what_it_cannot_run():
     x, w, mul, bias = synth.conv_inputs(O.ConvSpec(1, 6, 6, 64, 3, 3, 64), 1)
     for spec, why in [

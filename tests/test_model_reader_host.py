@@ -325,6 +325,55 @@ def test_section_shapes_at_any_batch_without_a_device_and_run_fails_loudly_witho
             m.run_section(0, 1, [8], [8, 8])
 
 
+def test_a_convolution_whose_declared_input_shape_disagrees_with_its_producer_is_refused():
+    """Round 4's advisor: the plan of an LceBconv2d is built from the FILE's shape of its input tensor while the buffer it reads is
+    sized from the walk's own shape inference; a file in which the two disagree (hand-edited, dynamic dimensions, an int8 tensor
+    wired into a convolution) must be refused by the walk -- not run a convolution past the end of a scratch buffer."""
+    spec = O.ConvSpec(1, 8, 8, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1)
+    _, w, mul, bias = synth.conv_inputs(spec, 3)
+
+    def build(q_shape, q_dtype=np.int32, pool=False):
+        b = ModelBuilder()
+        x = b.tensor([1, 8, 8, 64], np.float32, "x")
+        q = b.tensor(q_shape, q_dtype, "q")
+        y = b.tensor([1, 8, 8, 64], np.float32, "y")
+        tw, tm, tb = b.tensor(w.shape, np.int32, "w", w), b.tensor([64], np.float32, "m", mul), b.tensor([64], np.float32, "b", bias)
+        b.inputs, b.outputs = [x], [y]
+        b.custom_op("LceQuantize", [x], [q], b"")
+        b.custom_op("LceBconv2d", [q, tw, tm, tb, -1], [y], bconv_options(spec))
+        return b.finish(), y
+
+    good, y = build([1, 8, 8, 2])
+    assert mr.LceModel(good).section_tensor_shape(0, y, 5)[0] == (5, 8, 8, 64)
+    # the quantize produces 8x8x2 words from the 8x8x64 input; the file says the convolution reads 16x16x2
+    bad, y = build([1, 16, 16, 2])
+    with pytest.raises(amd.LceHipError, match="declared shape does not match"):
+        mr.LceModel(bad).section_tensor_shape(0, y, 5)
+
+
+def test_partition_starts_with_the_kind_of_the_first_ready_operator():
+    """graph_info.cc takes the first epoch's kind from the first ready node in execution order.  Here a builtin stem op (index 0)
+    and an LceQuantize of ANOTHER graph input (index 1) are both ready at the start: the builtin epoch runs first, so the
+    quantize shares a section with the LceBconv2d behind it instead of getting a leading section of its own."""
+    spec = O.ConvSpec(1, 8, 8, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1)
+    _, w, mul, bias = synth.conv_inputs(spec, 4)
+    b = ModelBuilder()
+    x0 = b.tensor([1, 8, 8, 64], np.float32, "x0")
+    x1 = b.tensor([1, 8, 8, 64], np.float32, "x1")
+    r = b.tensor([1, 8, 8, 64], np.float32, "relu")
+    q1 = b.tensor([1, 8, 8, 2], np.int32, "q1")
+    qr = b.tensor([1, 8, 8, 2], np.int32, "qr")
+    y = b.tensor([1, 8, 8, 64], np.float32, "y")
+    tw, tm, tb = b.tensor(w.shape, np.int32, "w", w), b.tensor([64], np.float32, "m", mul), b.tensor([64], np.float32, "b", bias)
+    b.inputs, b.outputs = [x0, x1], [y, q1]
+    b.builtin_op(19, [x0], [r])                         # 0: RELU (builtin), ready at the start
+    b.custom_op("LceQuantize", [x1], [q1], b"")         # 1: LCE, ready at the start too
+    b.custom_op("LceQuantize", [r], [qr], b"")          # 2
+    b.custom_op("LceBconv2d", [qr, tw, tm, tb, -1], [y], bconv_options(spec))   # 3
+    m = mr.LceModel(b.finish())
+    assert [s.ops for s in m.sections] == [[1, 2, 3]]
+
+
 def test_partition_is_linear_in_the_model_size():
     """Model open on an adversarially long chain: 4000 operators partition in well under a second (round 3's partition was
     quadratic in the operator count)."""

@@ -20,5 +20,35 @@ window)
     python tools/ab_opts.py 14 256x256 f32 256 5 100 base
   } > $OUT/ab.txt 2>&1
   ;;
+lowk)
+  # where does 28x28x128's gain with interleaved 4-row segments come from -- the segments or the interleave?  and the other low-K layers
+  R4="engine=stream,stream_rows=4"; R7="engine=stream,stream_rows=7"; R14="engine=stream,stream_rows=14"; R2="engine=stream,stream_rows=2"
+  {
+    python tools/ab_opts.py 28 128x128 f32 256 6 60 base rows4:$R4 rows4il:$R4,stream_interleave=1 rows7il:$R7,stream_interleave=1 rows14:$R14 rows14il:$R14,stream_interleave=1 rows2il:$R2,stream_interleave=1
+    python tools/ab_opts.py 28 128x128 i8 256 4 60 base rows4:$R4 rows4il:$R4,stream_interleave=1 rows14il:$R14,stream_interleave=1
+    python tools/ab_opts.py 28 128x128 bp 256 4 60 base rows4:$R4 rows4il:$R4,stream_interleave=1 rows14il:$R14,stream_interleave=1
+    python tools/ab_opts.py 56 64x64 f32 256 4 40 base stream56:engine=stream rows8:engine=stream,stream_rows=8 rows14:$R14 rows14il:$R14,stream_interleave=1 rows28il:engine=stream,stream_rows=28,stream_interleave=1
+    python tools/ab_opts.py 56 64x64 i8 256 4 40 base rows8il:engine=stream,stream_rows=8,stream_interleave=1 rows14il:$R14,stream_interleave=1
+    python tools/ab_opts.py 14 256x256 f32 256 4 100 base rows7:$R7 rows7il:$R7,stream_interleave=1 rows2il:$R2,stream_interleave=1
+    python tools/ab_opts.py 56 64x128s2 f32 256 4 60 base rows4il:$R4,stream_interleave=1 rows14il:$R14,stream_interleave=1
+    python tools/ab_opts.py 28 128x256s2 f32 256 4 100 base rows7il:$R7,stream_interleave=1 rows2il:$R2,stream_interleave=1
+    python tools/ab_opts.py 56 256x256 f32 256 3 20 base rows4il:engine=stream,stream_rows=4,stream_interleave=1 rows8il:engine=stream,stream_rows=8,stream_interleave=1
+    ./tools/probes/store_overlap | grep stream_pattern
+  } > $OUT/ab.txt 2>&1
+  ;;
+phases)
+  # block timelines (LCE_STREAM_PHASES build: bash tools/build_exp.sh sph:"-DLCE_STREAM_PHASES") of the low-K float layer with whole images, 4-row
+  # segments, and interleaved 4-row segments
+  export LCE_HIP_LIBRARY=$PWD/build_exp/lib_sph.so
+  {
+    for o in "" "stream_rows=4" "stream_rows=4,stream_interleave=1"; do
+      echo "## 28x28x128 f32 [$o]"; LCE_OPTS=$o python tools/stream_phases.py 28 128x128 f32
+    done
+    for o in "" "stream_rows=14,stream_interleave=1"; do
+      echo "## 56x56x64 f32 [$o]"; LCE_OPTS=$o python tools/stream_phases.py 56 64x64 f32
+    done
+    echo "## 14x14x256 f32"; python tools/stream_phases.py 14 256x256 f32
+  } > $OUT/phases.txt 2>&1
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
