@@ -50,5 +50,20 @@ phases)
     echo "## 14x14x256 f32"; python tools/stream_phases.py 14 256x256 f32
   } > $OUT/phases.txt 2>&1
   ;;
+ws1)
+  # the weight-streaming kernel against the planner's choice (byte comparison first, then interleaved timings)
+  {
+    for d in f32 i8 bp; do
+      python tools/ab_opts.py 14 256x256 $d 256 5 100 base wstream:engine=wstream
+      python tools/ab_opts.py 7 512x512 $d 256 5 100 base wstream:engine=wstream
+    done
+    python tools/ab_opts.py 14 256x512s2 f32 256 4 100 base wstream:engine=wstream
+    python tools/ab_opts.py 7 512x512s2 f32 256 4 100 base wstream:engine=wstream
+    python tools/ab_opts.py 28 128x256s2 f32 256 4 100 base wstream:engine=wstream
+    python tools/ab_opts.py 28 128x128 f32 256 4 60 base wstream:engine=wstream rows4il:engine=stream,stream_rows=4,stream_interleave=1
+    python tools/ab_opts.py 14 256x256 f32 64 4 100 base wstream:engine=wstream
+    python tools/ab_opts.py 14 256x256 f32 512 4 100 base wstream:engine=wstream
+  } > $OUT/ab.txt 2>&1
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
