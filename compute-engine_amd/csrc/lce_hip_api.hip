@@ -21,6 +21,7 @@
 #include "lce_tu_mfma_2d.hip"
 #include "lce_tu_pointwise.hip"
 #include "lce_tu_stream.hip"
+#include "lce_tu_wstream.hip"
 #endif
 #include "lce_plan.h"
 #include "lce_prepare.h"
@@ -567,6 +568,16 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
   if (!strcmp(key, "stream_interleave")) {   // the streaming kernel's segment -> block map: 1 = block b owns segments b, b + grid, ... (a compact write window), 0 = consecutive ones
     if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_interleave must be 0 or 1");
     h.stream_interleave_pref = value[0] == '1';
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
+  if (!strcmp(key, "wstream_blocks") || !strcmp(key, "wstream_images")) {   // tuning aids for the weight-streaming kernel: pixel blocks per block (1..4), images per group; 0 = auto
+    const int v = atoi(value);
+    const bool blocks = key[8] == 'b';
+    if (v < 0 || (v == 0 && strcmp(value, "0")) || (blocks && v > 4))
+      return fail(LCE_HIP_ERR_INVALID, "plan_set_option: wstream_blocks must be 0 (auto) .. 4, wstream_images 0 (auto) or a positive count");
+    (blocks ? h.ws_blocks_pref : h.ws_images_pref) = v;
     plan->selected_for_pixels = -1;
     plan->device_current = false;
     return LCE_HIP_OK;

@@ -175,6 +175,7 @@ struct StreamArgs {
   int32_t flat;                // 1: pixel blocks are cut from the block's segments laid end to end (NPX pixels each)
   int32_t NPX;                 // output pixels per segment = RS * OW
   int32_t NQ;                  // pixel blocks of a full block's stream = rows of the context table
+  uint32_t need0;              // = sched[0]: items resident before tile step 0 (here, so that the first rows' loads wait for the kernel arguments only)
   uint32_t in_bytes, w_bytes, out_bytes;   // bytes bound to the input / weight / output buffer resources (< 2^31)
   // the planner's tables (one buffer): sched at byte 0, one dword per tile step; lim: one dword per pixel block (its
   // last real row); ctx: 16 bytes per (pixel block, lane) = {tap-row LDS addresses 0..2, output byte offset}

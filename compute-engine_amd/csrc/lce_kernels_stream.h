@@ -262,6 +262,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // the CU's vector memory path busy for ~6 k cycles (295 KB per CU); a quarter goes out at once, the rest in small pieces
   // between the work that does not need them -- the per-channel constants, the ring's padding columns, the expansion of
   // the first rows -- so that work rides in the shadow of the bank's arrival instead of waiting in front of it or behind it.
+  // Round 5, K-split instances (kBankPaced): the first rows' loads go out FIRST, the fragments of the first kBankAhead K-steps
+  // behind them, and every K-step of the FIRST block step issues the two loads of K-step ks + kBankAhead behind its MFMAs -- the
+  // bank arrives during the first block step instead of in front of it.  A lone wave does not overlap its own load issue with
+  // its MFMAs (the step runs 3.8 k cycles of loads + 2 k of MFMAs, profiles/r05/stream_phases_paced.txt), so the block's life
+  // does not change much: 7x7x512 -2...-3 % (three output types, two boxes), 14x14x256 +1...2 %, L0 +-0 -- adopted where it gains.
   u32x4 W[KS][2];
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
   // loads [a, b) of the bank's 2 * KS, numbered ks * 2 + j
@@ -278,25 +283,29 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     }
     sched_fence();
   };
-  constexpr int kBankFirst = KS / 2;                        // the first run: a quarter of the bank
-  constexpr int kBankRest = 2 * KS - kBankFirst;            // the rest: sixteen pieces, one behind each expanded word
+  constexpr bool kBankPaced = KSPLIT;
+  constexpr int kBankAhead = 12;                            // paced: K-steps of the bank in flight ahead of the first block step's MFMAs
+  constexpr int kBankFirst = kBankPaced ? 2 * kBankAhead : KS / 2;          // the first run (unpaced: a quarter of the bank)
+  constexpr int kBankRest = kBankPaced ? 0 : 2 * KS - kBankFirst;           // the rest: sixteen pieces, one behind each expanded word
+  static_assert(kBankFirst <= 2 * KS, "the first run is part of the bank");
   auto bank_run = [&](auto rc) LCE_LAMBDA_INLINE { bank_loads(IntC<0>{}, IntC<kBankFirst>{}); };
   auto bank_piece = [&](auto pc) LCE_LAMBDA_INLINE {
     constexpr int p = decltype(pc)::value;
-    bank_loads(IntC<kBankFirst + kBankRest * p / 16>{}, IntC<kBankFirst + kBankRest * (p + 1) / 16>{});
+    if constexpr (!kBankPaced) bank_loads(IntC<kBankFirst + kBankRest * p / 16>{}, IntC<kBankFirst + kBankRest * (p + 1) / 16>{});
   };
   sched_fence();
-  bank_run(IntC<0>{});
+  if constexpr (!kBankPaced) bank_run(IntC<0>{});
   // ---- prologue.  The bank's first run goes out before anything else (it needs nothing but the kernel arguments, and the
   // schedule's first entry -- a dependent scalar load -- is still on its way); the first rows' loads follow, AHEAD of the
   // rest of the bank: the memory counter retires in order, so behind all 72 loads per lane they could not be consumed
   // before the whole bank had arrived. ----
-  const uint32_t need0 = sched[0];
+  const uint32_t need0 = kBankPaced ? G.need0 : sched[0];     // (paced: with the kernel arguments, no dependent load in front of the first rows')
   u32x4 wv0[4];
   uint32_t dv0[4];
   int mv0[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) item_issue((uint32_t)(k * 256 + tid), need0, wv0[k], dv0[k], mv0[k]);
+  if constexpr (kBankPaced) bank_run(IntC<0>{});
   LCE_SPH(58);
 
   LCE_SPH(59);
@@ -386,7 +395,6 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // The hint is a USE of the loaded value (a counted wait).  Round 4: it no longer sits here, in front of the first MFMA
   // -- the FIRST block step below takes each K-step's two fragments as they arrive (the bank is 295 KB per CU and takes
   // ~6 k cycles to come in; the first pixel block's 72 MFMAs now run inside that time instead of behind it).
-  // LCE_STREAM_BANK_UPFRONT (A/B aid): the round-3 order, all of the bank before the first MFMA.
   auto bank_home = [&](auto ksc) LCE_LAMBDA_INLINE {
     constexpr int ks = decltype(ksc)::value;
 #pragma unroll
@@ -395,15 +403,6 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       else keep_in_vgpr(W[ks][j]);
     }
   };
-#ifdef LCE_STREAM_BANK_UPFRONT
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (ks < 32) keep_in_agpr(W[ks][j]);
-      else keep_in_vgpr(W[ks][j]);
-    }
-#endif
   block_barrier_keep_vm();
   LCE_SPH(1);
 
@@ -790,9 +789,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       if constexpr (ks < KS) {
         constexpr int g = ks / GA;
         constexpr int fs = (g + k * NG) & 1;     // the fragment set this block's group g lives in (set 0 after a barrier)
-#ifndef LCE_STREAM_BANK_UPFRONT
         if constexpr (FIRST) bank_home(IntC<ks>{});     // this K-step's weights have arrived (a counted wait) and are at home
-#endif
         // ---------------- MFMA 0 ----------------
         if constexpr (ks == 0) acc[PAR][0] = mfma_fp4_32x32x64_unscaled(af[fs][0], W[0][0], kbt);    // K_bt - <a, w> = 2 * accum
         else acc[PAR][0] = mfma_fp4_32x32x64_unscaled(af[fs][ks % GA], W[ks][0], acc[PAR][0]);
@@ -877,6 +874,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 #endif
         }
 #endif
+        if constexpr (kBankPaced && FIRST && ks + kBankAhead < KS) bank_loads(IntC<2 * (ks + kBankAhead)>{}, IntC<2 * (ks + kBankAhead) + 2>{});
         if constexpr (kPipeBallots && (SIGN || DST == kDstBitpacked) && !FIRST && ks == SA) flush_ballots(IntC<NUA - 1>{});   // the last unit's
         if constexpr (SIGN && !FIRST && ks == SA) sign_store(epi_sob);      // phase A is complete: the drained block's sign words
         if constexpr (ks == SA) load_ctx(u + 1, nxt);
@@ -953,12 +951,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     block_barrier_keep_vm();     // this tile step's rows are visible; the rows it read may be overwritten
     LCE_SPH(2 + T);
   };
-#ifdef LCE_STREAM_BANK_UPFRONT
-  for (int T = 0; T < ntile; ++T) tile_step(TagSteady{}, T);
-#else
   if (ntile > 0) tile_step(TagFirst{}, 0);
   for (int T = 1; T < ntile; ++T) tile_step(TagSteady{}, T);
-#endif
 
   // drain: the last block step's accumulators (its set by the parity of the step count)
   auto drain = [&](f32x16 (&last)[2], int slot) LCE_LAMBDA_INLINE {

@@ -21,7 +21,7 @@
 //     transpose through a wave-private LDS scratch, row stores) run beside the other block's K loop.
 //
 // Same arithmetic as the other matrix-core kernels -- the planner's FP4 weight image (pack_for_mfma: negated,
-// [K-step][K-half][Npad][16 B]), accumulators start at K_bt and end as 2 * popcount-accumulator (output_transform.h:62-91),
+// tile-major: [32-channel tile][K-step][K-half][32 x 16 B]), accumulators start at K_bt and end as 2 * popcount-accumulator (output_transform.h:62-91),
 // float transform with two roundings (:99-106), int8 round-half-away + saturate (:31-44), bitpacked compare (:160-168)
 // -- so results are bit-identical to them and to the oracle.  Replaces core/indirect_bgemm/kernel_4x2_portable.h:84-111
 // (one GEMM for every shape) for the shapes the weight-stationary kernel serves badly.
@@ -30,10 +30,17 @@
 #include "lce_kernel_args.h"
 #include "lce_kernels.h"
 #include "lce_kernels_mfma.h"
+#ifdef LCE_STREAM_PHASES
+#include "lce_kernels_stream.h"     // (profiling builds: the streaming kernel's per-block time stamps, LCE_SPH)
+#else
+#ifndef LCE_SPH
+#define LCE_SPH(slot) do {} while (0)
+#endif
+#endif
 
 namespace lce {
 
-constexpr int kWsPrefetch = 2;        // K-steps of weight fragments in flight ahead of the one being multiplied
+constexpr int kWsPrefetch = 3;        // K-steps of weight fragments in flight ahead of the one being multiplied
 constexpr int kWsScratch = 8192;      // bytes of a wave's epilogue scratch: [32 pixel rows][64 channels] floats
 
 // DST: kDstFloat / kDstInt8 / kDstBitpacked.  KCH: 64-channel chunks per tap (3x3 filters: 9 * KCH K-steps).  NB: the most
@@ -59,12 +66,14 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
   const int n0 = (block_idx_y() * 4 + wave) * 64;
   const bool slice_ok = n0 < G.Npad;
   uint8_t* const lds0 = lds_base();
+  LCE_SPH(0);
 
   // ---- the weight stream: fragment (K-step ks, channel tile j) of lane (column l31, K-half) ----
   const rsrc_t rw = make_rsrc(wq, G.w_bytes);
-  const uint32_t wlane0 = slice_ok ? (uint32_t)(half * G.Npad + n0 + l31) * 16u : kOobOffset;
-  const uint32_t wlane1 = sat_add_u32(wlane0, 512u);                    // the slice's second 32 channels
-  const uint32_t wstep = (uint32_t)G.Npad * 32u;                        // bytes per K-step: 2 K-halves x Npad x 16
+  // (tile-major image, pack_for_mfma: [32-channel tile][K-step][K-half][32 x 16 B])
+  const uint32_t wlane0 = slice_ok ? ((uint32_t)(n0 >> 5) * (uint32_t)(KS * 2) + (uint32_t)half) * 512u + (uint32_t)l31 * 16u : kOobOffset;
+  const uint32_t wlane1 = sat_add_u32(wlane0, (uint32_t)(KS * 1024));   // the slice's second 32 channels
+  constexpr uint32_t wstep = 1024u;                                     // bytes per K-step of one tile: 2 K-halves x 512
   u32x4 Wr[NW][2];
   auto w_load = [&](int ks) LCE_LAMBDA_INLINE {
     Wr[ks % NW][0] = buf_load_so(rw, wlane0, (uint32_t)ks * wstep, (u32x4*)nullptr);
@@ -142,6 +151,7 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
     ta[q][0] = c[0]; ta[q][1] = c[1]; ta[q][2] = c[2];
   }
   block_barrier_keep_vm();        // the images are in LDS
+  LCE_SPH(1);
 
   // ---- K loop, K-major: weights of K-step ks + D on their way, one A fragment per pixel block, 2 MFMAs each ----
   f32x16 acc[NB][2];
@@ -152,9 +162,14 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
       u32x4 af[2][NBR];
 #pragma unroll
       for (int q = 0; q < NBR; ++q) af[0][q] = *(const u32x4*)(lds0 + ta[q][0]);
+      sched_fence();
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        // The scheduling fences pin what the source order says: left alone, the compiler sinks every load to just in front of
+        // its use to save registers (the first build: weight loads one K-step ahead instead of D, A fragments read right in
+        // front of their MFMAs), which exposes the L2 and LDS latencies the prefetch distances are there to hide.
         if (ks + D < KS) w_load(ks + D);
+        sched_fence();
 #pragma unroll
         for (int q = 0; q < NBR; ++q) {
           if (ks + 1 < KS) {      // the next K-step's fragment of this pixel block, one K-step ahead of its MFMAs
@@ -163,12 +178,18 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
           }
           acc[q][0] = mfma_fp4_32x32x64_unscaled(af[ks & 1][q], Wr[ks % NW][0], ks == 0 ? kbt : acc[q][0]);
           acc[q][1] = mfma_fp4_32x32x64_unscaled(af[ks & 1][q], Wr[ks % NW][1], ks == 0 ? kbt : acc[q][1]);
+          pin(acc[q][0]);          // (an MFMA has no side effect a scheduling fence could hold: the pins keep the pair in place)
+          pin(acc[q][1]);
+          sched_fence();
         }
       }
     }
   };
-  if (nbq >= (uint32_t)NB) kloop(IntC<NB>{});
-  else kloop(IntC<NB - 1>{});
+  if (slice_ok) {
+    if (nbq >= (uint32_t)NB) kloop(IntC<NB>{});
+    else kloop(IntC<NB - 1>{});
+  }
+  LCE_SPH(2);
 
   // ---- epilogue, one pixel block at a time: transform in place, [sign words], transpose through the wave's scratch, row stores ----
   const rsrc_t rout = make_rsrc(out, G.out_bytes);
@@ -282,6 +303,7 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
       wave_lds_fence();
     }
   }
+  LCE_SPH(63);
 }
 
 }  // namespace lce

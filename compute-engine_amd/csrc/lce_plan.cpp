@@ -612,6 +612,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.flat = p.st_flat;
   G.NPX = p.st_rs * p.out_w;
   G.NQ = p.st_nq;
+  G.need0 = p.st_tabs.empty() ? 0u : p.st_tabs[0];
   G.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
   G.w_bytes = (uint32_t)p.wq.size();
   G.out_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p));
@@ -685,11 +686,13 @@ std::string plan_wstream(HostPlan& p, int batch_chunk) {
   const int ny = ceil_div(ceil_div(d.channels_out, 64), 4), cus = std::max(1, p.num_cus);
   int best_ipb = 0;
   int64_t best_cost = 0;
+  const int nbmax = p.ws_blocks_pref > 0 ? p.ws_blocks_pref : 4;       // pixel blocks per block (tuning aid: wstream_blocks)
   for (int ipb = 1; ipb <= std::min(batch_chunk, 64); ++ipb) {
+    if (p.ws_images_pref > 0 && ipb != p.ws_images_pref) continue;
     const int64_t lds_images = ((int64_t)ipb * img_pitch + 1023) / 1024 * 1024;
     if (lds_images + kWsLdsExtra > 160 * 1024) break;
     const int occupancy = (int)std::min<int64_t>(2, (160 * 1024) / (lds_images + kWsLdsExtra));
-    const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, 4), groups = ceil_div(batch_chunk, ipb);
+    const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, nbmax), groups = ceil_div(batch_chunk, ipb);
     std::vector<int> nb_of_block;
     for (int y = 0; y < ny; ++y)
       for (int part = 0; part < parts; ++part)
@@ -700,7 +703,7 @@ std::string plan_wstream(HostPlan& p, int batch_chunk) {
   }
   if (best_ipb == 0) return "bconv2d: one image of this layer does not fit the weight-streaming kernel's LDS (whole images are resident)";
   const int ipb = best_ipb;
-  const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, 4);
+  const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, nbmax);
   p.ws_ipb = ipb; p.ws_parts = parts; p.ws_nq = nq; p.ws_npxg = ipb * ohw; p.ws_nb = ceil_div(nq, parts); p.ws_ny = ny;
   p.ws_hp = hp; p.ws_wp = wp; p.ws_pitch = pitch; p.ws_img_pitch = img_pitch; p.ws_qg = qg;
   p.ws_lds_images = (int)(((int64_t)ipb * img_pitch + 1023) / 1024 * 1024);
@@ -810,7 +813,13 @@ static void pack_for_mfma(HostPlan& p) {
         const uint8_t nib = ((w >> (ci % 32)) & 1u) ? 0x2 : 0xA;
         const int c = g * cin_g + ci;                         // position in the pixel's channel vector
         const int ks = t * kch + (c / 64 - chunk0), j = c % 64, half = j / 32, jj = j % 32;
-        uint8_t& byte = p.wq[(((size_t)ks * 2 + half) * p.npad + oc) * 16 + jj / 2];
+        // K-major (the block GEMM, the pointwise and the weight-stationary kernels): [K-step][K-half][Npad][16 B].  Tile-major (the
+        // weight-streaming kernel): [32-channel tile][K-step][K-half][32 x 16 B] -- a wave's fragment is 512 contiguous bytes and
+        // the fragments that the waves of a launch fetch at the same moment (one K-step, all tiles) lie KS KiB apart instead of
+        // inside two 4-KiB runs, i.e. spread over the L2's channels instead of queueing on two of them.
+        const size_t cell = p.wq_layout == 1 ? (((size_t)(oc / 32) * ks_total + ks) * 2 + half) * 32 + oc % 32
+                                             : ((size_t)ks * 2 + half) * p.npad + oc;
+        uint8_t& byte = p.wq[cell * 16 + jj / 2];
         byte |= (uint8_t)(nib << (4 * (jj & 1)));
       }
   }
@@ -1083,7 +1092,8 @@ static bool stream_worthwhile(const HostPlan& p) {
 static void use_wstream_plan(HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
   const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
-  const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
+  const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 1;
+  p.wq_layout = 1;                       // tile-major: [32-channel tile][K-step][K-half][32 x 16 B] (pack_for_mfma)
   p.mfma = want;
   p.use_mfma = true;
   p.use_wstream = true;
@@ -1129,7 +1139,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     const std::string err = plan_stream(p, batch_chunk);
     if (err.empty() && (p.engine_pref == 5 || stream_worthwhile(p))) {
       const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
-      const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
+      const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0;
+      p.wq_layout = 0;
       p.mfma = want;
       p.use_mfma = true;
       p.use_stream = true;
@@ -1179,7 +1190,8 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
         if (!direct) direct = true;  // reported below by direct_geometry
       }
     }
-    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn();
+    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0;
+    p.wq_layout = 0;
     p.mfma = want;
     p.cpad = ceil_div(d.channels_in, 64) * 64;
     p.npad = ceil_div(d.channels_out, want.bn()) * want.bn();

@@ -87,6 +87,7 @@ struct HostPlan {
   int kch = 0;                             // K-steps (64-channel chunks) per filter tap that a block runs: cpad/64,
                                            // or the chunks one group's channel slice touches
   std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
+  int wq_layout = 0;                       // 0: K-major [K-step][K-half][Npad][16 B]; 1: tile-major [Npad/32][K-step][K-half][32][16 B] (wstream)
   std::vector<float> mul_q, bias_q, thr_q; // Npad entries
 
   // weight-stationary streaming kernel (lce_kernels_stream.h); with use_mfma
@@ -111,6 +112,7 @@ struct HostPlan {
   bool use_wstream = false;
   int ws_ipb = 0, ws_parts = 0, ws_nq = 0, ws_npxg = 0, ws_nb = 0, ws_ny = 1;   // images per group, blocks per group, pixel blocks / pixels per group, most pixel blocks per block, grid.y
   int ws_hp = 0, ws_wp = 0, ws_pitch = 0, ws_img_pitch = 0, ws_qg = 0, ws_lds_images = 0;   // LDS image geometry
+  int ws_blocks_pref = 0, ws_images_pref = 0;   // tuning aids: most pixel blocks per block (0 = 4), images per group (0 = the cost model's choice)
   int ws_occupancy = 1;                      // blocks that fit a CU's LDS side by side (the kernel is built for two)
   uint32_t ws_tab_part = 0, ws_tab_ctx = 0;  // byte offsets inside st_tabs
   int64_t ws_cost = 0;                       // the planner's cycle estimate of a launch (plan_wstream)

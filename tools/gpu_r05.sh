@@ -65,5 +65,56 @@ ws1)
     python tools/ab_opts.py 14 256x256 f32 512 4 100 base wstream:engine=wstream
   } > $OUT/ab.txt 2>&1
   ;;
+ws2)
+  # the weight-streaming kernel with its schedule pinned: parts of at most 4 / 3 / 2 pixel blocks (when do the stores start?), groups of 1 / 2 / 4 images
+  W="engine=wstream"
+  {
+    python tools/ab_opts.py 14 256x256 f32 256 5 100 base ws4:$W ws3:$W,wstream_blocks=3 ws2:$W,wstream_blocks=2 ws1:$W,wstream_blocks=1
+    python tools/ab_opts.py 14 256x256 i8 256 5 100 base ws4:$W ws3:$W,wstream_blocks=3 ws2:$W,wstream_blocks=2
+    python tools/ab_opts.py 14 256x256 bp 256 5 100 base ws4:$W ws3:$W,wstream_blocks=3 ws2:$W,wstream_blocks=2
+    python tools/ab_opts.py 7 512x512 f32 256 5 100 base ws:$W i1b2:$W,wstream_images=1 i2b4:$W,wstream_images=2 i4b4:$W,wstream_images=4 i4b3:$W,wstream_images=4,wstream_blocks=3 i2b2:$W,wstream_images=2,wstream_blocks=2
+    python tools/ab_opts.py 7 512x512 i8 256 5 100 base ws:$W i2b4:$W,wstream_images=2 i4b4:$W,wstream_images=4 i2b2:$W,wstream_images=2,wstream_blocks=2
+    python tools/ab_opts.py 7 512x512 bp 256 5 100 base ws:$W i2b4:$W,wstream_images=2 i4b4:$W,wstream_images=4
+    python tools/ab_opts.py 14 256x512s2 f32 256 4 100 base ws:$W i2:$W,wstream_images=2
+  } > $OUT/ab.txt 2>&1
+  ;;
+paced)
+  # the bank's loads paced inside the first block step (in-tree) vs the previous build (build_exp/lib_prev.so), same box, alternating processes
+  {
+    for spec in "14 256x256 f32 256 3 100" "14 256x256 i8 256 3 100" "14 256x256 bp 256 3 100" "7 512x512 f32 256 3 100" "7 512x512 i8 256 3 100" \
+                "28 128x128 f32 256 3 60" "56 256x256 f32 256 3 20" "56 256x256 bp 256 3 20" "28 128x256s2 f32 256 3 100" "224 256x256 f32 16 3 20"; do
+      bash tools/ab_libs.sh 3 "$spec base" build_exp/lib_prev.so base
+    done
+  } > $OUT/ab.txt 2>&1
+  ;;
+phases2)
+  export LCE_HIP_LIBRARY=$PWD/build_exp/lib_sph.so
+  {
+    echo "## 14x14x256 f32 stream (paced bank)"; python tools/stream_phases.py 14 256x256 f32
+    echo "## 7x7x512 f32 stream (paced bank)"; python tools/stream_phases.py 7 512x512 f32
+    echo "## 14x14x256 f32 wstream"; LCE_OPTS=engine=wstream python tools/stream_phases.py 14 256x256 f32
+    echo "## 14x14x256 i8 wstream"; LCE_OPTS=engine=wstream python tools/stream_phases.py 14 256x256 i8
+    echo "## 14x14x256 bp wstream"; LCE_OPTS=engine=wstream python tools/stream_phases.py 14 256x256 bp
+    echo "## 56x56x256 f32 stream"; python tools/stream_phases.py 56 256x256 f32
+  } > $OUT/phases.txt 2>&1
+  ;;
+ws3)
+  # weight-streaming kernel with the tile-major weight image (in-tree) vs the K-major one (build_exp/lib_prev.so), same box
+  W="engine=wstream"
+  {
+    for spec in "14 256x256 f32 256 3 100" "14 256x256 i8 256 3 100" "14 256x256 bp 256 3 100" "7 512x512 f32 256 3 100" "7 512x512 i8 256 3 100" "7 512x512 bp 256 3 100" "14 256x512s2 f32 256 3 100"; do
+      bash tools/ab_libs.sh 2 "$spec base ws:$W ws3:$W,wstream_blocks=3 ws2:$W,wstream_blocks=2" build_exp/lib_prev.so base
+    done
+  } > $OUT/ab.txt 2>&1
+  ;;
+sweep)
+  # every candidate kernel on the planner's calibration grid (tools/engine_sweep.py)
+  rm -f $OUT/engine_sweep.jsonl
+  python tools/engine_sweep.py $OUT/engine_sweep.jsonl > $OUT/log.txt 2>&1
+  ;;
+sweepq)
+  rm -f $OUT/engine_sweep.jsonl
+  python tools/engine_sweep.py $OUT/engine_sweep.jsonl --quick 14x256x256 7x512x512 > $OUT/log.txt 2>&1
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
