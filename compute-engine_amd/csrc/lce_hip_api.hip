@@ -123,13 +123,7 @@ struct lce_hip_bconv2d_plan {
   size_t stage_in_bytes = 0, stage_out_bytes = 0;
   hipStream_t s_h2d = nullptr, s_run = nullptr, s_d2h = nullptr;
   std::vector<hipEvent_t> ev_in, ev_run;
-  // Which kernel is best can depend on whether the call wants the second (LceQuantize) output: the streaming kernel's sign
-  // gather costs it more than the block GEMM's (lce_plan.cpp, stream_candidate).  For such a layer run_dual drives a second
-  // plan -- same description, weights and options, want_sign set -- made on its first use, so a plan that is driven both
-  // ways never re-plans and never uploads twice.  Dropped whenever the weights or an option change.
-  lce_hip_bconv2d_plan* with_second_output = nullptr;
   ~lce_hip_bconv2d_plan() {
-    delete with_second_output;
     for (hipEvent_t e : ev_in) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_run) (void)hipEventDestroy(e);
     if (s_h2d) (void)hipStreamDestroy(s_h2d);
@@ -500,8 +494,6 @@ lce_hip_status lce_hip_bconv2d_plan_set_weights(lce_hip_bconv2d_plan* plan, cons
   if (!bp && (!post_mul || !post_bias))
     return fail(LCE_HIP_ERR_INVALID, "plan_set_weights: float/int8 output needs post_activation_multiplier and _bias");
   lce::fold_parameters(plan->host, filter, post_mul, post_bias, thresholds);
-  delete plan->with_second_output;
-  plan->with_second_output = nullptr;
   plan->device_current = false;
   plan->selected_for_pixels = -1;
   return LCE_HIP_OK;
@@ -523,8 +515,6 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
 lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const char* key, const char* value) {
   if (!plan || !key || !value) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: null argument");
   lce::HostPlan& h = plan->host;
-  delete plan->with_second_output;
-  plan->with_second_output = nullptr;
   if (!strcmp(key, "tile2d")) {   // tuning aid for the direct variant: auto | on | off
     if (!strcmp(value, "auto")) h.tile2d_pref = 0;
     else if (!strcmp(value, "on")) h.tile2d_pref = 1;
@@ -566,8 +556,8 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     return LCE_HIP_OK;
   }
   if (!strcmp(key, "stream_interleave")) {   // the streaming kernel's segment -> block map: 1 = block b owns segments b, b + grid, ... (a compact write window), 0 = consecutive ones
-    if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_interleave must be 0 or 1");
-    h.stream_interleave_pref = value[0] == '1';
+    if (strcmp(value, "0") && strcmp(value, "1") && strcmp(value, "auto")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_interleave must be auto, 0 or 1");
+    h.stream_interleave_pref = value[0] == 'a' ? -1 : value[0] == '1';
     plan->selected_for_pixels = -1;
     plan->device_current = false;
     return LCE_HIP_OK;
@@ -656,24 +646,9 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
   return LCE_HIP_OK;
 }
 
-// The plan run_dual drives: the plan itself unless the auto rule answers differently with the second output.
-static lce_hip_bconv2d_plan* plan_for_second_output(lce_hip_bconv2d_plan* plan) {
-  if (plan->host.d.dst_type == LCE_HIP_BITPACKED || !lce::auto_choice_depends_on_second_output(plan->host)) return plan;
-  if (!plan->with_second_output) {
-    lce_hip_bconv2d_plan* twin = new lce_hip_bconv2d_plan();
-    twin->host = plan->host;             // description, folded weights, options
-    twin->host.want_sign = true;
-    twin->host.kernel_name.clear();      // selects (and uploads) for itself on its first run
-    twin->cus_forced = plan->cus_forced;
-    plan->with_second_output = twin;
-  }
-  return plan->with_second_output;
-}
-
-const char* lce_hip_bconv2d_plan_kernel_name_dual(lce_hip_bconv2d_plan* plan) {
-  if (!plan) return "";
-  return lce_hip_bconv2d_plan_kernel_name(plan_for_second_output(plan));
-}
+// (The kernel choice does not depend on whether a call asks for the second output: one plan, one selection, both kinds of call.)
+const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan);
+const char* lce_hip_bconv2d_plan_kernel_name_dual(lce_hip_bconv2d_plan* plan) { return lce_hip_bconv2d_plan_kernel_name(plan); }
 
 const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan) {
   if (!plan) return "";
@@ -867,10 +842,7 @@ lce_hip_status lce_hip_bconv2d_run_dual(lce_hip_bconv2d_plan* plan, const int32_
                 "plan already writes bits)");
   if (plan->host.d.batch == 0) return LCE_HIP_OK;
   if (!output_bits_dev) return fail(LCE_HIP_ERR_INVALID, "bconv2d_run_dual: null argument");
-  if (lce_hip_status s = check_device(plan)) return s;   // (the plan and its twin are bound to the same device)
-  lce_hip_bconv2d_plan* const target = plan_for_second_output(plan);
-  target->device = plan->device;
-  plan = target;
+  if (lce_hip_status s = check_device(plan)) return s;
   return run_images(plan, input_dev, output_dev, output_bits_dev, 0, plan->host.d.batch, (hipStream_t)stream);
 }
 

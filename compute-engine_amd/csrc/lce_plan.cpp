@@ -1,6 +1,8 @@
 // Host-side planner for LceBconv2d on MI355X (see lce_plan.h).
 // Citations are relative to /root/reference/larq_compute_engine/.
 #include "lce_plan.h"
+#include <cstdio>
+#include <cstdlib>
 
 #include <limits.h>
 #include <string.h>
@@ -1019,74 +1021,137 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
   return G;
 }
 
-// Auto rule for the streaming kernel (profiles/r03/stream_vs_block_gemm.txt, batch 256): with a 3x3x256 filter bank
-// (36 K-steps per pixel block) it beats the block GEMM on every output type -- 56x56: float 0.188 vs 0.239 ms, int8
-// 0.175 vs 0.215, bitpacked 0.148 vs 0.162; 14x14: float 20.8 vs 23.6 us -- with 128 or 64 input channels a pixel
-// block has too few MFMAs to carry its epilogue and it loses (28x28x128 float 29.1 vs 27.5 us, 56x56x64 47.8 vs 40.7).
-// A launch must also fill the chip: at least three quarters of the CUs get a block, a block runs long enough
-// (>= 6 block steps) to pay for loading its filter bank, and segments are not slivers.
-// Auto rule: the layers whose K loop (36 K-steps) hides the woven epilogue -- 256 input channels, one 256-channel block per
-// CU (profiles/r03/stream_vs_block_gemm.txt).  Strided 3x3 layers were tried too (the ring expands every input row once, the
-// block GEMM a tile's whole 4x larger input neighbourhood): timed alone they gain 5-25 % (profiles/r03/stream_stride2.txt),
-// inside config 5's chain -- where every layer also writes its sign words -- nothing (0.2529 vs 0.2520 ms,
-// profiles/r03/strided_stream_chain.txt), so they stay where they were.
-// Which layers the planner tries the streaming kernel on by itself (everything else: engine=stream).  Measured against the
-// block GEMM at batch 256 (profiles/r03/stream_vs_block_gemm.txt, profiles/r04/ksplit_vs_block_gemm.txt):
-//   193..256 input channels, 192..256 output channels: 1.2-1.3x (L0, 14x14x256, 7x7x256);
-//   449..512 input channels (K split over wave pairs), >= 128 output channels: 7x7x512 1.1-1.25x, 7x7x512 -> 128 / 256 1.3-1.7x,
-//   7x7x512 stride 2 1.8x, 14x14x512 1.0-1.1x;
-//   64 / 128 input channels: slower (18 / 36 MFMAs per pixel block do not carry the epilogue) -- not tried.
-static bool stream_candidate(const HostPlan& p, bool want_sign) {
-  if (!stream_supported(p)) return false;
+// ------------------------------------------------------------------------------------
+// Which kernel runs a layer: a cost estimate per candidate, not a list of shapes (round 5)
+// ------------------------------------------------------------------------------------
+// Rounds 3-4 decided by a list of shape conditions measured at batch 256 on the bench's layers; at other batch sizes the list
+// fell through to whatever was left (profiles/r05/engine_sweep_box1.jsonl: batch 1 ... 64, the rule's pick took 1.2 - 7 x the
+// best candidate's time on 128 of 192 (layer, batch, output type) rows).  Now every candidate that can run the layer is PLANNED
+// (segments, blocks, block steps per block -- the planner's own simulation) and priced in microseconds by a small model of where
+// its time goes; the cheapest runs.  Candidates: the weight-stationary streaming kernel with the planner's own segments, or
+// with interleaved runs of r-row segments for every divisor r of the output height; the weight-streaming kernel; the block GEMM
+// (direct / workspace variant, chosen as before).  The model's constants are measured quantities (profiles/r05/README.md,
+// "cost model"): the launch floor, a block's prologue as a function of its filter bank's bytes through the CU's 51 B/clk vector
+// memory path, 33.2 cycles per FP4 MFMA at 1.2 x for the woven fillers, the epilogue's floor per block step by output type, the
+// chip's write rate by store pattern, the block GEMM's 0.14 us per K-step and 1.33 x when two blocks share a CU.
+// tests/test_planner_choice.py holds the choice to within 5 % of the best time recorded in the sweep table on every row.
+namespace cost {
+constexpr double kCyclesPerUs = 2100.0;    // the clock short launches sustain
+constexpr double kLaunchUs = 1.6;          // launch + first instruction (tools/probes/launch_floor.hip)
+constexpr double kMfmaCycles = 33.2;       // one v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (tools/probes/mfma_gap.hip)
+constexpr double kVmemBytesPerClk = 51.0;  // a CU's vector memory path, loads into registers (profiles/r05/stream_phases_paced.txt)
+constexpr double kL2BytesPerUs = 27.0e6;   // what the eight L2s deliver when every CU pulls the same filter bank (75 MB in 2.8 us)
+inline double store_bytes_per_us(int dst, bool compact_window) {   // the chip's write rate by the kernel's store pattern
+  if (dst == LCE_HIP_F32) return compact_window ? 5.6e6 : 5.2e6;
+  return 5.5e6;
+}
+inline double epilogue_us_per_step(int dst) { return dst == LCE_HIP_F32 ? 1.05 : dst == LCE_HIP_I8 ? 1.0 : 0.8; }
+// what a block step of MFMAs costs over its bare matrix time, by output type (the woven epilogue, and the clock the power
+// manager grants: the more the launch writes, the lower), and how much more on launches long enough to reach the sustained state
+inline double step_factor(int dst, int64_t usteps, bool ksplit) {
+  // (K-split instances: a wave transforms and stores 32 channels of a pixel block, not 64)
+  const double base = ksplit ? (dst == LCE_HIP_F32 ? 1.15 : dst == LCE_HIP_I8 ? 1.12 : 1.05) : (dst == LCE_HIP_F32 ? 1.3 : dst == LCE_HIP_I8 ? 1.25 : 1.05);
+  const double sustained = dst == LCE_HIP_BITPACKED ? 0.1 : 0.2;
+  return base * (1.0 + sustained * std::min(1.0, (double)usteps / 100.0));
+}
+}  // namespace cost
+
+static int64_t out_bytes_of(const HostPlan& p, int batch_chunk) {
+  return (int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p);
+}
+
+// The weight-stationary streaming kernel as plan_stream has just planned it (st_* fields) for launches of batch_chunk images.
+static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
+  using namespace cost;
   const int kch = ceil_div(p.d.channels_in, 64);
-#ifdef LCE_STREAM_AUTO_STRIDED   // (A/B aid: strided 3x3 layers of 128 / 256 input channels, any width of output)
-  if ((p.d.stride_height > 1 || p.d.stride_width > 1) && (kch == 2 || kch == 4) && p.d.channels_out >= 128) return true;
-#endif
-#ifdef LCE_STREAM_AUTO_LOWK      // (A/B aid: int8 layers of 64 / 128 input channels, whatever outputs are asked for)
-  if ((kch == 1 || kch == 2) && p.d.dst_type == LCE_HIP_I8 && p.d.channels_out >= 64) return true;
-#endif
-  // 64 / 128 input channels (18 / 36 MFMAs per pixel block: the epilogue is exposed).  Since the first block step takes its weights as
-  // they arrive (round 4) the streaming kernel is ahead of the block GEMM on these layers in some cases (batch 256, two boxes,
-  // profiles/r04/low_k_on_the_streaming_kernel.txt; us, streaming kernel vs block GEMM):
-  //   int8 WITHOUT the second output: 56x56x64 28.2 vs 30.1, 28x28x128 19.8 vs 22.0, stride 2: 19.1 vs 22.2 and 12.8 vs 14.8; WITH it the sign
-  //     gather costs the one-wave-per-SIMD kernel 5-10 us, the block GEMM 2-5: behind or level (37.9 vs 35.0, 24.6 vs 24.2) -> only without;
-  //   float, stride 2: 24.6 vs 26.4 and 15.0 vs 18.1 (with the second output 24.8 vs 28.6, 15.4 vs 18.3) -> both ways;
-  //   float 28x28x128: 25.4 vs 25.8, with the second output 26.1 vs 28.2 -> both ways;
-  //   float 56x56x64 (store-bound): 35.9 vs 39.9 on one box, 45.5 vs 40.0 on the next (one block per image, row by row: the store
-  //     pattern whose rate is a property of the box) -> not taken; bitpacked output: a tie -> not taken;
-  //   images wider than 64 pixels (112 / 224): 5-15 % behind the block GEMM's strips / 2-D tiles -> not taken.
-  // Later in round 4 the ballots of the second / bitpacked output lost their padding nops (lce_kernels_stream.h, kPipeBallots) and the picture
-  // changed (one box, profiles/r04/ballots_one_kstep_late.txt, us, streaming kernel vs block GEMM): int8 WITH the second output 22.9 vs 24.3
-  // (28x28x128), 34.2 vs 34.7 (56x56x64), stride 2: 22.8 vs 25.0 and 14.9 vs 16.2 -> int8 both ways; bitpacked output, stride 1: 16.1 vs 17.5
-  // and 21.8 vs 23.9, stride 2 (tools/strided_bp_check.py): 15.5 vs 18.3 (56x56x64 -> 128) and 10.8 vs 12.2 (28x28x128 -> 256) -> taken.
-  (void)want_sign;     // (no layer's answer depends on it any more; the C ABI's twin plan for run_dual stays for rules that do)
-  if ((kch == 1 || kch == 2) && p.d.channels_out >= 64 && p.d.in_width <= 64) {
-    const bool strided = p.d.stride_height > 1 || p.d.stride_width > 1;
-    if (p.d.dst_type == LCE_HIP_I8) return true;
-    if (p.d.dst_type == LCE_HIP_BITPACKED) return true;
-    if (p.d.dst_type == LCE_HIP_F32 && (strided || kch == 2)) return true;
+  const bool ksplit = stream_ksplit(p);
+  const double bank_kib = ksplit ? 288.0 : 72.0 * kch;                       // 4 waves x K-steps x 2 fragments x 1 KiB
+  const int64_t blocks = (int64_t)p.st_gx * p.st_ny, cus = std::max(1, p.num_cus);
+  const double bank_us = std::max(bank_kib * 1024.0 / kVmemBytesPerClk / kCyclesPerUs, (double)std::min(blocks, cus) * bank_kib * 1024.0 / kL2BytesPerUs);
+  const double prologue_us = 0.9 + bank_us + (ksplit ? 0.45 : 0.0);
+  const double mfma_us = (ksplit ? 72.0 : 18.0 * kch) * kMfmaCycles / kCyclesPerUs;    // per block step and wave
+  const int64_t usteps = ((int64_t)p.st_nq + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
+  const double step_us = std::max(step_factor(p.d.dst_type, usteps, ksplit) * mfma_us, epilogue_us_per_step(p.d.dst_type)) + (ksplit ? 0.08 : 0.0);
+  const int64_t rounds = (blocks + cus - 1) / cus;
+  // the ring's production: one quota of 256 items rides free per tile step, the rest is handled out of line
+  const double quotas = (double)p.st_spb * p.st_srs * p.st_ipr / 256.0, tiles = std::max<double>(1.0, (double)((usteps + 3) / 4));
+  const double production_us = std::max(0.0, quotas - tiles) * 0.12;
+  // a segment whose pixels do not fill its last 32-pixel block stores that block out of line, row by row
+  const bool ragged = !p.st_flat && (p.st_rs * p.st_wso) % 32 != 0;
+  const double partial_us = ragged ? (ksplit ? 0.2 : 0.35) * p.st_spb / (double)(1 << p.st_pph_log) : 0.0;
+  const double block_us = prologue_us + usteps * step_us + production_us + partial_us + 0.5;
+  const double compute_us = kLaunchUs + rounds * block_us;
+  // nothing is written before the first block step is over; from then on the chip's write rate for the pattern bounds the launch
+  // (interleaved runs: the launch writes gstr consecutive segments at a time -- the more compact that window, the closer to the
+  //  rate of one sequential stream; whole images per block: 256 streams megabytes apart)
+  double bytes_per_us = store_bytes_per_us(p.d.dst_type, false);
+  if (p.st_gstr > 1 && p.d.dst_type == LCE_HIP_F32) {
+    const double window = (double)p.st_gstr * p.st_rs * p.st_wso * stream_row_bytes(p);
+    bytes_per_us += 0.6e6 * std::min(1.0, std::max(0.0, (64.0e6 - window) / 48.0e6));
   }
-  if (kch == 8) return p.d.channels_out >= 128;
-  return kch == 4 && p.d.channels_out >= 192 && p.d.channels_out <= 256;
+  const double store_us = kLaunchUs + prologue_us + step_us + (double)out_bytes_of(p, batch_chunk) / bytes_per_us;
+  if (getenv("LCE_PLAN_DEBUG") && getenv("LCE_PLAN_DEBUG")[0] == '2')
+    fprintf(stderr, "[lce plan]   rows %d il %d: blocks %lld usteps %lld prologue %.2f step %.2f production %.2f partial %.2f compute %.2f store %.2f\n", p.st_rs, p.st_gstr > 1,
+            (long long)blocks, (long long)usteps, prologue_us, step_us, production_us, partial_us, compute_us, store_us);
+  return std::max(compute_us, store_us);
 }
-// true when the auto rule above answers differently for the two kinds of call (with / without the second output): the C ABI then keeps
-// one selection per kind (lce_hip_api.hip, run_dual), so a plan that is driven both ways never re-plans or re-uploads
-bool auto_choice_depends_on_second_output(const HostPlan& p) {
-  if (p.engine_pref != 0 || p.kernel_pref != 0 || p.tile_pref.tm != 0) return false;
-  return stream_candidate(p, false) != stream_candidate(p, true);
+
+// The weight-streaming kernel as plan_wstream has just planned it (ws_* fields).
+static double estimate_wstream_us(const HostPlan& p, int batch_chunk) {
+  using namespace cost;
+  const int kch = ceil_div(p.d.channels_in, 64), ks = 9 * kch, cus = std::max(1, p.num_cus);
+  const int groups = ceil_div(batch_chunk, p.ws_ipb);
+  // blocks are dispatched in index order (part-major), round-robin over the CUs: pixel blocks on the busiest CU
+  std::vector<int64_t> load(cus, 0);
+  int64_t b = 0, worst = 0;
+  int last_nb = 0;
+  for (int y = 0; y < p.ws_ny; ++y)
+    for (int part = 0; part < p.ws_parts; ++part)
+      for (int g = 0; g < groups; ++g, ++b) {
+        const int nb = p.ws_nq / p.ws_parts + (part < p.ws_nq % p.ws_parts ? 1 : 0);
+        load[b % cus] += nb;
+        worst = std::max(worst, load[b % cus]);
+        last_nb = nb;
+      }
+  const int64_t rounds = (b + (int64_t)cus * p.ws_occupancy - 1) / ((int64_t)cus * p.ws_occupancy);
+  const double crowd = std::min(1.0, (double)b / (2.0 * cus));                 // 0: blocks alone on their CUs ... 1: two per CU
+  const int items_per_lane = ceil_div(p.ws_ipb * p.ws_hp * p.ws_wp * p.ws_qg, 256);
+  const double prologue_us = (3400.0 + 600.0 * items_per_lane) / kCyclesPerUs + 0.6 * crowd;
+  // the K loops at the matrix cores' rate -- or at the rate the L2s deliver the launch's weight streams (every block pulls the
+  // whole image of its 256 channels: ks x 8 KiB)
+  const double kloop_us = std::max((double)worst * ks * 2 * (kMfmaCycles + 0.8 + 2.0 * crowd) / kCyclesPerUs, (double)b * ks * 8192.0 / kL2BytesPerUs);
+  // K-major: a block's outputs all come at its end.  int8 / bitpacked: the transform of its pixel blocks (beside the co-resident
+  // block's); float: the stores of (most of) the launch, which the chip writes at its own rate behind the K loops
+  double tail_us;
+  if (p.d.dst_type == LCE_HIP_F32) tail_us = std::max(0.5 * last_nb, 0.8 * (double)out_bytes_of(p, batch_chunk) / 5.0e6);
+  else tail_us = (p.d.dst_type == LCE_HIP_I8 ? 0.5 + 0.45 * crowd : 0.15) * last_nb;
+  return kLaunchUs + rounds * prologue_us + (p.ws_occupancy < 2 ? 1.15 : 1.0) * kloop_us + tail_us;
 }
-static bool stream_worthwhile(const HostPlan& p) {
-  const int cus = std::max(1, p.num_cus / p.st_ny);
-  const int64_t steps = ((int64_t)p.st_nq + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
-  // (segments of fewer than 4 rows re-expand their halo rows more than 1.5 times: left to the block GEMM)
-#ifndef LCE_STREAM_MIN_STEPS
-#define LCE_STREAM_MIN_STEPS 6
-#endif
-  // (512 input channels: the block GEMM is bound by its LDS traffic there -- 1 KiB of fragment reads per MFMA -- and loses even on
-  //  the shortest launches: 7x7x512 stride 2, two block steps per block, 9.8 vs 17.9 us, profiles/r04/ksplit_vs_block_gemm.txt)
-  const int64_t min_steps = stream_ksplit(p) ? 2 : LCE_STREAM_MIN_STEPS;
-  return p.st_gx * 4 >= cus * 3 && steps >= min_steps && (p.st_rs >= 4 || p.st_rs == p.out_h);
+
+// The block GEMM (direct or workspace variant, whichever select_kernel would take): K-steps at the LDS port's rate, two blocks
+// per CU that slow each other down, the output at the chip's write rate for block tiles.
+static double estimate_block_gemm_us(const HostPlan& p, int64_t pixels) {
+  using namespace cost;
+  const MfmaCfg c = choose_mfma_cfg(p, pixels);
+  const int64_t blocks = ((pixels + c.bm() - 1) / c.bm()) * ceil_div(p.d.channels_out, c.bn()), cus = std::max(1, p.num_cus);
+  const int ks = p.d.filter_height * p.d.filter_width * ceil_div(p.d.channels_in / std::max(1, p.d.groups), 64);
+  const double dst_f = p.d.dst_type == LCE_HIP_F32 ? 1.0 : p.d.dst_type == LCE_HIP_I8 ? 0.94 : 0.78;
+  const double area = (double)c.bm() * c.bn() / (128.0 * 128.0);
+  // a block alone on its CU runs at the latency of its K-steps (0.138 us each for 128 x 128; a smaller tile's are no shorter);
+  // a launch of many rounds at the matrix cores' / the LDS port's throughput, where the cheaper epilogues show
+  const double alone_us = (3.4 + (0.4 + 0.138 * ks) * std::max(1.0, area)) * (p.d.dst_type == LCE_HIP_BITPACKED ? 0.93 : 1.0);
+  const double round_us = (1.6 + (1.6 + 0.14 * ks) * area) * dst_f;
+  double compute_us;
+  if (blocks <= cus) compute_us = alone_us;
+  else if (blocks <= 2 * cus) compute_us = alone_us * (1.0 + 0.33 * (double)(blocks - cus) / cus);
+  else compute_us = std::max(1.33 * alone_us, 1.33 * round_us * ((double)blocks / (2.0 * cus) + 0.35));
+  const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
+  const double store_us = 3.0 + (double)out_bytes_of(p, batch_chunk) / 5.5e6;
+  return kLaunchUs + std::max(compute_us, store_us);
 }
+
+// the streaming kernel's candidates: the planner's own segments, then interleaved runs of r-row segments
+struct StreamCandidate { int rows, interleave; double us; };
 
 // plan_wstream succeeded: the plan runs the weight-streaming kernel
 static void use_wstream_plan(HostPlan& p) {
@@ -1132,12 +1197,64 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     use_wstream_plan(p);
     return "";
   }
-  p.use_stream = false;
-  if (p.engine_pref == 5 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 && stream_candidate(p, p.want_sign))) {
-    // weight-stationary streaming kernel: the planner's FP4 weight image with 64-channel granularity
+  const bool auto_rule = p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0;
+  bool gemm_by_estimate = false;      // the block GEMM was priced cheapest among the matrix-core kernels: not the xor-popcount engine then
+  if ((p.engine_pref == 5 || auto_rule) && stream_supported(p)) {
+    // The streaming family: every candidate is planned and priced (estimate_*_us above); the cheapest runs.  engine=stream
+    // restricts the choice to the weight-stationary kernel's own variants; stream_rows / stream_interleave pin theirs.
     const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
-    const std::string err = plan_stream(p, batch_chunk);
-    if (err.empty() && (p.engine_pref == 5 || stream_worthwhile(p))) {
+    const int rows_pref = p.stream_rows_pref, il_pref = p.stream_interleave_pref;
+    std::vector<StreamCandidate> cands;
+    if (il_pref <= 0) cands.push_back(StreamCandidate{rows_pref, 0, 0.0});
+    if (il_pref != 0)
+      for (int r = p.out_h - 1; r >= 2; --r) {
+        if (p.out_h % r != 0 || (rows_pref != 0 && rows_pref != r)) continue;
+        // (segments that would leave more than 15 % of their last pixel block empty are not worth pricing: every block of
+        //  such a run pays the padded matrix work and the out-of-line stores)
+        const int px = r * p.out_w;
+        if (rows_pref == 0 && ceil_div(px, 32) * 32 * 100 > px * 115) continue;
+        cands.push_back(StreamCandidate{r, 1, 0.0});
+      }
+    if (il_pref == 1 && cands.empty()) cands.push_back(StreamCandidate{rows_pref, 1, 0.0});   // (nothing to interleave: one segment per image)
+    int best = -1;
+    std::string first_err;
+    for (size_t i = 0; i < cands.size(); ++i) {
+      p.stream_rows_pref = cands[i].rows;
+      p.stream_interleave_pref = cands[i].interleave;
+      const std::string err = plan_stream(p, batch_chunk);
+      if (!err.empty()) { if (first_err.empty()) first_err = err; cands[i].us = -1.0; continue; }
+      if (cands[i].interleave && p.st_gstr <= 1) { cands[i].us = -1.0; continue; }      // (one segment per block: the same plan as without)
+      cands[i].us = estimate_stream_us(p, batch_chunk);
+      if (best < 0 || cands[i].us < cands[best].us) best = (int)i;
+    }
+    p.stream_rows_pref = rows_pref;
+    p.stream_interleave_pref = il_pref;
+    double best_us = best >= 0 ? cands[best].us : 1e30;
+    bool take_wstream = false;
+    const bool debug = getenv("LCE_PLAN_DEBUG") != nullptr;      // (the estimates of every candidate, on stderr: tools/planner_regret.py)
+    if (debug)
+      for (const StreamCandidate& c : cands) fprintf(stderr, "[lce plan] stream rows=%d il=%d: %.2f us\n", c.rows, c.interleave, c.us);
+    if (auto_rule) {
+      if (wstream_supported(p) && plan_wstream(p, batch_chunk).empty()) {
+        const double us = estimate_wstream_us(p, batch_chunk);
+        if (debug) fprintf(stderr, "[lce plan] wstream images=%d blocks=%d: %.2f us\n", p.ws_ipb, p.ws_nb, us);
+        if (us < best_us) { best_us = us; take_wstream = true; }
+      }
+      const double gemm_us = estimate_block_gemm_us(p, pixels);
+      if (debug) fprintf(stderr, "[lce plan] block GEMM: %.2f us\n", gemm_us);
+      if (gemm_us < best_us) { best = -1; take_wstream = false; best_us = -1.0; gemm_by_estimate = true; }   // the block GEMM, below
+    }
+    if (take_wstream) {
+      use_wstream_plan(p);
+      return "";
+    }
+    if (best >= 0 && best_us >= 0.0) {
+      p.stream_rows_pref = cands[best].rows;
+      p.stream_interleave_pref = cands[best].interleave;
+      const std::string err = plan_stream(p, batch_chunk);
+      p.stream_rows_pref = rows_pref;
+      p.stream_interleave_pref = il_pref;
+      if (!err.empty()) return err;     // (cannot happen: the same plan succeeded a moment ago)
       const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
       const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0;
       p.wq_layout = 0;
@@ -1159,10 +1276,12 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
       p.kernel_name = nm;
       return "";
     }
-    if (p.engine_pref == 5) return err;
+    if (p.engine_pref == 5) return first_err.empty() ? std::string("bconv2d: the streaming kernel cannot run this launch") : first_err;
+  } else if (p.engine_pref == 5) {
+    return plan_stream(p, 1);      // (the message that says why)
   }
   if (p.engine_pref >= 2 || (p.engine_pref == 0 && p.kernel_pref == 0 && p.tile_pref.tm == 0 &&
-                             mfma_supported(p) && pixels * d.channels_out >= (1 << 16))) {
+                             mfma_supported(p) && (gemm_by_estimate || pixels * d.channels_out >= (1 << 16)))) {
     p.use_mfma = true;
     p.use_tiled = false;
     MfmaCfg want = choose_mfma_cfg(p, pixels);

@@ -100,7 +100,7 @@ struct HostPlan {
   int st_pitch = 0;                          // bytes per ring row slot
   int st_nstrip = 1, st_rseg = 0, st_wso = 0;   // column strips of wide images: strips per image, row segments per image, output columns per strip
   int stream_strip_pref = -1;                // testing aid: -1 auto, 0 never, else the strip width (a multiple of 32 that divides the output width)
-  int stream_interleave_pref = 0;            // 1: a block's segments are gx apart (interleaved runs: a compact, moving write window), 0: consecutive
+  int stream_interleave_pref = -1;           // 1: a block's segments are gx apart (interleaved runs: a compact, moving write window), 0: consecutive, -1: the cost estimate decides
   int st_gstr = 1;                           // the planned segment stride of a block's run (1: consecutive segments)
   int st_flat = 0;                           // 1: 32-pixel blocks are cut from the concatenated pixels of a block's segments (whole small images)
   int st_nq = 0;                             // pixel blocks of a full block's stream (rows of the context table)
@@ -141,7 +141,6 @@ bool tiled_supports(const HostPlan& p, int tn);
 // Choose kernel + tile for `pixels` output pixels per launch and (re)build the packed
 // operands.  Returns "" or an error message (e.g. a forced variant that cannot run).
 std::string select_kernel(HostPlan& p, int64_t pixels);
-bool auto_choice_depends_on_second_output(const HostPlan& p);   // lce_plan.cpp, behind stream_candidate
 
 // Largest batch chunk one launch may take (buffer resources bind < 2 GiB).
 int max_batch_per_launch(const HostPlan& p);

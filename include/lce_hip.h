@@ -200,8 +200,8 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
                                                const char* value);
 /* Name of the kernel variant the next run will launch (static string owned by the plan). */
 const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan);
-/* The same for lce_hip_bconv2d_run_dual: on a few layers (int8 output, 64 / 128 input channels) the best kernel depends on
- * whether the call asks for the second output, and the plan keeps one selection for each kind of call. */
+/* The same for lce_hip_bconv2d_run_dual.  Since round 5 the choice does not depend on the kind of call (one selection per plan):
+ * kept for callers of round 4's ABI, returns what lce_hip_bconv2d_plan_kernel_name returns. */
 const char* lce_hip_bconv2d_plan_kernel_name_dual(lce_hip_bconv2d_plan* plan);
 
 /* Replaces bconv2d::Eval (bconv2d.cc:550-564) -> BConv2DReference /
