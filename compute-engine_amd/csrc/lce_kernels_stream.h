@@ -34,22 +34,9 @@
 #include "lce_kernel_args.h"
 #include "lce_kernels.h"
 #include "lce_kernels_mfma.h"
+#include "lce_stream_stamps.h"
 
 namespace lce {
-
-#ifdef LCE_STREAM_PHASES
-// Profiling aid (never defined in the product build): wave 0 of every block stamps s_memtime at entry, first rows
-// resident, and after every tile step (up to 60), the last slot at exit.
-__device__ unsigned long long lce_stream_tl[512 * 64];
-#define LCE_SPH(slot)                                                                               \
-  do {                                                                                              \
-    const int sph_b = block_idx_y() * grid_dim_x() + block_idx_x();                                 \
-    if (thread_idx_x() == 0 && sph_b < 512 && (slot) < 64)                                          \
-      lce_stream_tl[sph_b * 64 + (slot)] = __builtin_readcyclecounter();                            \
-  } while (0)
-#else
-#define LCE_SPH(slot) do {} while (0)
-#endif
 
 // Dword DD of fp4_of_full_word (lce_kernels_mfma.h): byte DD of the word as eight FP4 codes, 4 VALU.
 template <int DD>

@@ -30,13 +30,7 @@
 #include "lce_kernel_args.h"
 #include "lce_kernels.h"
 #include "lce_kernels_mfma.h"
-#ifdef LCE_STREAM_PHASES
-#include "lce_kernels_stream.h"     // (profiling builds: the streaming kernel's per-block time stamps, LCE_SPH)
-#else
-#ifndef LCE_SPH
-#define LCE_SPH(slot) do {} while (0)
-#endif
-#endif
+#include "lce_stream_stamps.h"
 
 namespace lce {
 

@@ -1068,7 +1068,7 @@ static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
   const double bank_kib = ksplit ? 288.0 : 72.0 * kch;                       // 4 waves x K-steps x 2 fragments x 1 KiB
   const int64_t blocks = (int64_t)p.st_gx * p.st_ny, cus = std::max(1, p.num_cus);
   const double bank_us = std::max(bank_kib * 1024.0 / kVmemBytesPerClk / kCyclesPerUs, (double)std::min(blocks, cus) * bank_kib * 1024.0 / kL2BytesPerUs);
-  const double prologue_us = 0.9 + bank_us + (ksplit ? 0.45 : 0.0);
+  const double prologue_us = 0.9 + bank_us + (ksplit ? 0.1 : 0.0);
   const double mfma_us = (ksplit ? 72.0 : 18.0 * kch) * kMfmaCycles / kCyclesPerUs;    // per block step and wave
   const int64_t usteps = ((int64_t)p.st_nq + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
   const double step_us = std::max(step_factor(p.d.dst_type, usteps, ksplit) * mfma_us, epilogue_us_per_step(p.d.dst_type)) + (ksplit ? 0.08 : 0.0);
@@ -1078,16 +1078,21 @@ static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
   const double production_us = std::max(0.0, quotas - tiles) * 0.12;
   // a segment whose pixels do not fill its last 32-pixel block stores that block out of line, row by row
   const bool ragged = !p.st_flat && (p.st_rs * p.st_wso) % 32 != 0;
-  const double partial_us = ragged ? (ksplit ? 0.2 : 0.35) * p.st_spb / (double)(1 << p.st_pph_log) : 0.0;
+  const double partial_us = ragged ? (ksplit ? 0.12 : 0.2) * p.st_spb / (double)(1 << p.st_pph_log) : 0.0;
   const double block_us = prologue_us + usteps * step_us + production_us + partial_us + 0.5;
   const double compute_us = kLaunchUs + rounds * block_us;
   // nothing is written before the first block step is over; from then on the chip's write rate for the pattern bounds the launch
   // (interleaved runs: the launch writes gstr consecutive segments at a time -- the more compact that window, the closer to the
   //  rate of one sequential stream; whole images per block: 256 streams megabytes apart)
   double bytes_per_us = store_bytes_per_us(p.d.dst_type, false);
-  if (p.st_gstr > 1 && p.d.dst_type == LCE_HIP_F32) {
-    const double window = (double)p.st_gstr * p.st_rs * p.st_wso * stream_row_bytes(p);
-    bytes_per_us += 0.6e6 * std::min(1.0, std::max(0.0, (64.0e6 - window) / 48.0e6));
+  if (p.d.dst_type == LCE_HIP_F32) {
+    // (float rows: 5.0 TB/s on launches of >= 205 MB -- the power budget is shared with the matrix cores -- up to 5.65 on <= 51 MB)
+    const double mb = (double)out_bytes_of(p, batch_chunk) / 1.0e6;
+    bytes_per_us = 5.0e6 + 0.65e6 * std::min(1.0, std::max(0.0, (205.0 - mb) / 154.0));
+    // the window the launch's blocks write into at any moment: gstr consecutive segments (interleaved runs), else every block's own
+    // run -- the whole output
+    const double window = p.st_gstr > 1 ? (double)p.st_gstr * p.st_rs * p.st_wso * stream_row_bytes(p) : (double)out_bytes_of(p, batch_chunk);
+    bytes_per_us += 0.42e6 * std::min(1.0, std::max(0.0, (64.0e6 - window) / 48.0e6));
   }
   const double store_us = kLaunchUs + prologue_us + step_us + (double)out_bytes_of(p, batch_chunk) / bytes_per_us;
   if (getenv("LCE_PLAN_DEBUG") && getenv("LCE_PLAN_DEBUG")[0] == '2')
@@ -1119,7 +1124,9 @@ static double estimate_wstream_us(const HostPlan& p, int batch_chunk) {
   const double prologue_us = (3400.0 + 600.0 * items_per_lane) / kCyclesPerUs + 0.6 * crowd;
   // the K loops at the matrix cores' rate -- or at the rate the L2s deliver the launch's weight streams (every block pulls the
   // whole image of its 256 channels: ks x 8 KiB)
-  const double kloop_us = std::max((double)worst * ks * 2 * (kMfmaCycles + 0.8 + 2.0 * crowd) / kCyclesPerUs, (double)b * ks * 8192.0 / kL2BytesPerUs);
+  // ... or, with one or two pixel blocks per block, at the latency of the weight loads (kWsPrefetch K-steps in flight)
+  const double kloop_us = std::max(std::max((double)worst * ks * 2 * (kMfmaCycles + 0.8 + 2.0 * crowd) / kCyclesPerUs, (double)b * ks * 8192.0 / kL2BytesPerUs),
+                                   0.055 * ks);
   // K-major: a block's outputs all come at its end.  int8 / bitpacked: the transform of its pixel blocks (beside the co-resident
   // block's); float: the stores of (most of) the launch, which the chip writes at its own rate behind the K loops
   double tail_us;
@@ -1146,7 +1153,7 @@ static double estimate_block_gemm_us(const HostPlan& p, int64_t pixels) {
   else if (blocks <= 2 * cus) compute_us = alone_us * (1.0 + 0.33 * (double)(blocks - cus) / cus);
   else compute_us = std::max(1.33 * alone_us, 1.33 * round_us * ((double)blocks / (2.0 * cus) + 0.35));
   const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
-  const double store_us = 3.0 + (double)out_bytes_of(p, batch_chunk) / 5.5e6;
+  const double store_us = 2.4 + (double)out_bytes_of(p, batch_chunk) / 5.75e6;
   return kLaunchUs + std::max(compute_us, store_us);
 }
 

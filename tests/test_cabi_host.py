@@ -133,10 +133,10 @@ def test_kernel_selection_is_host_side_and_named():
     # 2048 input channels: the LDS halo of any tile is too big -> workspace GEMM
     deep = amd.Bconv2dPlan(amd.ConvParams(8, 28, 28, 2048, 3, 3, 256, padding=amd.PADDING_SAME, pad_values=1))
     assert deep.kernel_name().startswith("bconv2d_mfma<f32,")
-    # 128 input channels, float, batch 256: the streaming kernel since round 4 (it was behind the block GEMM before the first block step
-    # took its weights as they arrive); the block GEMM when asked for
+    # 128 input channels, float, batch 256: float rows of a low-K layer are store-bound -- interleaved runs of 4-row segments write one
+    # compact window (round 5); the block GEMM when asked for
     mid = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1))
-    assert mid.kernel_name() == "bconv2d_stream<f32,3x3x128,rows28>"
+    assert mid.kernel_name() == "bconv2d_stream<f32,3x3x128,rows4,il>"
     mid.set_option("engine", "direct")
     assert mid.kernel_name() == "bconv2d_mfma_direct<f32,128x128>"
     midb = amd.Bconv2dPlan(amd.ConvParams(256, 28, 28, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1, dst_type=amd.BITPACKED))
@@ -184,10 +184,11 @@ def test_empty_batch_is_legal_and_a_no_op():
 @pytest.mark.parametrize("hw,c,dst,want", [
     (56, 256, "F32", "bconv2d_stream<f32,3x3x256,rows56>"),         # BASELINE L0: the weight-stationary streaming kernel,
     (56, 256, "I8", "bconv2d_stream<i8,3x3x256,rows56>"),           # one image per block (round 3; profiles/r03/)
-    (14, 256, "I8", "bconv2d_stream<i8,3x3x256,rows14>"),
+    (14, 256, "I8", "bconv2d_wstream<i8,3x3x256,images1,blocks4>"),   # round 5: weights streamed, activations stationary (store-light single-round layers)
+    (14, 256, "BITPACKED", "bconv2d_wstream<bitpacked,3x3x256,images1,blocks4>"),
     (56, 256, "BITPACKED", "bconv2d_stream<bitpacked,3x3x256,rows56>"),
     (56, 64, "F32", "bconv2d_mfma_direct<f32,256x64>"),            # QuickNet stages
-    (28, 128, "F32", "bconv2d_stream<f32,3x3x128,rows28>"),        # round 4 (profiles/r04/low_k_on_the_streaming_kernel.txt)
+    (28, 128, "F32", "bconv2d_stream<f32,3x3x128,rows4,il>"),      # round 5: interleaved runs (profiles/r05/interleaved_runs.txt)
     (56, 64, "I8", "bconv2d_stream<i8,3x3x64,rows56>"),            # int8: with and without the second output
     (28, 128, "BITPACKED", "bconv2d_stream<bitpacked,3x3x128,rows28>"),   # since the ballots lost their padding
     (14, 256, "F32", "bconv2d_stream<f32,3x3x256,rows14>"),
@@ -195,16 +196,16 @@ def test_empty_batch_is_legal_and_a_no_op():
     (7, 512, "I8", "bconv2d_stream<i8,3x3x512,rows7>"),
 ])
 def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
-    """The auto rule is tuned on measurements (profiles/r01/tile_sweep_v8.jsonl, profiles/r03/stream_vs_block_gemm.txt, profiles/r04/ksplit_vs_block_gemm.txt); this pins what it
-    picks for the BASELINE.json layers at batch 256 so that a planner edit shows up as a diff."""
+    """The planner prices every candidate kernel (csrc/lce_plan.cpp, estimate_*_us; calibrated on profiles/r05/engine_sweep_box*.jsonl, held to the
+    measured best by tests/test_planner_choice.py); this pins what it picks for the BASELINE.json layers at batch 256 so that a planner edit shows
+    up as a diff."""
     p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=getattr(amd, dst))
     assert amd.Bconv2dPlan(p).kernel_name() == want
 
 
 def test_planner_choice_for_run_dual():
-    """lce_hip_bconv2d_plan_kernel_name_dual names the kernel run_dual launches.  The C ABI keeps one selection per kind of call
-    where the auto rule depends on the second output (a twin plan, lce_hip_api.hip); since the ballots of the second output lost
-    their padding the streaming kernel wins both ways on every measured layer, so the two names agree."""
+    """lce_hip_bconv2d_plan_kernel_name_dual names the kernel run_dual launches: since round 5 the same kernel as run's (the cost
+    estimate does not depend on the kind of call; round 4's twin plan is gone)."""
     for hw, c, dst in ((56, 64, amd.I8), (28, 128, amd.I8), (28, 128, amd.F32), (56, 256, amd.F32)):
         p = amd.ConvParams(256, hw, hw, c, 3, 3, c, padding=amd.PADDING_SAME, pad_values=1, dst_type=dst)
         plan = amd.Bconv2dPlan(p)
@@ -221,7 +222,11 @@ def test_planner_fallbacks():
         return amd.Bconv2dPlan(amd.ConvParams(**base)).kernel_name()
     assert name(groups=2) == "bconv2d_mfma_direct<f32,256x64>"         # grouped, 64 channels per group: one group per block
     assert name(groups=4).startswith("bconv2d_tiled<")                 # 32 channels per group: xor-popcount engine
-    assert name(batch=1, in_height=4, in_width=4, channels_out=8).startswith("bconv2d_tiled<")   # too small for the matrix cores
+    # a launch of sixteen pixels: round 4 sent it to the xor-popcount engine; any launch the streaming family can run is priced now,
+    # and one block of the weight-streaming kernel is the cheapest (batch-1 rows of profiles/r05/engine_sweep_box1.jsonl)
+    assert name(batch=1, in_height=4, in_width=4, channels_out=8).startswith("bconv2d_wstream<")
+    assert name(batch=1, in_height=4, in_width=4, channels_in=32, channels_out=8).startswith("bconv2d_stream<")   # (32 channels pad to one 64-channel chunk)
+    assert name(batch=1, in_height=8, in_width=8, filter_height=5, filter_width=5, channels_out=8).startswith("bconv2d_tiled<")   # 5x5, tiny: still the xor-popcount engine
     assert name(channels_in=2048, batch=8).startswith("bconv2d_mfma<")  # LDS halo too large: workspace GEMM
     # 13x13 outputs: a 128-pixel tile would be 34 % padding -> workspace GEMM (tiles span images)
     assert name(channels_in=100, channels_out=33, stride_height=2, stride_width=2).startswith("bconv2d_mfma<")

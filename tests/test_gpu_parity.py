@@ -194,6 +194,23 @@ def test_conv_reference_grid(case):
         _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF)
 
 
+@pytest.mark.parametrize("case", GRID, ids=_id)
+def test_conv_reference_grid_planners_own_choice(case):
+    """The same grid with engine=auto (round-4 review): whatever the planner's cost estimate picks for each case -- the
+    weight-stationary / weight-streaming kernels, the block GEMM, the xor-popcount engine -- against the oracle, all three
+    output types, both semantics.  (The grid's tiny launches are exactly where round 5's rule differs most from round 4's.)"""
+    inp, flt, g, st, dil, pad, act = case
+    for sem in (O.SEM_REFERENCE, O.SEM_OPTIMIZED):
+        if not legal(inp, flt, g, pad, sem):
+            continue
+        padding, pv = PADS[pad]
+        spec = O.ConvSpec(inp[0], inp[1], inp[2], inp[3], flt[0], flt[1], flt[2], g, st[0], st[1],
+                          dil[0], dil[1], padding, pv, act, sem)
+        if spec.out_h <= 0 or spec.out_w <= 0:
+            continue
+        _check_all_dst(spec, zlib.crc32(_id(case).encode()) & 0xFFFF, engine="auto")
+
+
 @pytest.mark.parametrize("engine", ["mfma", "direct"])
 @pytest.mark.parametrize("case", [c for c in GRID if c[2] == 1], ids=_id)
 def test_conv_reference_grid_mfma_engine(case, engine):

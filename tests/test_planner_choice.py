@@ -1,0 +1,50 @@
+"""The planner's choice against the measured sweep of every candidate kernel (round-4 review, item 5).
+
+profiles/r05/engine_sweep_box*.jsonl (tools/engine_sweep.py, one GPU box each): for the QuickNet / Bi-RealNet 3x3 layers -- stride 1
+and the stride-2 layers of config 5 -- at batch 1, 16, 64 and 256 and the three output types, the time of every kernel the planner can
+choose between (block GEMM direct / workspace, the weight-stationary streaming kernel with whole-image and interleaved r-row segments,
+the weight-streaming kernel).  The kernel `auto` picks on the HOST (no GPU needed: selection is host-side) must be within 5 % of the
+best candidate's time, times averaged over the boxes.  Round 4's decision list is at 20 - 640 % on 128 of the 192 rows of box 1."""
+import glob
+import importlib
+import json
+import os
+
+import pytest
+
+amd = importlib.import_module("compute-engine_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAYERS = {(56, 64, 64, 1), (28, 128, 128, 1), (14, 256, 256, 1), (7, 512, 512, 1), (56, 256, 256, 1),
+          (56, 64, 128, 2), (28, 128, 256, 2), (14, 256, 512, 2), (7, 512, 512, 2)}
+
+
+def _table():
+    """{(hw, cin, cout, stride, batch, dst): {kernel name: mean us over the boxes that measured it}}"""
+    acc = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "engine_sweep_box*.jsonl"))):
+        for line in open(path):
+            r = json.loads(line)
+            key = (r["hw"], r["cin"], r["cout"], r["stride"], r["batch"], r["dst"])
+            for cand, name in r["kernel"].items():
+                acc.setdefault(key, {}).setdefault(name, []).append(r["us"][cand])
+    return {k: {n: sum(v) / len(v) for n, v in d.items()} for k, d in acc.items()}
+
+
+TABLE = _table()
+ROWS = sorted(k for k in TABLE if k[:4] in LAYERS)
+
+
+def test_the_sweep_covers_the_grid():
+    assert len(ROWS) == len(LAYERS) * 4 * 3, len(ROWS)
+
+
+@pytest.mark.parametrize("key", ROWS, ids=lambda k: "%dx%dx%d_s%d_b%d_%s" % k)
+def test_auto_is_within_5_percent_of_the_best_measured_candidate(key):
+    hw, cin, cout, stride, batch, dst = key
+    p = amd.ConvParams(batch, hw, hw, cin, 3, 3, cout, stride_height=stride, stride_width=stride, padding=amd.PADDING_SAME,
+                       pad_values=1, dst_type={"f32": amd.F32, "i8": amd.I8, "bp": amd.BITPACKED}[dst], out_scale=0.125, out_zero_point=3)
+    name = amd.Bconv2dPlan(p).kernel_name()
+    times = TABLE[key]
+    assert name in times, "the sweep never measured %s for this row (re-run tools/engine_sweep.py)" % name
+    best = min(times.values())
+    assert times[name] <= 1.05 * best, "%s: %.2f us, best %.2f us (%s)" % (name, times[name], best, min(times, key=times.get))
