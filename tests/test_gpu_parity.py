@@ -312,19 +312,21 @@ def test_conv_grouped_on_the_matrix_cores(cin, cout, groups, engine):
 def test_direct_variant_2d_tiles_on_wide_images(shape):
     """Wide images (the north star's 224x224xC feature maps): the direct variant tiles the output in BM/32 rows x 32
     columns, the halo being the tile's own neighbourhood instead of whole image rows.  All three output types against
-    the oracle, partial tiles at the right / bottom edge, strides, a 5x5 filter, exact SAME-zero padding; the planner
-    picks the variant by itself."""
+    the oracle, partial tiles at the right / bottom edge, strides, a 5x5 filter, exact SAME-zero padding; the block GEMM
+    picks the 2-D variant by itself (engine=direct: since round 5 the planner's cost estimate sends the small ones of these
+    launches to the streaming kernel, which test_conv_reference_grid_planners_own_choice and the stream tests cover)."""
     b, h, w_, cin, cout, k, st, pad = shape
     padding, pv = PADS[pad]
     spec = O.ConvSpec(b, h, w_, cin, k, k, cout, 1, st, st, 1, 1, padding, pv, O.ACT_RELU if pad == "VALID" else O.ACT_NONE,
                       O.SEM_REFERENCE)
-    names = _check_all_dst(spec, h + w_ + cin, engine="auto")
+    names = _check_all_dst(spec, h + w_ + cin, engine="direct")
     assert all(n.startswith("bconv2d_mfma_direct<") and n.endswith("/2d") for n in names), names
     # the float layer's second output from the same tiles
     x, w, mul, bias = synth.conv_inputs(spec, h, negative_mul_fraction=0.3)
     bias = (bias - 0.45 * k * k * cin * np.abs(mul)).astype(np.float32)
     plan = amd.Bconv2dPlan(_params(spec, amd.F32))
     plan.set_weights(w, mul, bias)
+    plan.set_option("engine", "direct")
     y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
     torch.cuda.synchronize()
     assert plan.kernel_name().endswith("/2d")
