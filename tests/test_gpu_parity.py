@@ -1206,7 +1206,7 @@ def test_birealnet_stack_batch256():
     assert all(chain.fed[1:])
     chain.run_chain()
     names = _check_chain(chain, [0, 131, 255], O.DST_I8)
-    assert all(n.startswith(("bconv2d_mfma", "bconv2d_pointwise", "bconv2d_stream")) for n in names), names
+    assert all(n.startswith(("bconv2d_mfma", "bconv2d_pointwise", "bconv2d_stream", "bconv2d_wstream")) for n in names), names
     assert sum(n.startswith("bconv2d_pointwise") for n in names) == 4, names     # the 1x1 layers stream, 512 channels included
 
 

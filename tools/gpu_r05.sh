@@ -116,5 +116,57 @@ sweepq)
   rm -f $OUT/engine_sweep.jsonl
   python tools/engine_sweep.py $OUT/engine_sweep.jsonl --quick 14x256x256 7x512x512 > $OUT/log.txt 2>&1
   ;;
+evidence)
+  # the round's rocprofv3 evidence in one call (as tools/sessions/gpu_evidence_r04.sh): PARTS=1234 selects
+  R=$GRAFT_REPO_ROOT
+  mkdir -p $OUT/layers
+  export TMPDIR=/tmp
+  cd /tmp
+  PARTS=${PARTS:-1234}
+  if [[ $PARTS == *1* ]]; then
+    PARTS=1 bash $R/tools/gpu_profile_round.sh r05_evidence > $OUT/part1.log 2>&1; tail -3 $OUT/part1.log
+  fi
+  if [[ $PARTS == *2* ]]; then
+  one() {  # tag K stride batch steps args...
+    local t=$1 k=$2 st=$3 b=$4 n=$5; shift 5
+    LCE_K=$k LCE_STRIDE=$st timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/layers/$t -o t -- \
+        python $R/tools/run_one.py "$@" $n $b > $OUT/layers/$t.log 2>/dev/null
+    { echo "# $t: run_one.py $* $n $b (filter ${k}x${k}, stride $st) -> HIP events: $(tail -1 $OUT/layers/$t.log)"; python3 $R/tools/steady_stats.py $OUT/layers/$t/t_kernel_trace.csv $n; } | tee -a $OUT/layer_steady_stats.txt
+    rm -rf $OUT/layers/$t
+  }
+  : > $OUT/layer_steady_stats.txt
+  one l0_f32            3 1 256 40  56 256 f32 auto auto
+  one l0_int8           3 1 256 40  56 256 i8  auto auto
+  one l0_bitpacked      3 1 256 40  56 256 bp  auto auto
+  one quicknet_56x64    3 1 256 100 56 64  f32 auto auto
+  one quicknet_28x128   3 1 256 100 28 128 f32 auto auto
+  one quicknet_14x256   3 1 256 200 14 256 f32 auto auto
+  one quicknet_7x512    3 1 256 200 7  512 f32 auto auto
+  one wstream_14x256_i8 3 1 256 200 14 256 i8  auto auto
+  one wstream_14x256_bp 3 1 256 200 14 256 bp  auto auto
+  one wstream_14x256x512_s2_i8 3 2 256 200 14 256x512 i8 auto auto
+  one ksplit_7x512_i8   3 1 256 200 7  512 i8  auto auto
+  one strips_224x256    3 1 16  40  224 256 f32 auto auto
+  one small_batch_14x256_b16 3 1 16 200 14 256 f32 auto auto
+  fi
+  if [[ $PARTS == *3* ]]; then
+  for spec in "pmc_l0_f32 3 1 56 256 f32 256" "pmc_28x128_f32 3 1 28 128 f32 256" "pmc_14x256_i8 3 1 14 256 i8 256" "pmc_7x512_f32 3 1 7 512 f32 256" "pmc_14x256x512_s2_i8 3 2 14 256x512 i8 256"; do
+    set -- $spec
+    LCE_K=$2 LCE_STRIDE=$3 bash $R/tools/gpu_pmc_one.sh r05_evidence/$1 $4 $5 $6 auto auto 20 $7 > $OUT/$1.log 2>&1
+    tail -2 $OUT/$1.log | cut -c1-160
+  done
+  fi
+  if [[ $PARTS == *4* ]]; then
+  cd $R && timeout 900 python bench.py --extra-json $OUT/bench_extra.json > $OUT/bench_default_run.json 2> $OUT/bench_default_run.err
+  timeout 600 python bench.py --spinup-ms 0 --no-extra --no-cpu-baseline > $OUT/bench_no_spinup.json 2> $OUT/bench_no_spinup.err
+  timeout 900 python bench.py --measure-traffic --no-extra --no-cpu-baseline > $OUT/bench_measured_traffic.json 2> $OUT/bench_measured_traffic.err
+  fi
+  du -sh $OUT
+  ;;
+box)
+  # the headline on this box (bench_box_spread.txt: one call per box)
+  python bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+  python -c "import json;d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]);print('ms_per_step %.4f  roofline.frac %.4f  p10/p50/p90 %s  kernel %s' % (d['ms_per_step'], d['roofline']['frac'], d.get('ms_per_step_p10_p50_p90'), d['kernel']))" | tee -a $OUT/line.txt
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
