@@ -423,6 +423,9 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   // column strips of 64 or 32 output columns (round 4; instances exist for the 256-channel bank).
   std::vector<int> widths;
   if (p.stream_strip_pref <= 0) widths.push_back(0);
+  // (a strip width forced on a layer whose bank is not the 256-channel one: say so, instead of "the ring does not fit")
+  if (p.stream_strip_pref > 0 && ceil_div(d.channels_in, 64) != 4)
+    return "bconv2d: stream_strip: column strips exist for the 256-channel filter bank only (193..256 input channels)";
   if (ceil_div(d.channels_in, 64) == 4 && p.stream_strip_pref != 0) {
     if (p.stream_strip_pref > 0) {
       if (p.stream_strip_pref % 32 != 0 || p.out_w % p.stream_strip_pref != 0)
@@ -513,6 +516,8 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
     if (ring + stream_lds_extra(p) > 160 * 1024) continue;
     const int pbs = ceil_div(rs * ow_seg, 32);
+    // (the strips epilogue's out-of-line path does not add the segment's place: a strip is a multiple of 32 columns, so no block is partial)
+    if (strips && (rs * ow_seg) % 32 != 0) continue;
     const int64_t nq = flat ? (spb * (int64_t)rs * p.out_w + 31) / 32 : spb * pbs;
     p.st_flat = flat ? 1 : 0;
     p.st_nq = (int)nq;
@@ -1242,7 +1247,7 @@ std::string select_kernel(HostPlan& p, int64_t pixels) {
     if (debug)
       for (const StreamCandidate& c : cands) fprintf(stderr, "[lce plan] stream rows=%d il=%d: %.2f us\n", c.rows, c.interleave, c.us);
     if (auto_rule) {
-      if (wstream_supported(p) && plan_wstream(p, batch_chunk).empty()) {
+      if (wstream_supported(p) && !getenv("LCE_PLAN_NO_WSTREAM") && plan_wstream(p, batch_chunk).empty()) {   // (the variable: an A/B aid, as LCE_PLAN_DEBUG)
         const double us = estimate_wstream_us(p, batch_chunk);
         if (debug) fprintf(stderr, "[lce plan] wstream images=%d blocks=%d: %.2f us\n", p.ws_ipb, p.ws_nb, us);
         if (us < best_us) { best_us = us; take_wstream = true; }

@@ -185,7 +185,17 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *              expands its own input halo into LDS; what "auto" picks whenever it fits) | "pointwise" (1x1
  *              ungrouped layers of any stride, 64 / 128 / 256 / 512 input channels after padding to 64, a multiple
  *              of 32 output channels: filter bank
- *              in registers, waves stream 32-pixel tiles; what "auto" picks for such layers);
+ *              in registers, waves stream 32-pixel tiles; what "auto" picks for such layers)
+ *              | "stream" (ungrouped 3x3 layers without dilation, 64 / 128 / 256 / 512 input channels after padding: persistent
+ *              blocks, the filter bank resident in registers, input rows expanded once into an LDS ring; its cheapest variant by the
+ *              planner's estimate) | "wstream" (the same layers from 128 input channels on: activations stationary in LDS, weights
+ *              streamed into registers during the K loop; for launches of a few block steps).  "auto" prices every kernel that can
+ *              run the layer -- the streaming kernel's variants, the weight-streaming kernel, the block GEMM -- and takes the
+ *              cheapest (csrc/lce_plan.cpp, estimate_*_us; LCE_PLAN_DEBUG=1 in the environment prints the prices);
+ *   "stream_rows" = "0" (auto) | rows per segment (a divisor of the output height), "stream_interleave" = "auto" | "0" | "1"
+ *              (a block owns segments b, b + grid, ... instead of consecutive ones), "stream_strip" = "-1" (auto) | "0" | a strip width,
+ *              "stream_pixel_phases", "stream_flat", "compute_units", "wstream_blocks" = "0".."4", "wstream_images": tuning / testing
+ *              aids of the two streaming kernels;
  *   "kernel" = "auto" | "tiled" | "general"                        (valu engine);
  *   "tile"   = "auto" | valu lane tile "4x16"|"2x32"|"2x16"|"1x32"|"1x16"
  *                     | matrix-core block tile "256x256"|"256x128"|"512x64"|"128x256"|"128x128"|"256x64"|"128x64"

@@ -203,6 +203,17 @@ def test_planner_choices_for_the_baseline_layers(hw, c, dst, want):
     assert amd.Bconv2dPlan(p).kernel_name() == want
 
 
+def test_forced_strips_on_another_bank_say_so():
+    """Advisor (round 4): stream_strip > 0 on a layer whose filter bank is not the 256-channel one used to end in the unrelated
+    'row ring does not fit LDS'."""
+    p = amd.ConvParams(2, 8, 64, 128, 3, 3, 128, padding=amd.PADDING_SAME, pad_values=1)
+    plan = amd.Bconv2dPlan(p)
+    plan.set_option("engine", "stream")
+    plan.set_option("stream_strip", "32")
+    assert plan.kernel_name() == ""
+    assert "256-channel filter bank only" in amd.lib().lce_hip_last_error().decode()
+
+
 def test_planner_choice_for_run_dual():
     """lce_hip_bconv2d_plan_kernel_name_dual names the kernel run_dual launches: since round 5 the same kernel as run's (the cost
     estimate does not depend on the kind of call; round 4's twin plan is gone)."""

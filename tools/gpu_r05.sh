@@ -2,7 +2,7 @@
 # Round 5's measurement calls, one function per call: bash tools/gpu_r05.sh <part>   (run on the GPU box by gpurun; output under gpurun_out/r05_<part>/)
 cd $GRAFT_REPO_ROOT
 PART=$1
-OUT=gpurun_out/r05_$PART
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r05_$PART
 mkdir -p $OUT
 IL4="engine=stream,stream_rows=4,stream_interleave=1"
 IL8="engine=stream,stream_rows=8,stream_interleave=1"
@@ -167,6 +167,15 @@ box)
   # the headline on this box (bench_box_spread.txt: one call per box)
   python bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
   python -c "import json;d=json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1]);print('ms_per_step %.4f  roofline.frac %.4f  p10/p50/p90 %s  kernel %s' % (d['ms_per_step'], d['roofline']['frac'], d.get('ms_per_step_p10_p50_p90'), d['kernel']))" | tee -a $OUT/line.txt
+  ;;
+stacks)
+  # the three stacks of bench.py with and without the weight-streaming kernel among the planner's candidates (LCE_PLAN_NO_WSTREAM=1), alternating, one box
+  for r in 1 2 3; do
+    for v in "" 1; do
+      if [ -z "$v" ]; then tag=with_wstream; unset LCE_PLAN_NO_WSTREAM; else tag=without_wstream; export LCE_PLAN_NO_WSTREAM=1; fi
+      python bench.py --no-cpu-baseline --extra-json "" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); e=d['extra']; print('$tag', 'L0 %.4f' % d['ms_per_step'], {k: e[k] for k in e if 'layers' in k or k.startswith('quicknet_1') or k.startswith('quicknet_7')})" | tee -a $OUT/stacks.txt
+    done
+  done
   ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
