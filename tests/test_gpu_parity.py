@@ -733,6 +733,69 @@ def test_l0_batch256_streaming_kernel(dst):
     assert ",rows14>" in pname and np.array_equal(part.view(np.uint8), got[:201].view(np.uint8)), pname
 
 
+WS_FULL = [
+    # batch, h = w, cin, cout, stride
+    (256, 14, 256, 256, 1),     # QuickNet's third section: one image per group, parts of 4 + 3 pixel blocks, two blocks per CU
+    (256, 7, 512, 512, 1),      # the fourth: K depth 72, two blocks in y
+    (256, 14, 256, 512, 2),     # config 5's strided layer (7x7 outputs)
+    (67, 7, 256, 320, 1),       # a batch that does not fill the chip, 320 channels (a short last slice group)
+]
+
+
+@pytest.mark.parametrize("shape", WS_FULL, ids=lambda s: "%dx%dx%dx%d_s%d" % (s[0], s[1], s[2], s[3], s[4]))
+def test_weight_streaming_kernel_full_size(shape):
+    """Round 5: the weight-streaming kernel (engine=wstream) at the sizes the planner takes it for: ALL images bit-exact vs the
+    oracle for the three output types, equal to the block GEMM's bytes, and the second (sign-word) output of run_dual."""
+    b, hw, cin, cout, st = shape
+    spec = O.ConvSpec(b, hw, hw, cin, 3, 3, cout, 1, st, st, 1, 1, O.PADDING_SAME, 1, O.ACT_RELU if st == 2 else O.ACT_NONE, O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, b + hw + cin, negative_mul_fraction=0.25)
+    thr = O.thresholds_converter(spec, mul, bias)
+    scale, zp = synth.int8_quant_params(hw + cin)
+    for dst, odst in ((amd.F32, O.DST_F32), (amd.I8, O.DST_I8), (amd.BITPACKED, O.DST_BITPACKED)):
+        kw = dict(mul=mul, bias=bias) if dst != amd.BITPACKED else dict(thr=thr)
+        if dst == amd.I8:
+            kw.update(scale=scale, zp=zp)
+        got, name = _gpu_conv(spec, dst, x, w, engine="wstream", **kw)
+        assert name.startswith("bconv2d_wstream<"), name
+        want = O.bconv2d(spec, odst, x, w, mul, bias, thresholds=thr, out_scale=float(scale), out_zero_point=zp, threads=NTHREADS)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), name
+        ref, rname = _gpu_conv(spec, dst, x, w, engine="direct", **kw)
+        assert rname.startswith("bconv2d_mfma") and np.array_equal(ref.view(np.uint8), got.view(np.uint8)), rname
+    plan = amd.Bconv2dPlan(_params(spec, amd.F32))
+    plan.set_weights(w, mul, bias)
+    plan.set_option("engine", "wstream")
+    y, bits = plan.run_dual(torch.from_numpy(x).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(bits, amd.bitpack(y)) and plan.kernel_name().startswith("bconv2d_wstream<")
+
+
+@pytest.mark.parametrize("shape", [(256, 28, 128, 128, 1, 4), (256, 56, 64, 128, 2, 4), (256, 56, 256, 256, 1, 8), (201, 28, 128, 128, 1, 7)],
+                         ids=lambda s: "%dx%dx%dx%d_s%d_rows%d" % s)
+def test_streaming_kernel_interleaved_runs_full_size(shape):
+    """Round 5: a block of the streaming kernel owns segments b, b + grid, b + 2 grid, ... (stream_interleave=1) -- the planner's own
+    choice for float rows of the low-K layers.  ALL images bit-exact vs the oracle, three output types; equal to consecutive runs."""
+    b, hw, cin, cout, st, rows = shape
+    spec = O.ConvSpec(b, hw, hw, cin, 3, 3, cout, 1, st, st, 1, 1, O.PADDING_SAME, 1, O.ACT_NONE, O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, b + hw + cin)
+    thr = O.thresholds_converter(spec, mul, bias)
+    scale, zp = synth.int8_quant_params(hw + cout)
+    opts = (("stream_rows", str(rows)), ("stream_interleave", "1"))
+    for dst, odst in ((amd.F32, O.DST_F32), (amd.I8, O.DST_I8), (amd.BITPACKED, O.DST_BITPACKED)):
+        kw = dict(mul=mul, bias=bias) if dst != amd.BITPACKED else dict(thr=thr)
+        if dst == amd.I8:
+            kw.update(scale=scale, zp=zp)
+        got, name = _gpu_conv(spec, dst, x, w, engine="stream", opts=opts, **kw)
+        assert name.endswith(",il>"), name
+        want = O.bconv2d(spec, odst, x, w, mul, bias, thresholds=thr, out_scale=float(scale), out_zero_point=zp, threads=NTHREADS)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), name
+        del want
+        plain, pname = _gpu_conv(spec, dst, x, w, engine="stream", opts=(("stream_rows", str(rows)), ("stream_interleave", "0")), **kw)
+        assert not pname.endswith(",il>") and np.array_equal(plain.view(np.uint8), got.view(np.uint8)), pname
+    if hw == 28 and b == 256:     # what `auto` picks for this layer (tests/test_planner_choice.py holds it to the measured best)
+        _, aname = _gpu_conv(spec, amd.F32, x, w, engine="auto", mul=mul, bias=bias)
+        assert aname == "bconv2d_stream<f32,3x3x128,rows4,il>", aname
+
+
 @pytest.mark.parametrize("shape", [(3, 19, 23, 64, 64), (2, 14, 14, 256, 256), (5, 7, 7, 96, 144), (300, 14, 14, 256, 256)])
 def test_streaming_kernel_run_dual(shape):
     """lce_hip_bconv2d_run_dual on the streaming kernel (float and int8 plans): the first output equals lce_hip_bconv2d_run,
