@@ -409,4 +409,22 @@ LCE_DEVICE void cvt_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint3
       : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
 
+// The same eight conversions with v_cvt_rpi_i32_f32 = floor(x + 0.5) -- EXACTLY, for every float of magnitude <= 129, plain and in
+// this SDWA byte form (tools/probes/cvt_rpi.hip runs all of them) -- instead of truncation: round-half-up in one instruction per value,
+// no copysign / add in front of it.  Differs from the reference's round-half-AWAY only at exact negative ties, which the planner rules
+// out per plan before it selects a kernel built with it (lce_plan.cpp, int8_floor_rounding_is_exact).
+LCE_DEVICE void cvt_rpi_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint32_t& hi) {
+  asm("v_cvt_rpi_i32_f32_sdwa %0, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %1, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %0, %3 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %1, %7 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %0, %4 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %1, %8 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %0, %5 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "v_cvt_rpi_i32_f32_sdwa %1, %9 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+      "s_nop 0"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+
 }  // namespace lce_dev

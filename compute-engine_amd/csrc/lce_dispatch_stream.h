@@ -9,28 +9,30 @@ namespace lce {
 
 // 3x3 filters over 64 / 128 / 256 / 512 (padded) input channels; FAST = every padded word exists and padding is +1;
 // CLAMP = the float transform's clamp is not the identity; SIGN = the epilogue also writes the output's LceQuantize
-template <int DST, bool FAST, bool CLAMP, bool SIGN>
+template <int DST, bool FAST, bool CLAMP, bool SIGN, bool I8F>
 stream_fn stream_by_kch(int kch, bool strips) {
   if (strips)     // column strips of wide images: built for the 256-channel bank (the north star's 224 x 224 x 256 maps)
-    return kch == 4 ? bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN, false, true> : nullptr;
+    return kch == 4 ? bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN, false, true, I8F> : nullptr;
   switch (kch) {
-    case 8: return bconv2d_stream<DST, 3, 3, 8, FAST, CLAMP, SIGN, true>;     // 512 input channels: K split over wave pairs
-    case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN>;
-    case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP, SIGN>;
-    case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP, SIGN>;
+    case 8: return bconv2d_stream<DST, 3, 3, 8, FAST, CLAMP, SIGN, true, false, I8F>;     // 512 input channels: K split over wave pairs
+    case 4: return bconv2d_stream<DST, 3, 3, 4, FAST, CLAMP, SIGN, false, false, I8F>;
+    case 2: return bconv2d_stream<DST, 3, 3, 2, FAST, CLAMP, SIGN, false, false, I8F>;
+    case 1: return bconv2d_stream<DST, 3, 3, 1, FAST, CLAMP, SIGN, false, false, I8F>;
     default: return nullptr;
   }
 }
-template <int DST, bool CLAMP, bool SIGN>
+template <int DST, bool CLAMP, bool SIGN, bool I8F = false>
 stream_fn stream_by_fast(int kch, bool fast, bool strips) {
-  return fast ? stream_by_kch<DST, true, CLAMP, SIGN>(kch, strips) : stream_by_kch<DST, false, CLAMP, SIGN>(kch, strips);
+  return fast ? stream_by_kch<DST, true, CLAMP, SIGN, I8F>(kch, strips) : stream_by_kch<DST, false, CLAMP, SIGN, I8F>(kch, strips);
 }
-inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips = false) {
+// i8_floor: the int8 instances whose rounding is floor(x + 0.5) (the planner's int8_floor_ok)
+inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips = false, bool i8_floor = false) {
   switch (dst) {
     case LCE_HIP_F32:
       if (clamp) return sign ? stream_by_fast<kDstFloat, true, true>(kch, fast, strips) : stream_by_fast<kDstFloat, true, false>(kch, fast, strips);
       return sign ? stream_by_fast<kDstFloat, false, true>(kch, fast, strips) : stream_by_fast<kDstFloat, false, false>(kch, fast, strips);
     case LCE_HIP_I8:
+      if (i8_floor) return sign ? stream_by_fast<kDstInt8, false, true, true>(kch, fast, strips) : stream_by_fast<kDstInt8, false, false, true>(kch, fast, strips);
       return sign ? stream_by_fast<kDstInt8, false, true>(kch, fast, strips) : stream_by_fast<kDstInt8, false, false>(kch, fast, strips);
     default: return stream_by_fast<kDstBitpacked, false, false>(kch, fast, strips);
   }

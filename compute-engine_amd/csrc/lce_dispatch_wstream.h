@@ -9,30 +9,32 @@ namespace lce {
 
 // 3x3 filters over 128 / 256 / 512 (padded) input channels; NB = the most pixel blocks a block owns; SIGN = the epilogue also
 // writes the output's LceQuantize
-template <int DST, int KCH, bool SIGN>
+template <int DST, int KCH, bool SIGN, bool I8F>
 wstream_fn wstream_by_nb(int nb) {
   switch (nb) {
-    case 1: return bconv2d_wstream<DST, KCH, 1, SIGN>;
-    case 2: return bconv2d_wstream<DST, KCH, 2, SIGN>;
-    case 3: return bconv2d_wstream<DST, KCH, 3, SIGN>;
-    case 4: return bconv2d_wstream<DST, KCH, 4, SIGN>;
+    case 1: return bconv2d_wstream<DST, KCH, 1, SIGN, I8F>;
+    case 2: return bconv2d_wstream<DST, KCH, 2, SIGN, I8F>;
+    case 3: return bconv2d_wstream<DST, KCH, 3, SIGN, I8F>;
+    case 4: return bconv2d_wstream<DST, KCH, 4, SIGN, I8F>;
     default: return nullptr;
   }
 }
-template <int DST, bool SIGN>
+template <int DST, bool SIGN, bool I8F>
 wstream_fn wstream_by_kch(int kch, int nb) {
   switch (kch) {
-    case 8: return wstream_by_nb<DST, 8, SIGN>(nb);
-    case 4: return wstream_by_nb<DST, 4, SIGN>(nb);
-    case 2: return wstream_by_nb<DST, 2, SIGN>(nb);
+    case 8: return wstream_by_nb<DST, 8, SIGN, I8F>(nb);
+    case 4: return wstream_by_nb<DST, 4, SIGN, I8F>(nb);
+    case 2: return wstream_by_nb<DST, 2, SIGN, I8F>(nb);
     default: return nullptr;
   }
 }
-inline wstream_fn find_wstream(int dst, int kch, int nb, bool sign) {
+inline wstream_fn find_wstream(int dst, int kch, int nb, bool sign, bool i8_floor = false) {
   switch (dst) {
-    case LCE_HIP_F32: return sign ? wstream_by_kch<kDstFloat, true>(kch, nb) : wstream_by_kch<kDstFloat, false>(kch, nb);
-    case LCE_HIP_I8: return sign ? wstream_by_kch<kDstInt8, true>(kch, nb) : wstream_by_kch<kDstInt8, false>(kch, nb);
-    default: return wstream_by_kch<kDstBitpacked, false>(kch, nb);
+    case LCE_HIP_F32: return sign ? wstream_by_kch<kDstFloat, true, false>(kch, nb) : wstream_by_kch<kDstFloat, false, false>(kch, nb);
+    case LCE_HIP_I8:
+      if (i8_floor) return sign ? wstream_by_kch<kDstInt8, true, true>(kch, nb) : wstream_by_kch<kDstInt8, false, true>(kch, nb);
+      return sign ? wstream_by_kch<kDstInt8, true, false>(kch, nb) : wstream_by_kch<kDstInt8, false, false>(kch, nb);
+    default: return wstream_by_kch<kDstBitpacked, false, false>(kch, nb);
   }
 }
 

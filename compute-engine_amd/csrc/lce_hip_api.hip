@@ -572,6 +572,14 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     plan->device_current = false;
     return LCE_HIP_OK;
   }
+  if (!strcmp(key, "int8_rounding")) {      // testing aid: "exact" keeps the round-half-away instances even where floor(x + 0.5) is proven equal
+    if (strcmp(value, "auto") && strcmp(value, "exact")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: int8_rounding must be auto or exact");
+    h.int8_exact_pref = value[0] == 'e';
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    h.wq.clear();
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "stream_flat")) {       // testing aid for the streaming kernel: 0 = never cut pixel blocks across a block's images
     if (strcmp(value, "0") && strcmp(value, "1")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_flat must be 0 or 1");
     h.stream_noflat = value[0] == '0';
@@ -685,7 +693,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
     if (h.use_mfma && h.use_pointwise && ((uintptr_t)out & 15) == 0) {
       // 1x1 streaming kernel: waves walk 32-pixel tiles of the launch's pixel matrix
       if (lce_hip_status s = mfma_selftest_once(plan->device, 0)) return s;
-      lce::pointwise_fn fn = lce::lookup_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
+      lce::pointwise_fn fn = lce::lookup_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1, h.int8_floor_ok);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const lce::PwArgs P = lce::make_pw_args(h, nb);
       // k tiles per wave: enough blocks (>= 12 per CU when the launch has them) for the dispatcher to even
@@ -702,7 +710,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       if (lce_hip_status s = mfma_selftest_once(plan->device, 2)) return s;
       const lce::WsArgs G = lce::make_ws_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
-      lce::wstream_fn fn = lce::lookup_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, with_sign);
+      lce::wstream_fn fn = lce::lookup_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, with_sign, h.int8_floor_ok);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::wstream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
@@ -719,7 +727,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       if (lce_hip_status s = mfma_selftest_once(plan->device, 1)) return s;
       const lce::StreamArgs G = lce::make_stream_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
-      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign, G.NSTRIP > 1);
+      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign, G.NSTRIP > 1, h.int8_floor_ok);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::stream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {

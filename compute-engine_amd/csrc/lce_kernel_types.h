@@ -37,11 +37,11 @@ inline mfma_fn lookup_mfma(int dst, int bm, int bn, bool zero_pad_correction, bo
 // the workspace variant's expansion pass (bits -> FP4 word planes); returns the launch's hipError_t as an int
 int launch_expand_fp4(unsigned grid_x, void* stream, const uint32_t* in, void* workspace, const MfmaArgs& G, uint64_t chunks);
 // lce_tu_pointwise.hip
-pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided);
+pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided, bool i8_floor);
 // lce_tu_stream.hip
-stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips);
+stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips, bool i8_floor);
 // lce_tu_wstream.hip
-wstream_fn lookup_wstream(int dst, int kch, int nb, bool sign);
+wstream_fn lookup_wstream(int dst, int kch, int nb, bool sign, bool i8_floor);
 int mfma_selftest_wstream();
 // known-answer test of the unscaled FP4 MFMA as each of those two translation units compiled it (lce_mfma_selftest.h):
 // 0 = as assumed, 1 = wrong products, < 0 = -(hipError_t)

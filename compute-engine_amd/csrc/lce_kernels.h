@@ -80,6 +80,15 @@ LCE_DEVICE void round_pack8_i8_clamped(f32x4 a, f32x4 b, uint32_t& lo, uint32_t&
   cvt_pack8_i8(a, b, lo, hi);
 }
 
+// The two int8 roundings of the streaming kernels' epilogues, on eight values already inside [-128, 127]: I8F = false: round half away
+// from zero as the reference writes it (the add + the truncating conversion); I8F = true: floor(x + 0.5) in one instruction per value
+// (cvt_rpi_pack8_i8) -- the planner selects those instances only for plans on which the two agree on every value the layer can produce.
+template <bool I8F>
+LCE_DEVICE void pack8_i8_clamped(f32x4 a, f32x4 b, uint32_t& lo, uint32_t& hi) {
+  if constexpr (I8F) cvt_rpi_pack8_i8(a, b, lo, hi);
+  else round_pack8_i8_clamped(a, b, lo, hi);
+}
+
 // :17-27,31-44,133-143 -- std::round (half away from zero), saturate to int8.
 LCE_DEVICE int ot_int8(int acc, int cmin, int cmax, float mul, float bias) {
   return round_sat_i8(ot_float(acc, cmin, cmax, mul, bias));

@@ -46,7 +46,9 @@ __device__ unsigned long long lce_pw_tl[8192 * 4];
 // waits for the tile's stores as well
 constexpr int pw_min_blocks(int, int) { return 2; }
 
-template <int DST, int NC, int NJ, bool STRIDED>
+// I8F (int8 output): the rounding is floor(x + 0.5) in one instruction (lce_kernels.h, pack8_i8_clamped): instances the planner selects only
+// when that equals the reference's round-half-away on every value the plan can produce.
+template <int DST, int NC, int NJ, bool STRIDED, bool I8F = false>
 LCE_KERNEL void __launch_bounds__(256, pw_min_blocks(NC, NJ))
 bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t* __restrict__ wq,
                   const float* __restrict__ mul, const float* __restrict__ bias,
@@ -271,7 +273,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
 #pragma unroll
           for (int q = 0; q < 4; q += 2) {       // (values already inside [-128, 127])
             uint32_t lo, hi;
-            round_pack8_i8_clamped(src[q], src[q + 1], lo, hi);
+            pack8_i8_clamped<I8F>(src[q], src[q + 1], lo, hi);
             hold[S][k][q] = lo;
             hold[S][k][q + 1] = hi;
           }

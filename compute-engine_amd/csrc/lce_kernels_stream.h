@@ -67,7 +67,9 @@ constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 // STRIPS (round 4; wide images): a segment is a run of output rows of ONE column strip of an image (StreamArgs), so that a ring
 // row is a strip's width + halo instead of the whole padded row (224 x 144 B x 9-12 slots do not fit LDS).  Only the production's
 // address arithmetic and the block's first output pixel differ; a strip is a multiple of 32 columns, so a pixel block never wraps.
-template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false, bool STRIPS = false>
+// I8F (int8 output): the rounding is floor(x + 0.5), one instruction per value (lce_kernels.h, pack8_i8_clamped): selected by the planner only where
+// that equals the reference's round-half-away on every value the plan can produce.
+template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false, bool STRIPS = false, bool I8F = false>
 LCE_KERNEL void __launch_bounds__(256, 1)
 bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
                const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
@@ -633,10 +635,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       // a packed-f32 add beside the MFMA stream costs a dozen cycles more than its issue slot
       // (the conversion, which truncates, packs as it goes -- two dwords at a time: cvt_pack8_i8)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) yb[k][i] = yb[k][i] + __builtin_copysignf(0x1.fffffep-2f, yb[k][i]);
+      for (int i = 0; i < 4; ++i) if constexpr (!I8F) yb[k][i] = yb[k][i] + __builtin_copysignf(0x1.fffffep-2f, yb[k][i]);
       if constexpr ((k & 1) == 1) {
         uint32_t lo, hi;
-        cvt_pack8_i8(yb[k - 1], yb[k], lo, hi);
+        if constexpr (I8F) cvt_rpi_pack8_i8(yb[k - 1], yb[k], lo, hi);      // floor(x + 0.5): no add in front of the conversion
+        else cvt_pack8_i8(yb[k - 1], yb[k], lo, hi);
         pk[k >> 2][(k & 3) - 1] = lo;
         pk[k >> 2][k & 3] = hi;
       }

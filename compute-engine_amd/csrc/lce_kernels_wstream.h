@@ -40,7 +40,8 @@ constexpr int kWsScratch = 8192;      // bytes of a wave's epilogue scratch: [32
 // DST: kDstFloat / kDstInt8 / kDstBitpacked.  KCH: 64-channel chunks per tap (3x3 filters: 9 * KCH K-steps).  NB: the most
 // pixel blocks a block of this launch owns (the planner's parts differ by at most one: a block runs NB or NB - 1).
 // SIGN (float / int8): the epilogue also writes the LceQuantize of the values it produces (lce_hip_bconv2d_run_dual).
-template <int DST, int KCH, int NB, bool SIGN>
+// I8F (int8 output): round with floor(x + 0.5) (lce_kernels.h, pack8_i8_clamped; selected only where that is exact for the plan).
+template <int DST, int KCH, int NB, bool SIGN, bool I8F = false>
 LCE_KERNEL void __launch_bounds__(256, 2)
 bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
                 const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
@@ -286,7 +287,7 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
 #pragma unroll
           for (int h = 0; h < 4; h += 2) {       // (values already inside [-128, 127])
             uint32_t lo, hi;
-            round_pack8_i8_clamped(src[h], src[h + 1], lo, hi);
+            pack8_i8_clamped<I8F>(src[h], src[h + 1], lo, hi);
             pk[h] = lo;
             pk[h + 1] = hi;
           }

@@ -840,13 +840,75 @@ static void pack_for_mfma(HostPlan& p) {
     // rounding is), so med3(y(x), lo, hi) == saturate(y(med3(x, clamp_min, clamp_max))) for every x: the pointwise
     // kernel spends one clamp instead of two (lce_kernels_pointwise.h)
     p.thr_q.assign((size_t)2 * p.npad, 0.0f);
-    for (int i = 0; i < n; ++i) {
-      auto y = [&](int32_t x) { volatile float pr = (float)x * p.mul[i]; volatile float r = pr + p.bias[i]; return (float)r; };
-      const float a0 = y(p.clamp_min), a1 = y(p.clamp_max);
+    auto transformed = [](float mul, float bias, int32_t x) { volatile float pr = (float)x * mul; volatile float r = pr + bias; return (float)r; };
+    auto set_range = [&](int i, float mul, float bias) {
+      const float a0 = transformed(mul, bias, p.clamp_min), a1 = transformed(mul, bias, p.clamp_max);
       float lo = std::min(a0, a1), hi = std::max(a0, a1);
       if (!(lo == lo) || !(hi == hi)) { lo = -128.0f; hi = 127.0f; }   // NaN parameters: unspecified in the reference
       p.thr_q[i] = std::max(-128.0f, std::min(127.0f, lo));
       p.thr_q[p.npad + i] = std::max(-128.0f, std::min(127.0f, hi));
+    };
+    for (int i = 0; i < n; ++i) set_range(i, p.mul[i], p.bias[i]);
+    // Can the epilogues round with floor(y + 0.5) (one v_cvt_rpi_i32_f32 per value, exact for every float: tools/probes/cvt_rpi.hip)
+    // instead of round-half-away (output_transform.h:31-44)?  The two differ only where the clamped y is an exact NEGATIVE tie
+    // (-k - 0.5).  y = fl(fl(x * mul) + bias) takes finitely many values on a plan -- x runs over the values the accumulator can hold
+    // inside the clamps: the EVEN integers (x = K_bt - <a, w> = 2 * popcount) and the two clamp ends -- so every one of them is
+    // checked, for every channel.  Layers do hold ties (y lives on the grid of its operands' ulps: 2^-17 near |y| = 100 with
+    // multipliers well below 1, 2^-10 where x * mul reaches 10^4), so a channel that ties is given NEIGHBOURING parameters -- the
+    // bias up to four grid steps lower, the multiplier up to two ulps either side -- which turn its ties into non-ties that round the
+    // way the reference rounds the tie, and the whole channel is enumerated again against the reference's own arithmetic with the
+    // ORIGINAL parameters: equal int8 for every x, and no negative tie left (so the round-half-away instances agree on the adjusted
+    // parameters too).  No neighbour passes (multipliers like 0.25 with integer biases: positive and negative ties all over the
+    // channel): the plan keeps the exact instances and the original parameters.
+    p.int8_floor_ok = !p.int8_exact_pref && !getenv("LCE_PLAN_INT8_EXACT");   // (the env: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
+    p.int8_bias_adjusted = 0;
+    const int32_t x_lo = std::max<int32_t>(0, p.clamp_min), x_hi = (int32_t)std::min<int64_t>(2 * (int64_t)p.backtransform_add, p.clamp_max);
+    const bool even_only = cin_g % 2 == 0;   // (an odd channel count under zero padding: border pixels drop an odd number of terms)
+    auto sat8_half_away = [](float y) { const float r = std::round(y); return (int)std::max(-128.0f, std::min(127.0f, r)); };
+    auto channel_ok = [&](int i, float mul, float bias, int32_t* bad_x) {
+      const float a0 = transformed(mul, bias, p.clamp_min), a1 = transformed(mul, bias, p.clamp_max);
+      if (!(a0 == a0) || !(a1 == a1)) return false;
+      const float lo = std::max(-128.0f, std::min(127.0f, std::min(a0, a1))), hi = std::max(-128.0f, std::min(127.0f, std::max(a0, a1)));
+      for (int32_t x = x_lo; x <= x_hi; x = !even_only ? x + 1 : x == x_lo ? ((x_lo + 2) & ~1) : x == x_hi ? x + 1 : std::min(x + 2, x_hi)) {
+        float yc = transformed(mul, bias, x);
+        yc = yc < lo ? lo : (yc > hi ? hi : yc);
+        const bool negative_tie = yc < 0.0f && yc - std::floor(yc) == 0.5f;
+        if (negative_tie || (int)std::floor((double)yc + 0.5) != sat8_half_away(transformed(p.mul[i], p.bias[i], x))) {
+          if (bad_x) *bad_x = x;
+          return false;
+        }
+      }
+      return true;
+    };
+    struct Adjusted { int i; float mul, bias; };
+    std::vector<Adjusted> adjusted;
+    for (int i = 0; i < n && p.int8_floor_ok; ++i) {
+      int32_t bad = 0;
+      if (channel_ok(i, p.mul[i], p.bias[i], &bad)) continue;
+      // the grid step of y around the tie: the coarser of the product's and the bias's ulp (a smaller step is absorbed by the sum's rounding)
+      const float y_bad = transformed(p.mul[i], p.bias[i], bad), pr_bad = std::fabs((float)bad * p.mul[i]);
+      const float big = std::max(std::max(pr_bad, std::fabs(p.bias[i])), std::fabs(y_bad));
+      const float step = std::max(std::nextafter(big, INFINITY) - big, std::ldexp(1.0f, -20));
+      bool found = false;
+      for (int dm = 0; dm <= 4 && !found; ++dm) {            // multiplier: 0, +1, -1, +2, -2 ulps
+        float m2 = p.mul[i];
+        for (int s = 0; s < (dm + 1) / 2; ++s) m2 = std::nextafter(m2, (dm & 1) ? INFINITY : -INFINITY);
+        for (int k = dm == 0 ? 1 : 0; k <= 4 && !found; ++k) {
+          const float b2 = p.bias[i] - (float)k * step;
+          if (channel_ok(i, m2, b2, nullptr)) { adjusted.push_back({i, m2, b2}); found = true; }
+        }
+      }
+      if (!found) {
+        if (getenv("LCE_PLAN_DEBUG"))
+          fprintf(stderr, "[lce plan] int8: channel %d, accumulator %d -> y = %.9g: an exact negative tie that no neighbouring (multiplier, bias) resolves, round-half-away instances\n",
+                  i, bad, (double)y_bad);
+        p.int8_floor_ok = false;
+      }
+    }
+    if (p.int8_floor_ok) {
+      for (const auto& a : adjusted) { p.mul_q[a.i] = a.mul; p.bias_q[a.i] = a.bias; set_range(a.i, a.mul, a.bias); }
+      p.int8_bias_adjusted = (int)adjusted.size();
+      if (getenv("LCE_PLAN_DEBUG") && !adjusted.empty()) fprintf(stderr, "[lce plan] int8: floor rounding, %zu channel(s) with adjusted parameters\n", adjusted.size());
     }
     return;
   }

@@ -86,6 +86,11 @@ struct HostPlan {
   int cpad = 0, hp = 0, wp = 0, npad = 0;  // workspace geometry / padded channel count
   int kch = 0;                             // K-steps (64-channel chunks) per filter tap that a block runs: cpad/64,
                                            // or the chunks one group's channel slice touches
+  // int8 plans: floor(y + 0.5) equals the reference's round-half-away on EVERY value this plan can produce (no reachable exact negative
+  // tie; pack_for_mfma checks every channel x every accumulator value inside the clamps): the streaming kernels' one-instruction rounding
+  bool int8_floor_ok = false;
+  int int8_bias_adjusted = 0;       // channels whose bias the floor-rounding proof lowered by a few 2^-17 (lce_plan.cpp, pack_for_mfma)
+  bool int8_exact_pref = false;            // testing aid (int8_rounding=exact): never take the floor instances
   std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
   int wq_layout = 0;                       // 0: K-major [K-step][K-half][Npad][16 B]; 1: tile-major [Npad/32][K-step][K-half][32][16 B] (wstream)
   std::vector<float> mul_q, bias_q, thr_q; // Npad entries

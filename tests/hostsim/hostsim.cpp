@@ -94,6 +94,8 @@ int g_stream_phases = 0;      // its pixel phases per block (0 = auto)
 int g_stream_strip = -1;      // its column strips (-1 auto, 0 never, else the width)
 int g_stream_interleave = 0;  // its segment -> block map (1: interleaved runs)
 int g_pw_nj = 0;              // the pointwise kernel's 32-channel tiles per block (0 = auto)
+int g_last_int8_adjusted = 0;   // ... and the number of channels whose bias its floor-rounding proof adjusted
+int g_last_int8_floor = -1;   // the last convolution's plan: 1 = its int8 rounding ran as floor(x + 0.5), 0 = round-half-away, -1 = not an int8 matrix-core plan
 
 }  // namespace
 
@@ -107,6 +109,8 @@ void hostsim_set_stream_phases(int phases) { g_stream_phases = phases; }
 void hostsim_set_stream_strip(int width) { g_stream_strip = width; }
 void hostsim_set_stream_interleave(int on) { g_stream_interleave = on; }
 void hostsim_set_pointwise(int channel_tiles) { g_pw_nj = channel_tiles; }
+int hostsim_last_int8_floor() { return g_last_int8_floor; }
+int hostsim_last_int8_adjusted() { return g_last_int8_adjusted; }
 
 // kernel_pref: 0 auto, 1 tiled, 2 general; tm/tn 0 = auto; max_batch 0 = planner's choice
 // engine_pref: 0 auto, 1 valu, 2 mfma
@@ -136,6 +140,8 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     strncpy(name_out, h.kernel_name.c_str(), name_len - 1);
     name_out[name_len - 1] = 0;
   }
+  g_last_int8_adjusted = h.int8_bias_adjusted;
+  g_last_int8_floor = h.d.dst_type == LCE_HIP_I8 && h.use_mfma && (h.use_stream || h.use_wstream || h.use_pointwise) ? (h.int8_floor_ok ? 1 : 0) : -1;
   // the padded tables get the same slack as the device uploads
   auto slack_u = [](std::vector<uint32_t> v) { v.resize(v.size() + 16, 0u); return v; };
   const std::vector<uint32_t> packed = slack_u(h.packed), filt = slack_u(h.filter);
@@ -152,7 +158,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     if (h.use_mfma && h.use_wstream) {
       const WsArgs G = make_ws_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      wstream_fn fn = find_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, sgn != nullptr);
+      wstream_fn fn = find_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, sgn != nullptr, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
@@ -164,7 +170,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     } else if (h.use_mfma && h.use_stream) {
       const StreamArgs G = make_stream_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1);
+      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
@@ -174,7 +180,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
         fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out, sgn);
       });
     } else if (h.use_mfma && h.use_pointwise) {
-      pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1);
+      pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const PwArgs P = make_pw_args(h, nb);
       std::vector<uint8_t> wq = h.wq;

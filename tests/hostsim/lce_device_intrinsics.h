@@ -243,4 +243,10 @@ inline void cvt_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint32_t&
   hi = pack4_u8((int)b[0], (int)b[1], (int)b[2], (int)b[3]);
 }
 
+inline void cvt_rpi_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint32_t& hi) {      // floor(x + 0.5), exactly
+  auto r = [](float x) { return (int)floor((double)x + 0.5); };
+  lo = pack4_u8(r(a[0]), r(a[1]), r(a[2]), r(a[3]));
+  hi = pack4_u8(r(b[0]), r(b[1]), r(b[2]), r(b[3]));
+}
+
 }  // namespace lce_dev

@@ -103,6 +103,17 @@ def set_stream_interleave(on: int = 0):
     lib().hostsim_set_stream_interleave(int(on))
 
 
+def last_int8_floor() -> int:
+    """1: the last convolution's int8 rounding ran as floor(x + 0.5) (the planner proved it equal to round-half-away on that plan),
+    0: as round-half-away, -1: not an int8 plan of the streaming / pointwise kernels."""
+    return int(lib().hostsim_last_int8_floor())
+
+
+def last_int8_adjusted() -> int:
+    """Channels of the last int8 plan whose bias the planner's floor-rounding proof lowered (lce_plan.cpp, pack_for_mfma)."""
+    return int(lib().hostsim_last_int8_adjusted())
+
+
 def set_pointwise(channel_tiles: int = 0):
     """The pointwise kernel's 32-channel tiles per block (0 = auto: 1 for the small launches of these tests)."""
     lib().hostsim_set_pointwise(int(channel_tiles))

@@ -750,6 +750,57 @@ def test_wstream_second_output_is_the_lcequantize_of_the_output(cin, cout, hw, z
         H.set_stream(256, 0)
 
 
+@pytest.mark.parametrize("engine,shape", [("stream", (2, 8, 8, 64, 64, 3)), ("stream", (2, 6, 6, 256, 64, 3)), ("wstream", (2, 7, 7, 256, 64, 3)),
+                                          ("pointwise", (2, 9, 9, 128, 64, 1))], ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_int8_floor_rounding_is_taken_only_where_it_is_exact(engine, shape):
+    """Round 5: the streaming / weight-streaming / pointwise kernels round int8 outputs with floor(y + 0.5) (one instruction) on plans where
+    that provably equals the reference's round-half-away -- no accumulator value inside the clamps lands on an exact negative tie for any
+    channel -- and with the exact sequence otherwise.  Random parameters: floor instances, equal to the oracle.  Multipliers of -0.25 with
+    zero bias: y = -x / 4 hits -k - 0.5 whenever x = 2 (mod 4): the planner must keep the exact instances, and the bytes still equal the
+    oracle's (with floor rounding every such tie would be off by one)."""
+    b, h, w_, cin, cout, k = shape
+    spec = O.ConvSpec(b, h, w_, cin, k, k, cout, padding=O.PADDING_SAME if k == 3 else O.PADDING_VALID, pad_values=1 if k == 3 else 0)
+    x, w, mul, bias = synth.conv_inputs(spec, 17 + cin)
+    H.set_stream(2, 0)
+    try:
+        got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=0.5, out_zero_point=-7, engine=engine)
+        assert H.last_int8_floor() == 1, name
+        assert np.array_equal(got, O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=0.5, out_zero_point=-7)), name
+        mul_t = np.full(cout, -0.25, np.float32)
+        mul_t[::3] = 0.25
+        bias_t = np.zeros(cout, np.float32)
+        got, name = H.bconv2d(spec, O.DST_I8, x, w, mul_t, bias_t, out_scale=1.0, out_zero_point=0, engine=engine)
+        want = O.bconv2d(spec, O.DST_I8, x, w, mul_t, bias_t, out_scale=1.0, out_zero_point=0)
+        assert H.last_int8_floor() == 0, name
+        assert np.array_equal(got, want), name
+    finally:
+        H.set_stream(256, 0)
+
+
+def test_int8_floor_rounding_with_an_adjusted_bias_equals_the_oracle():
+    """A layer with real-valued parameters does hold an exact negative tie now and then (about 2^-17 per value near |y| = 100); the
+    planner lowers that channel's bias by a few 2^-17 and proves the whole channel again.  Parameters are drawn until a plan with an
+    adjusted channel shows up (about every second draw of this shape); every plan's bytes equal the oracle's."""
+    spec = O.ConvSpec(1, 5, 5, 256, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1)
+    adjusted = 0
+    H.set_stream(2, 0)
+    try:
+        for seed in range(12):
+            rng = np.random.default_rng(900 + seed)
+            x, w, _, _ = synth.conv_inputs(spec, seed)
+            mul = rng.uniform(0.02, 0.09, 96).astype(np.float32) * rng.choice([-1.0, 1.0], 96).astype(np.float32)
+            bias = rng.uniform(-20.0, 20.0, 96).astype(np.float32)
+            got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=0.73, out_zero_point=3, engine="stream")
+            assert np.array_equal(got, O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=0.73, out_zero_point=3)), (seed, name)
+            if H.last_int8_floor() == 1:
+                adjusted += H.last_int8_adjusted()
+            if adjusted:
+                break
+        assert adjusted > 0
+    finally:
+        H.set_stream(256, 0)
+
+
 def test_wstream_kernel_refuses_what_it_cannot_run():
     for spec, why in [
         (O.ConvSpec(1, 6, 6, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "128, 256 or 512 input channels"),

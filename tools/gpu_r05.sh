@@ -177,5 +177,24 @@ stacks)
     done
   done
   ;;
+i8floor)
+  # int8 epilogues with floor(y + 0.5) rounding (one v_cvt_rpi_i32_f32; planner-proven per plan) vs the round-half-away sequence: tests, per-layer A/B, stacks A/B
+  python -m pytest tests/test_gpu_parity.py -q -x -k "int8 or i8 or ties" > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt
+  E="int8_rounding=exact"
+  {
+    for spec in "56 64x64 i8 256 5 40" "28 128x128 i8 256 5 60" "14 256x256 i8 256 5 100" "7 512x512 i8 256 5 100" "56 256x256 i8 256 4 20" "56 64x128s2 i8 256 5 60" "28 128x256s2 i8 256 5 100" "14 256x512s2 i8 256 5 100"; do
+      LCE_PLAN_DEBUG=1 python tools/ab_opts.py $spec base exact:$E 2>&1 | grep -v "us$\|estimate"
+    done
+    for spec in "56 64x64 i8 256 5 40" "56 256x256 i8 256 5 20" "28 128x128 i8 256 5 60" "14 256x256 i8 256 5 100"; do
+      LCE_K=1 LCE_PLAN_DEBUG=1 python tools/ab_opts.py $spec base exact:$E 2>&1 | grep -v "us$\|estimate"
+    done
+  } > $OUT/ab.txt 2>&1
+  for r in 1 2 3; do
+    for v in "" 1; do
+      if [ -z "$v" ]; then tag=floor; unset LCE_PLAN_INT8_EXACT; else tag=exact; export LCE_PLAN_INT8_EXACT=1; fi
+      python bench.py --no-cpu-baseline --extra-json "" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); e=d['extra']; print('$tag', 'L0 %.4f' % d['ms_per_step'], {k: e[k] for k in e if 'layers' in k or k.startswith('quicknet_1') or k.startswith('quicknet_7')})" | tee -a $OUT/stacks.txt
+    done
+  done
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
