@@ -536,6 +536,7 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     p.st_spb = (int)spb; p.st_gx = (int)ceil_div((int)s, (int)spb); p.st_rows = rows; p.st_ring_bytes = (int)ring;
     p.st_batch = batch_chunk;
     p.wp = wp;
+    if (const char* dbg = getenv("LCE_PLAN_DEBUG")) if (atoi(dbg) >= 2) fprintf(stderr, "[lce plan] stream geometry: rows/segment %d, ring %d rows x %d B = %lld B (+%d), blocks %d x %d, segments/block %lld\n", rs, rows, pitch, (long long)ring, stream_lds_extra(p), p.st_gx, ny, (long long)spb);
     p.st_pitch = pitch;
     // ---- the tables: [sched | lim | ctx] ----
     const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
@@ -865,11 +866,30 @@ static void pack_for_mfma(HostPlan& p) {
     const int32_t x_lo = std::max<int32_t>(0, p.clamp_min), x_hi = (int32_t)std::min<int64_t>(2 * (int64_t)p.backtransform_add, p.clamp_max);
     const bool even_only = cin_g % 2 == 0;   // (an odd channel count under zero padding: border pixels drop an odd number of terms)
     auto sat8_half_away = [](float y) { const float r = std::round(y); return (int)std::max(-128.0f, std::min(127.0f, r)); };
+    // The accumulator values a channel is checked on, in order: x_lo, the even values above it, x_hi.  y is monotone in x (each rounding
+    // is), so the values whose y lies strictly inside the clamps are one run of them -- found by bisection -- and every value outside
+    // it produces the clamp itself: the run, one value either side of it and the two ends are all that needs checking.
+    const int32_t first_even = even_only ? ((x_lo + 2) & ~1) : x_lo + 1;
+    const int32_t n_mid = even_only ? (x_hi > first_even ? (x_hi - 1 - first_even) / 2 + 1 : 0) : std::max(0, x_hi - 1 - x_lo);
+    const int32_t n_x = x_hi > x_lo ? n_mid + 2 : 1;
+    auto x_at = [&](int32_t k) { return k == 0 ? x_lo : k == n_x - 1 ? x_hi : first_even + (even_only ? 2 : 1) * (k - 1); };
+    auto inner_run = [&](float mul, float bias, float lo, float hi, int32_t* k0, int32_t* k1) {
+      const bool inc = transformed(mul, bias, x_hi) >= transformed(mul, bias, x_lo);
+      auto below = [&](int32_t k) { const float y = transformed(mul, bias, x_at(k)); return inc ? y <= lo : y >= hi; };        // before the run
+      auto not_past = [&](int32_t k) { const float y = transformed(mul, bias, x_at(k)); return inc ? y < hi : y > lo; };       // before its end
+      int32_t a = 0, b = n_x;
+      while (a < b) { const int32_t m = a + (b - a) / 2; if (below(m)) a = m + 1; else b = m; }
+      *k0 = a;
+      b = n_x;
+      while (a < b) { const int32_t m = a + (b - a) / 2; if (not_past(m)) a = m + 1; else b = m; }
+      *k1 = a;                                                                                                                  // [k0, k1)
+    };
+    const bool check_all = getenv("LCE_PLAN_INT8_FULL") != nullptr;   // (testing aid: every value instead of the run -- tests compare the two)
     auto channel_ok = [&](int i, float mul, float bias, int32_t* bad_x) {
       const float a0 = transformed(mul, bias, p.clamp_min), a1 = transformed(mul, bias, p.clamp_max);
       if (!(a0 == a0) || !(a1 == a1)) return false;
       const float lo = std::max(-128.0f, std::min(127.0f, std::min(a0, a1))), hi = std::max(-128.0f, std::min(127.0f, std::max(a0, a1)));
-      for (int32_t x = x_lo; x <= x_hi; x = !even_only ? x + 1 : x == x_lo ? ((x_lo + 2) & ~1) : x == x_hi ? x + 1 : std::min(x + 2, x_hi)) {
+      auto value_ok = [&](int32_t x) {
         float yc = transformed(mul, bias, x);
         yc = yc < lo ? lo : (yc > hi ? hi : yc);
         const bool negative_tie = yc < 0.0f && yc - std::floor(yc) == 0.5f;
@@ -877,7 +897,18 @@ static void pack_for_mfma(HostPlan& p) {
           if (bad_x) *bad_x = x;
           return false;
         }
-      }
+        return true;
+      };
+      // the run inside the candidate's clamps and the run inside int8's range under the reference's parameters, one value either side
+      int32_t k0, k1, r0, r1;
+      inner_run(mul, bias, lo, hi, &k0, &k1);
+      inner_run(p.mul[i], p.bias[i], -128.5f, 127.5f, &r0, &r1);
+      k0 = std::max(0, std::min(k0, r0) - 1);
+      k1 = std::min(n_x, std::max(k1, r1) + 1);
+      if (check_all) { k0 = 0; k1 = n_x; }
+      if (!value_ok(x_lo) || !value_ok(x_hi)) return false;
+      for (int32_t k = k0; k < k1; ++k)
+        if (!value_ok(x_at(k))) return false;
       return true;
     };
     struct Adjusted { int i; float mul, bias; };

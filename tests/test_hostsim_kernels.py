@@ -801,6 +801,39 @@ def test_int8_floor_rounding_with_an_adjusted_bias_equals_the_oracle():
         H.set_stream(256, 0)
 
 
+def test_int8_floor_proof_by_bisection_equals_the_full_enumeration(monkeypatch):
+    """The planner checks the run of accumulator values whose output lies inside the clamps (found by bisection: y is monotone in x), one
+    value either side and the two ends; LCE_PLAN_INT8_FULL=1 checks every value.  Same verdict and same number of adjusted channels on
+    parameters of every kind: tiny and large multipliers, both signs, zero, activations that cut into int8's range, ties all over."""
+    rng = np.random.default_rng(77)
+    verdicts = []
+    for case in range(24):
+        cin, cout = [(64, 32), (128, 48), (256, 64)][case % 3]
+        act = [O.ACT_NONE, O.ACT_RELU, O.ACT_RELU6, O.ACT_RELU_N1_TO_1][case % 4]
+        spec = O.ConvSpec(1, 4, 4, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=1, activation=act)
+        x, w, _, _ = synth.conv_inputs(spec, case)
+        kind = case % 6
+        mul = rng.uniform(0.001, [0.05, 0.5, 4.0][kind % 3], cout).astype(np.float32) * rng.choice([-1.0, 1.0], cout).astype(np.float32)
+        if kind == 3:
+            mul = np.where(rng.random(cout) < 0.5, 0.25, -0.125).astype(np.float32)
+        if kind == 4:
+            mul[::5] = 0.0
+        bias = (rng.uniform(-30, 30, cout) if kind != 3 else rng.integers(-9, 9, cout)).astype(np.float32)
+        scale, zp = float(rng.choice([0.0625, 0.37, 1.0, 2.5])), int(rng.integers(-20, 21))
+        got = []
+        for full in ("", "1"):
+            if full:
+                monkeypatch.setenv("LCE_PLAN_INT8_FULL", "1")
+            else:
+                monkeypatch.delenv("LCE_PLAN_INT8_FULL", raising=False)
+            out, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp, engine="stream")
+            assert np.array_equal(out, O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp)), (case, name, full)
+            got.append((H.last_int8_floor(), H.last_int8_adjusted()))
+        assert got[0] == got[1], (case, got)
+        verdicts.append(got[0])
+    assert any(v[0] == 1 for v in verdicts) and any(v[0] == 0 for v in verdicts) and any(v[1] > 0 for v in verdicts), verdicts
+
+
 def test_wstream_kernel_refuses_what_it_cannot_run():
     for spec, why in [
         (O.ConvSpec(1, 6, 6, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "128, 256 or 512 input channels"),

@@ -196,5 +196,13 @@ i8floor)
     done
   done
   ;;
+occ2)
+  # two blocks of the streaming kernel per CU on 64-input-channel layers (launch bounds (256, 2): <= 256 registers per wave): in-tree vs build_exp/lib_base.so (one block per CU)
+  {
+    for spec in "56 64x64 i8 256 3 40" "56 64x64 f32 256 3 40" "56 64x64 bp 256 3 40" "56 64x128s2 i8 256 3 60" "56 64x128s2 f32 256 3 60" "112 64x64 i8 64 3 20"; do
+      bash tools/ab_libs.sh 2 "$spec one:engine=stream two:engine=stream,compute_units=512 three:engine=stream,compute_units=768" build_exp/lib_base.so base
+    done
+  } > $OUT/ab.txt 2>&1
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
