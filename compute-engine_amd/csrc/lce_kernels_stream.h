@@ -507,6 +507,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // t - 2 (the chain through bw[]), so at least six instructions -- with one unit per K-step also two MFMAs -- lie in between.
   // (Float kernels with several units per K-step -- 64 / 128 input channels -- keep the padded form: store-bound, they measured equal
   //  or 3 % slower with it, profiles/r04/ballots_one_kstep_late.txt.)
+  constexpr bool kTight = SIGN && !FAST && KCH >= 4;      // instances at the register file's limit: phase B's reads ride in phase C
   constexpr bool kPipeBallots = KSPLIT || KS * 4 / 9 >= 16 || DST != kDstFloat;
   unsigned long long pend[2] = {0ull, 0ull};
   // the lanes of unit T's ballots (pend as unit T left it)
@@ -616,7 +617,7 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       buf_store1(rsgn, (n0 >> 5) + 1 < G.Wout ? sat_add_u32(sob, 4u) : kOobOffset, bw[1]);
     }
   };
-  auto epi_b = [&](auto kc) LCE_LAMBDA_INLINE {
+  auto epi_b_read = [&](auto kc) LCE_LAMBDA_INLINE {
     constexpr int k = decltype(kc)::value;
     if constexpr (DST == kDstFloat) {
       yb[k] = *(const f32x4*)(scratch + ((lane / LPR) + RPI * k) * SCW + (lane & (LPR - 1)) * 4);
@@ -625,9 +626,13 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       yb[k] = *(const f32x4*)(scratch + ((lane / LPR) + RPI * (k >> 2)) * SCW + (lane & (LPR - 1)) * 16 + (k & 3) * 4);
     }
   };
+  auto epi_b = [&](auto kc) LCE_LAMBDA_INLINE {
+    if constexpr (!kTight) epi_b_read(kc);
+  };
   // `ob` = this lane's byte offset for store instruction 0 (out of range: nothing is stored)
   auto epi_c = [&](auto kc, uint32_t ob) LCE_LAMBDA_INLINE {
     constexpr int k = decltype(kc)::value;
+    if constexpr (kTight) epi_b_read(kc);
     if constexpr (DST == kDstFloat) {
       buf_store_streaming_so(rout, ob, (uint32_t)(RPI * k) * row_bytes, yb[k]);
     } else if constexpr (DST == kDstInt8) {
