@@ -6,7 +6,6 @@
 
 #include <algorithm>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "lce_dispatch.h"
@@ -20,7 +19,7 @@ namespace {
 // Lanes of a wave executed one after the other (no wave collectives needed).
 template <typename F>
 void launch_sequential(int grid_x, int grid_y, int block, F&& body) {
-  lce_dev::ThreadCtx& c = lce_dev::g_ctx;
+  lce_dev::ThreadCtx& c = g_ctx;
   c.bar = nullptr;
   c.xchg = nullptr;
   c.bdim_x = block;
@@ -33,17 +32,16 @@ void launch_sequential(int grid_x, int grid_y, int block, F&& body) {
       }
 }
 
-// The 64 lanes of every wave run as 64 real threads so ballot/shuffle work.  The threads are created once per
-// launch and walk the (block, wave) list together (thread creation used to dominate the suite's run time).
+// The 64 lanes of every wave run in lock step (fibers of this thread: lce_device_intrinsics.h) so ballot / shuffle work; they walk
+// the (block, wave) list together.
 template <typename F>
 void launch_lockstep(int grid_x, int block, F&& body) {
-  std::barrier<> bar(64);
+  lce_dev::FiberBarrier bar(64);
   uint32_t xchg[64] = {0};
-  std::vector<std::thread> lanes;
-  for (int l = 0; l < 64; ++l)
-    lanes.emplace_back([&, l] {
-      lce_dev::ThreadCtx& c = lce_dev::g_ctx;
-      c.bar = &bar; c.xchg = xchg; c.bdim_x = block; c.gdim_x = grid_x;
+  lce_dev::run_fibers(64,
+    [&](int l, lce_dev::ThreadCtx& c) { c.bar = &bar; c.xchg = xchg; c.bdim_x = block; c.gdim_x = grid_x; (void)l; },
+    [&](int l) {
+      lce_dev::ThreadCtx& c = g_ctx;
       for (int bx = 0; bx < grid_x; ++bx)
         for (int w = 0; w < block / 64; ++w) {
           c.bid_x = bx; c.bid_y = 0; c.tid_x = w * 64 + l;
@@ -51,39 +49,29 @@ void launch_lockstep(int grid_x, int block, F&& body) {
           bar.arrive_and_wait();   // the exchange area is free again before the next wave starts
         }
     });
-  for (auto& t : lanes) t.join();
 }
 
-// A whole thread block in lock step: `block` real threads (64 per wave), a block barrier, shared LDS and a per-wave
-// exchange area for the MFMA emulation.  One set of threads per launch; they run the blocks one after the other,
-// with zeroed LDS for each.
+// A whole thread block in lock step: `block` fibers (64 per wave), a block barrier, shared LDS and a per-wave exchange area for
+// the MFMA emulation.  One set of fibers per launch; they run the blocks one after the other, with zeroed LDS for each.
 template <typename F>
 void launch_block_lockstep(int grid_x, int grid_y, int block, size_t lds_bytes, F&& body) {
-  std::vector<uint8_t> lds(lds_bytes + 64, 0);
-  std::barrier<> block_bar(block);
-  std::vector<std::barrier<>*> wave_bar;
-  for (int w = 0; w < block / 64; ++w) wave_bar.push_back(new std::barrier<>(64));
-  std::vector<uint32_t> xchg((block / 64) * 64, 0), mx((block / 64) * 64 * 8, 0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < block; ++t)
-    th.emplace_back([&, t] {
-      lce_dev::ThreadCtx& c = lce_dev::g_ctx;
-      const int w = t / 64;
-      c.bar = wave_bar[w]; c.xchg = xchg.data() + w * 64; c.mfma_xchg = mx.data() + w * 64 * 8;
-      c.block_bar = &block_bar; c.lds = lds.data();
-      c.bdim_x = block; c.gdim_x = grid_x; c.tid_x = t;
-      for (int by = 0; by < grid_y; ++by)
-        for (int bx = 0; bx < grid_x; ++bx) {
-          c.bid_x = bx; c.bid_y = by;
-          c.dma.clear();
-          body();
-          block_bar.arrive_and_wait();
-          if (t == 0) memset(lds.data(), 0, lds.size());
-          block_bar.arrive_and_wait();
-        }
-    });
-  for (auto& x : th) x.join();
-  for (auto* b : wave_bar) delete b;
+  // the blocks of a launch are independent: OS threads take them in turn, each with its own LDS and its own set of fibers
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int bid = 0; bid < grid_x * grid_y; ++bid) {
+    const int bx = bid % grid_x, by = bid / grid_x;
+    std::vector<uint8_t> lds(lds_bytes + 64, 0);
+    lce_dev::FiberBarrier block_bar(block);
+    std::vector<lce_dev::FiberBarrier> wave_bar(block / 64, lce_dev::FiberBarrier(64));
+    std::vector<uint32_t> xchg((block / 64) * 64, 0), mx((block / 64) * 64 * 8, 0);
+    lce_dev::run_fibers(block,
+      [&](int t, lce_dev::ThreadCtx& c) {
+        const int w = t / 64;
+        c.bar = &wave_bar[w]; c.xchg = xchg.data() + w * 64; c.mfma_xchg = mx.data() + w * 64 * 8;
+        c.block_bar = &block_bar; c.lds = lds.data();
+        c.bdim_x = block; c.gdim_x = grid_x; c.tid_x = t; c.bid_x = bx; c.bid_y = by;
+      },
+      [&](int) { body(); });
+  }
 }
 
 std::string g_err;

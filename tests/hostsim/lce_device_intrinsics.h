@@ -1,7 +1,7 @@
 // HOST replacement of compute-engine_amd/csrc/lce_device_intrinsics.h -- TEST ONLY.
 //
 // The CPU-only test suite compiles the real kernel bodies (lce_kernels.h) against this
-// header and executes them thread by thread, so index arithmetic, padding, grouping and
+// header and executes them thread by thread (lanes that need collectives: as fibers in lock step), so index arithmetic, padding, grouping and
 // the fused output transforms are exercised without a GPU.  Nothing in the product
 // includes this file; it is not a fallback path (the shipped library is built only from
 // the gfx950 header and fails loudly without a device).
@@ -10,7 +10,9 @@
 #include <stdint.h>
 #include <string.h>
 
-#include <barrier>
+#include <sys/mman.h>
+
+#include <functional>
 #include <deque>
 #include <vector>
 
@@ -33,20 +35,137 @@ constexpr int kWave = 64;
 
 struct f32x16 { float v[16]; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
 
+// ---- cooperative lanes ------------------------------------------------------------------------------------------------
+// The simulated threads of a wave / block that need collectives (ballots, shuffles, the MFMA emulation, LDS fences, block barriers)
+// run as FIBERS of one OS thread: a barrier is a counter, waiting is a switch to the next fiber (a dozen instructions: callee-saved
+// registers and the stack pointer).  (Until round 5 every lane was an OS thread on a std::barrier: 256 threads on 8 cores spent the
+// suite's time in futex calls -- 14 of its 18 minutes.)
+#if !defined(__x86_64__)
+#error "the host simulation's fiber switch is written for x86-64 (the container's and the driver's CPU)"
+#endif
+extern "C" void lce_fiber_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl lce_fiber_switch
+.type lce_fiber_switch,@function
+lce_fiber_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size lce_fiber_switch,.-lce_fiber_switch
+)");
+
+struct FiberBarrier {
+  int n, arrived = 0;
+  unsigned gen = 0;
+  explicit FiberBarrier(int n_) : n(n_) {}
+  inline void arrive_and_wait();
+};
+
 struct ThreadCtx {
   int tid_x = 0, bid_x = 0, bid_y = 0, bdim_x = 1, gdim_x = 1;
   // block-level state (lock-step block mode): LDS, block barrier, per-wave MFMA exchange
   uint8_t* lds = nullptr;
-  std::barrier<>* block_bar = nullptr;
+  FiberBarrier* block_bar = nullptr;
   uint32_t* mfma_xchg = nullptr;  // per wave: 64 lanes x 8 dwords (a[4], b[4])
-  // wave collectives (only valid when the 64 lanes of a wave run as real threads)
-  std::barrier<>* bar = nullptr;
+  // wave collectives (only valid when the 64 lanes of a wave run in lock step)
+  FiberBarrier* bar = nullptr;
   uint32_t* xchg = nullptr;  // 64 slots shared by the wave
   // LDS-DMA in flight (this lane's 16 bytes of every piece its wave issued), oldest first
   struct PendingDma { uint8_t* dst; uint8_t data[16]; };
   std::deque<PendingDma> dma;
 };
-inline thread_local ThreadCtx g_ctx;
+inline thread_local ThreadCtx g_main_ctx;             // the OS thread's own context (sequential launches)
+inline thread_local ThreadCtx* g_ctxp = &g_main_ctx;  // the running fiber's
+#define g_ctx (*::lce_dev::g_ctxp)
+
+struct FiberSet {
+  static constexpr size_t kStack = 4u << 20;          // per fiber, reserved lazily
+  struct Fiber { void* sp = nullptr; ThreadCtx ctx; bool done = false; };
+  std::vector<Fiber> f;
+  std::function<void(int)> body;
+  int cur = 0, alive = 0;
+  void* main_sp = nullptr;
+  uint8_t* stacks = nullptr;
+};
+inline thread_local FiberSet* g_fibers = nullptr;
+
+inline void fiber_switch_to(int to) {
+  FiberSet& s = *g_fibers;
+  const int from = s.cur;
+  s.cur = to;
+  g_ctxp = &s.f[to].ctx;
+  lce_fiber_switch(&s.f[from].sp, s.f[to].sp);
+}
+inline void fiber_yield() {
+  FiberSet& s = *g_fibers;
+  const int n = (int)s.f.size();
+  int to = s.cur;
+  do { to = to + 1 == n ? 0 : to + 1; } while (s.f[to].done && to != s.cur);
+  if (to != s.cur) fiber_switch_to(to);
+}
+inline void FiberBarrier::arrive_and_wait() {
+  const unsigned g = gen;
+  if (++arrived == n) { arrived = 0; ++gen; return; }
+  while (gen == g) fiber_yield();
+}
+extern "C" inline void lce_fiber_entry() {
+  FiberSet& s = *g_fibers;
+  const int me = s.cur;
+  s.body(me);
+  s.f[me].done = true;
+  if (--s.alive == 0) {
+    void* dummy;
+    g_ctxp = &g_main_ctx;
+    lce_fiber_switch(&dummy, s.main_sp);
+  }
+  fiber_yield();      // to a fiber that is not done; never resumed
+  __builtin_trap();
+}
+// Runs body(t) for t in [0, n) as n fibers of the calling thread, round-robin at every wait, until all have returned.
+// `setup(t, ctx)` fills each fiber's context first.
+template <typename Setup>
+inline void run_fibers(int n, Setup&& setup, std::function<void(int)> body) {
+  FiberSet s;
+  s.f.resize(n);
+  s.body = std::move(body);
+  s.alive = n;
+  const size_t bytes = (size_t)n * FiberSet::kStack;
+  s.stacks = (uint8_t*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (s.stacks == (uint8_t*)MAP_FAILED) __builtin_trap();
+  for (int t = 0; t < n; ++t) {
+    setup(t, s.f[t].ctx);
+    // the frame lce_fiber_switch pops: six callee-saved registers, then the entry point as its return address; above it one slot
+    // so that the entry point starts with the stack alignment of a called function
+    uint64_t* top = (uint64_t*)(s.stacks + (size_t)(t + 1) * FiberSet::kStack);
+    top[-1] = 0;
+    top[-2] = (uint64_t)(void*)&lce_fiber_entry;
+    for (int r = 3; r <= 8; ++r) top[-r] = 0;
+    s.f[t].sp = (void*)(top - 8);
+  }
+  FiberSet* outer = g_fibers;
+  ThreadCtx* outer_ctx = g_ctxp;
+  g_fibers = &s;
+  s.cur = 0;
+  g_ctxp = &s.f[0].ctx;
+  lce_fiber_switch(&s.main_sp, s.f[0].sp);
+  g_fibers = outer;
+  g_ctxp = outer_ctx;
+  munmap(s.stacks, bytes);
+}
+
 
 inline int thread_idx_x() { return g_ctx.tid_x; }
 inline int block_idx_x() { return g_ctx.bid_x; }
@@ -134,21 +253,31 @@ inline void xor_popc_acc(int& c0, int& c1, int& c2, int& c3, uint32_t w, uint32_
 inline int fp4_pm1(uint32_t nib) { return nib == 0x2 ? 1 : nib == 0xA ? -1 : 0; }
 inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c);
 inline f32x16 mfma_fp4_32x32x64_unscaled(u32x4 a, u32x4 b, f32x16 c) { return mfma_fp4_32x32x64(a, b, c); }
+// Every lane first reduces its 32 codes of A and of B to two 32-bit masks each (non-zero, negative), so that a dot product over the
+// 64 K positions is three popcounts: sum = #(both non-zero) - 2 * #(both non-zero, signs differ).
+inline void fp4_masks(const u32x4& v, uint32_t& nz, uint32_t& neg) {
+  nz = 0; neg = 0;
+  for (int j = 0; j < 32; ++j) {
+    const int val = fp4_pm1((v[j / 8] >> (4 * (j % 8))) & 0xF);
+    if (val != 0) nz |= 1u << j;
+    if (val < 0) neg |= 1u << j;
+  }
+}
 inline f32x16 mfma_fp4_32x32x64(u32x4 a, u32x4 b, f32x16 c) {
   const int lane = g_ctx.tid_x & 63;
-  uint32_t* x = g_ctx.mfma_xchg;
-  for (int i = 0; i < 4; ++i) { x[lane * 8 + i] = a[i]; x[lane * 8 + 4 + i] = b[i]; }
+  uint32_t* x = g_ctx.mfma_xchg;      // per lane: [a.nz, a.neg, b.nz, b.neg, ...]
+  fp4_masks(a, x[lane * 8 + 0], x[lane * 8 + 1]);
+  fp4_masks(b, x[lane * 8 + 2], x[lane * 8 + 3]);
   g_ctx.bar->arrive_and_wait();
   const int col = lane & 31;
+  const uint64_t bnz = (uint64_t)x[col * 8 + 2] | (uint64_t)x[(col + 32) * 8 + 2] << 32;
+  const uint64_t bneg = (uint64_t)x[col * 8 + 3] | (uint64_t)x[(col + 32) * 8 + 3] << 32;
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    int sum = 0;
-    for (int k = 0; k < 64; ++k) {
-      const int j = k & 31, src_a = row + 32 * (k >> 5), src_b = col + 32 * (k >> 5);
-      const uint32_t na = (x[src_a * 8 + j / 8] >> (4 * (j % 8))) & 0xF;
-      const uint32_t nb = (x[src_b * 8 + 4 + j / 8] >> (4 * (j % 8))) & 0xF;
-      sum += fp4_pm1(na) * fp4_pm1(nb);
-    }
+    const uint64_t anz = (uint64_t)x[row * 8 + 0] | (uint64_t)x[(row + 32) * 8 + 0] << 32;
+    const uint64_t aneg = (uint64_t)x[row * 8 + 1] | (uint64_t)x[(row + 32) * 8 + 1] << 32;
+    const uint64_t both = anz & bnz;
+    const int sum = __builtin_popcountll(both) - 2 * __builtin_popcountll(both & (aneg ^ bneg));
     c[r] += (float)sum;
   }
   g_ctx.bar->arrive_and_wait();
