@@ -403,6 +403,36 @@ def test_mfma_random_specs(seed):
         done += 1
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_planners_own_choice_on_random_layers(seed):
+    """Round 5: whatever kernel the planner's cost estimate picks (streaming with its own or interleaved segments, weight-streaming,
+    pointwise, block GEMM, xor-popcount), on random layers of the kind the streaming family serves -- 3x3 and 1x1 filters, 64 .. 512
+    input channels (ragged ones included), batches 1 .. 6, 1 .. 256 'compute units' -- all three output types equal the oracle's, with
+    the planner's batch chunking and with a forced one."""
+    g = synth.rng(9100 + seed)
+    k = int(g.choice([3, 3, 3, 1]))
+    cin = int(g.choice([64, 128, 256, 512, 96, 200, 320, 40]))
+    cout = int(g.choice([16, 32, 48, 64, 80, 128, 192, 256, 304, 512]))
+    sh, sw = (int(v) for v in g.choice([1, 1, 2], 2))
+    pad = str(g.choice(["ONE", "ONE", "SAME", "VALID"])) if k == 3 else "VALID"
+    act = int(g.choice([O.ACT_NONE, O.ACT_RELU, O.ACT_RELU6, O.ACT_RELU_N1_TO_1]))
+    padding, pv = PADS[pad]
+    if pad == "SAME" and cin % 2:
+        padding, pv = PADS["ONE"]
+    big = seed % 4 == 3           # every fourth layer: launches of many block steps (interleaved runs, the pointwise kernel, several rounds)
+    h, w_ = (int(g.integers(12, 40)), int(g.integers(12, 40))) if big else (int(g.integers(3, 16)), int(g.integers(3, 16)))
+    batch = int(g.integers(4, 20)) if big else int(g.integers(1, 7))
+    spec = O.ConvSpec(batch, h, w_, cin, k, k, cout, 1, sh, sw, 1, 1, padding, pv, act, O.SEM_REFERENCE)
+    cus = int(g.choice([4, 8, 16])) if big else int(g.choice([1, 2, 3, 4, 8, 256]))
+    H.set_stream(cus, 0)
+    try:
+        names = _run_all_dst_mfma(spec, 9200 + seed, engine="auto")
+        names += _run_all_dst_mfma(spec, 9300 + seed, max_batch=int(g.integers(1, batch + 1)), engine="auto")
+        assert names
+    finally:
+        H.set_stream(256, 0)
+
+
 @pytest.mark.parametrize("engine", ["mfma", "direct"])
 @pytest.mark.parametrize("cin,cout,groups,tile", [(128, 128, 2, (128, 64)), (192, 256, 2, (128, 128)), (128, 256, 4, (128, 64)),
                                                   (320, 128, 2, (256, 64)), (64, 128, 2, (128, 64))])
