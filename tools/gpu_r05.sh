@@ -204,5 +204,14 @@ occ2)
     done
   } > $OUT/ab.txt 2>&1
   ;;
+pkf32)
+  # the packed-f32 output transform (v_pk_mul_f32 / v_pk_add_f32, -DLCE_STREAM_PK_F32) on the LOW-K streaming instances, where the epilogue is
+  # not in an MFMA's shadow (round-4 review, item 3): build_exp/lib_pkf32.so vs the same single-translation-unit build without the flag
+  {
+    for spec in "56 64x64 f32 256 3 40" "28 128x128 f32 256 3 60" "56 64x64 i8 256 3 40" "56 64x128s2 f32 256 3 60" "56 256x256 f32 256 3 20"; do
+      bash tools/ab_libs.sh 2 "$spec base stream:engine=stream" build_exp/lib_unity.so build_exp/lib_pkf32.so
+    done
+  } > $OUT/ab.txt 2>&1
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
