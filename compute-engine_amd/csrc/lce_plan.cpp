@@ -893,7 +893,8 @@ static void pack_for_mfma(HostPlan& p) {
         float yc = transformed(mul, bias, x);
         yc = yc < lo ? lo : (yc > hi ? hi : yc);
         const bool negative_tie = yc < 0.0f && yc - std::floor(yc) == 0.5f;
-        if (negative_tie || (int)std::floor((double)yc + 0.5) != sat8_half_away(transformed(p.mul[i], p.bias[i], x))) {
+        if (!(yc == yc) || negative_tie ||      // (NaN: infinite multipliers -- unspecified in the reference, the exact instances)
+            (int)std::floor((double)yc + 0.5) != sat8_half_away(transformed(p.mul[i], p.bias[i], x))) {
           if (bad_x) *bad_x = x;
           return false;
         }

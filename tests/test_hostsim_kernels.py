@@ -831,6 +831,27 @@ def test_int8_floor_rounding_with_an_adjusted_bias_equals_the_oracle():
         H.set_stream(256, 0)
 
 
+def test_int8_floor_proof_leaves_non_finite_parameters_to_the_exact_instances():
+    """A NaN parameter or an infinite multiplier (0 * inf: unspecified in the reference) must not be 'proven': the plan keeps the
+    round-half-away instances and the original parameters; in every case the finite channels still equal the oracle's bytes."""
+    spec = O.ConvSpec(1, 5, 5, 64, 3, 3, 32, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 5)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=0.37, out_zero_point=2)
+    H.set_stream(2, 0)
+    try:
+        for bad in (np.inf, -np.inf, np.nan):
+            for which in ("mul", "bias"):
+                m2, b2 = mul.copy(), bias.copy()
+                (m2 if which == "mul" else b2)[3] = bad
+                got, name = H.bconv2d(spec, O.DST_I8, x, w, m2, b2, out_scale=0.37, out_zero_point=2, engine="stream")
+                if which == "mul" or bad != bad:          # (an infinite bias saturates every value: that IS provable)
+                    assert H.last_int8_floor() == 0, (bad, which, name)
+                keep = np.arange(32) != 3
+                assert np.array_equal(got[..., keep], want[..., keep]), (bad, which, name)
+    finally:
+        H.set_stream(256, 0)
+
+
 def test_int8_floor_proof_by_bisection_equals_the_full_enumeration(monkeypatch):
     """The planner checks the run of accumulator values whose output lies inside the clamps (found by bisection: y is monotone in x), one
     value either side and the two ends; LCE_PLAN_INT8_FULL=1 checks every value.  Same verdict and same number of adjusted channels on
