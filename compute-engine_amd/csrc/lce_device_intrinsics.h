@@ -136,6 +136,13 @@ LCE_DEVICE f32x2 mul_then_add_pk(f32x2 a, f32x2 b, f32x2 c) {
   const f32x2 p = a * b;
   return p + c;
 }
+// ONE rounding: v_fma_f32 / v_pk_fma_f32.  Not the reference's transform (two roundings, mul_then_add): only the int8 instances whose plan
+// the planner has PROVEN byte-identical with it use these (I8F: lce_plan.cpp, prepare_int8_epilogue).
+LCE_DEVICE float fma1(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+LCE_DEVICE f32x2 fma2(f32x2 a, float b, float c) {
+  const f32x2 bb = {b, b}, cc = {c, c};
+  return __builtin_elementwise_fma(a, bb, cc);
+}
 // A use of `v` that generates nothing: keeps its registers allocated (and unmodified) up to this point.
 LCE_DEVICE void keep_alive(const u32x4& v) { asm volatile("" ::"v"(v)); }
 

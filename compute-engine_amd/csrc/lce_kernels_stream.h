@@ -67,8 +67,8 @@ constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 // STRIPS (round 4; wide images): a segment is a run of output rows of ONE column strip of an image (StreamArgs), so that a ring
 // row is a strip's width + halo instead of the whole padded row (224 x 144 B x 9-12 slots do not fit LDS).  Only the production's
 // address arithmetic and the block's first output pixel differ; a strip is a multiple of 32 columns, so a pixel block never wraps.
-// I8F (int8 output): the rounding is floor(x + 0.5), one instruction per value (lce_kernels.h, pack8_i8_clamped): selected by the planner only where
-// that equals the reference's round-half-away on every value the plan can produce.
+// I8F (int8 output): the transform is ONE fma and the rounding floor(x + 0.5), one instruction each per value (lce_kernels.h, pack8_i8_clamped):
+// selected by the planner only where that equals the reference's two roundings + round-half-away on every value the plan can produce.
 template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false, bool STRIPS = false, bool I8F = false>
 LCE_KERNEL void __launch_bounds__(256, 1)
 bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
@@ -575,7 +575,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
         y = transform2(x, mj[j], bj[j]);
       } else {
         const f32x2 x = {acc[j][r0], acc[j][r0 + 1]};
-        y = transform2(x, mj[j], bj[j]);
+        if constexpr (I8F) { y[0] = fma1(x[0], mj[j][0], bj[j][0]); y[1] = fma1(x[1], mj[j][1], bj[j][1]); }   // one rounding: proven per plan
+        else y = transform2(x, mj[j], bj[j]);
         y[0] = med3(y[0], tj[j], uj[j]);                   // one clamp: see lce_kernels_pointwise.h
         y[1] = med3(y[1], tj[j], uj[j]);
       }

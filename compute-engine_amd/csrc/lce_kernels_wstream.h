@@ -40,7 +40,7 @@ constexpr int kWsScratch = 8192;      // bytes of a wave's epilogue scratch: [32
 // DST: kDstFloat / kDstInt8 / kDstBitpacked.  KCH: 64-channel chunks per tap (3x3 filters: 9 * KCH K-steps).  NB: the most
 // pixel blocks a block of this launch owns (the planner's parts differ by at most one: a block runs NB or NB - 1).
 // SIGN (float / int8): the epilogue also writes the LceQuantize of the values it produces (lce_hip_bconv2d_run_dual).
-// I8F (int8 output): round with floor(x + 0.5) (lce_kernels.h, pack8_i8_clamped; selected only where that is exact for the plan).
+// I8F (int8 output): transform with one fma, round with floor(x + 0.5) (lce_kernels.h, pack8_i8_clamped; selected only where that is exact for the plan).
 template <int DST, int KCH, int NB, bool SIGN, bool I8F = false>
 LCE_KERNEL void __launch_bounds__(256, 2)
 bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
@@ -244,7 +244,7 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
           if constexpr (DST == kDstFloat) {
             if (!G.noclamp) { x[0] = med3(x[0], G.cmin, G.cmax); x[1] = med3(x[1], G.cmin, G.cmax); }
           }
-          const f32x2 y = mul_then_add2(x, mj[j], bj[j]);
+          const f32x2 y = I8F ? fma2(x, mj[j], bj[j]) : mul_then_add2(x, mj[j], bj[j]);      // (I8F: one rounding, proven per plan)
           if constexpr (DST == kDstInt8) {   // one clamp: the transformed range of the clamped accumulator, inside int8's (lce_kernels_pointwise.h)
             acc[q][j][r] = med3(y[0], tj[j], uj[j]);
             acc[q][j][r + 1] = med3(y[1], tj[j], uj[j]);

@@ -799,6 +799,134 @@ static int group_chunks(const lce_hip_bconv2d_desc& d) {
   return most;
 }
 
+// int8 plans: the per-channel constants of the matrix-core kernels' epilogues -- mul_q, bias_q, thr_q = [lo | hi] -- and whether the
+// selected kernel may run its one-instruction forms (int8_floor_ok).  Runs after EVERY kernel selection (select_kernel): what can be
+// proven depends on the arithmetic of the kernel that will run.
+//
+// thr_q: the per-channel range of the transformed value y over the clamped accumulator x in [clamp_min, clamp_max], intersected with
+// int8's range.  y is monotone in x (each rounding is), so med3(y(x), lo, hi) == saturate(y(med3(x, clamp_min, clamp_max))) for every
+// x: the kernels spend one clamp instead of two (lce_kernels_pointwise.h).
+//
+// The one-instruction forms (I8F instances): rounding = floor(y + 0.5) (v_cvt_rpi_i32_f32, exact for every float: tools/probes/cvt_rpi.hip)
+// instead of round-half-away (output_transform.h:31-44) -- they differ only where the clamped y is an exact NEGATIVE tie (-k - 0.5) --
+// and, in the streaming and the weight-streaming kernel, y = fma(x, mul, bias) (one rounding) instead of fl(fl(x * mul) + bias).  On
+// one plan y takes finitely many values: x runs over the values the accumulator can hold inside the clamps -- the EVEN integers
+// (x = K_bt - <a, w> = 2 * popcount) and the two clamp ends -- so every one of them is checked, per channel, against the reference's
+// arithmetic: equal int8, and no negative tie (so that the second output's y < threshold also means what it means in the reference).
+// Layers do hold ties and near-ties (y lives on the grid of its operands' ulps: 2^-17 near |y| = 100 with multipliers well below 1,
+// 2^-10 where x * mul reaches 10^4), so a channel that fails is given NEIGHBOURING parameters -- the bias up to four grid steps lower,
+// the multiplier up to two ulps either side -- and enumerated again against the reference's arithmetic on the ORIGINAL parameters.  No
+// neighbour passes (multipliers like 0.25 with integer biases: positive and negative ties all over the channel): the plan keeps the
+// exact instances and the original parameters.
+// (Kernels with the reference's own two roundings -- the pointwise kernel, whose launches fall back to the block GEMM on unaligned
+//  output pointers, and the block GEMM itself -- get parameters proven under two roundings: with no negative tie left, round-half-away
+//  and floor(y + 0.5) agree on them.)
+static void prepare_int8_epilogue(HostPlan& p) {
+  const lce_hip_bconv2d_desc& d = p.d;
+  const int n = d.channels_out, cin_g = d.channels_in / d.groups;
+  p.mul_q.assign(p.npad, 0.0f);
+  p.bias_q.assign(p.npad, 0.0f);
+  std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
+  std::copy(p.bias.begin(), p.bias.end(), p.bias_q.begin());
+  p.thr_q.assign((size_t)2 * p.npad, 0.0f);
+  const bool one_rounding = p.use_stream || p.use_wstream;
+  auto two_roundings = [](float mul, float bias, int32_t x) { volatile float pr = (float)x * mul; volatile float r = pr + bias; return (float)r; };
+  auto proven_form = [&](float mul, float bias, int32_t x) { return one_rounding ? std::fmaf((float)x, mul, bias) : two_roundings(mul, bias, x); };
+  auto set_range = [&](int i, float mul, float bias, bool proven) {
+    const float a0 = proven ? proven_form(mul, bias, p.clamp_min) : two_roundings(mul, bias, p.clamp_min);
+    const float a1 = proven ? proven_form(mul, bias, p.clamp_max) : two_roundings(mul, bias, p.clamp_max);
+    float lo = std::min(a0, a1), hi = std::max(a0, a1);
+    if (!(lo == lo) || !(hi == hi)) { lo = -128.0f; hi = 127.0f; }   // NaN parameters: unspecified in the reference
+    p.thr_q[i] = std::max(-128.0f, std::min(127.0f, lo));
+    p.thr_q[p.npad + i] = std::max(-128.0f, std::min(127.0f, hi));
+  };
+  for (int i = 0; i < n; ++i) set_range(i, p.mul[i], p.bias[i], false);
+  p.int8_floor_ok = !p.int8_exact_pref && !getenv("LCE_PLAN_INT8_EXACT");   // (the env: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
+  p.int8_bias_adjusted = 0;
+  const int32_t x_lo = std::max<int32_t>(0, p.clamp_min), x_hi = (int32_t)std::min<int64_t>(2 * (int64_t)p.backtransform_add, p.clamp_max);
+  const bool even_only = cin_g % 2 == 0;   // (an odd channel count under zero padding: border pixels drop an odd number of terms)
+  auto sat8_half_away = [](float y) { const float r = std::round(y); return (int)std::max(-128.0f, std::min(127.0f, r)); };
+  // The accumulator values a channel is checked on, in order: x_lo, the even values above it, x_hi.  y is monotone in x (each rounding
+  // is), so the values whose y lies strictly inside the clamps are one run of them -- found by bisection -- and every value outside
+  // it produces the clamp itself: the run, one value either side of it and the two ends are all that needs checking.
+  const int32_t first_even = even_only ? ((x_lo + 2) & ~1) : x_lo + 1;
+  const int32_t n_mid = even_only ? (x_hi > first_even ? (x_hi - 1 - first_even) / 2 + 1 : 0) : std::max(0, x_hi - 1 - x_lo);
+  const int32_t n_x = x_hi > x_lo ? n_mid + 2 : 1;
+  auto x_at = [&](int32_t k) { return k == 0 ? x_lo : k == n_x - 1 ? x_hi : first_even + (even_only ? 2 : 1) * (k - 1); };
+  auto inner_run = [&](auto&& y_of, float lo, float hi, int32_t* k0, int32_t* k1) {
+    const bool inc = y_of(x_hi) >= y_of(x_lo);
+    auto below = [&](int32_t k) { const float y = y_of(x_at(k)); return inc ? y <= lo : y >= hi; };        // before the run
+    auto not_past = [&](int32_t k) { const float y = y_of(x_at(k)); return inc ? y < hi : y > lo; };       // before its end
+    int32_t a = 0, b = n_x;
+    while (a < b) { const int32_t m = a + (b - a) / 2; if (below(m)) a = m + 1; else b = m; }
+    *k0 = a;
+    b = n_x;
+    while (a < b) { const int32_t m = a + (b - a) / 2; if (not_past(m)) a = m + 1; else b = m; }
+    *k1 = a;                                                                                                // [k0, k1)
+  };
+  const bool check_all = getenv("LCE_PLAN_INT8_FULL") != nullptr;   // (testing aid: every value instead of the run -- tests compare the two)
+  auto channel_ok = [&](int i, float mul, float bias, int32_t* bad_x) {
+    const float a0 = proven_form(mul, bias, p.clamp_min), a1 = proven_form(mul, bias, p.clamp_max);
+    if (!(a0 == a0) || !(a1 == a1)) return false;
+    const float lo = std::max(-128.0f, std::min(127.0f, std::min(a0, a1))), hi = std::max(-128.0f, std::min(127.0f, std::max(a0, a1)));
+    auto value_ok = [&](int32_t x) {
+      float yc = proven_form(mul, bias, x);
+      yc = yc < lo ? lo : (yc > hi ? hi : yc);
+      const bool negative_tie = yc < 0.0f && yc - std::floor(yc) == 0.5f;
+      if (!(yc == yc) || negative_tie ||      // (NaN: infinite multipliers -- unspecified in the reference, the exact instances)
+          (int)std::floor((double)yc + 0.5) != sat8_half_away(two_roundings(p.mul[i], p.bias[i], x))) {
+        if (bad_x) *bad_x = x;
+        return false;
+      }
+      return true;
+    };
+    // the run inside the candidate's clamps and the run inside int8's range under the reference's parameters, one value either side
+    int32_t k0, k1, r0, r1;
+    inner_run([&](int32_t x) { return proven_form(mul, bias, x); }, lo, hi, &k0, &k1);
+    inner_run([&](int32_t x) { return two_roundings(p.mul[i], p.bias[i], x); }, -128.5f, 127.5f, &r0, &r1);
+    k0 = std::max(0, std::min(k0, r0) - 1);
+    k1 = std::min(n_x, std::max(k1, r1) + 1);
+    if (check_all) { k0 = 0; k1 = n_x; }
+    if (!value_ok(x_lo) || !value_ok(x_hi)) return false;
+    for (int32_t k = k0; k < k1; ++k)
+      if (!value_ok(x_at(k))) return false;
+    return true;
+  };
+  struct Adjusted { int i; float mul, bias; };
+  std::vector<Adjusted> adjusted;
+  for (int i = 0; i < n && p.int8_floor_ok; ++i) {
+    int32_t bad = 0;
+    if (channel_ok(i, p.mul[i], p.bias[i], &bad)) continue;
+    // the grid step of y around the failing value: the coarser of the product's and the bias's ulp (a smaller step is absorbed by the sum's rounding)
+    const float y_bad = proven_form(p.mul[i], p.bias[i], bad), pr_bad = std::fabs((float)bad * p.mul[i]);
+    const float big = std::max(std::max(pr_bad, std::fabs(p.bias[i])), std::fabs(y_bad));
+    const float step = std::max(std::nextafter(big, INFINITY) - big, std::ldexp(1.0f, -20));
+    bool found = false;
+    for (int dm = 0; dm <= 4 && !found; ++dm) {            // multiplier: 0, +1, -1, +2, -2 ulps
+      float m2 = p.mul[i];
+      for (int s = 0; s < (dm + 1) / 2; ++s) m2 = std::nextafter(m2, (dm & 1) ? INFINITY : -INFINITY);
+      for (int t = 0; t < 9 && !found; ++t) {
+        const int k = t < 5 ? t : 4 - t;                            // 0, 1, 2, 3, 4 steps lower, then 1 .. 4 higher
+        if (dm == 0 && k == 0) continue;
+        const float b2 = p.bias[i] - (float)k * step;
+        if (channel_ok(i, m2, b2, nullptr)) { adjusted.push_back({i, m2, b2}); found = true; }
+      }
+    }
+    if (!found) {
+      if (getenv("LCE_PLAN_DEBUG"))
+        fprintf(stderr, "[lce plan] int8: channel %d, accumulator %d -> y = %.9g: no neighbouring (multiplier, bias) reproduces the reference there, round-half-away instances\n",
+                i, bad, (double)y_bad);
+      p.int8_floor_ok = false;
+    }
+  }
+  if (p.int8_floor_ok) {
+    for (const auto& a : adjusted) { p.mul_q[a.i] = a.mul; p.bias_q[a.i] = a.bias; }
+    for (int i = 0; i < n; ++i) set_range(i, p.mul_q[i], p.bias_q[i], true);
+    p.int8_bias_adjusted = (int)adjusted.size();
+    if (getenv("LCE_PLAN_DEBUG") && !adjusted.empty()) fprintf(stderr, "[lce plan] int8: one-instruction forms, %zu channel(s) with adjusted parameters\n", adjusted.size());
+  }
+}
+
 static void pack_for_mfma(HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
   const int taps = d.filter_height * d.filter_width, n = d.channels_out;
@@ -835,115 +963,7 @@ static void pack_for_mfma(HostPlan& p) {
   p.bias_q.assign(p.npad, 0.0f);
   std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
   std::copy(p.bias.begin(), p.bias.end(), p.bias_q.begin());
-  if (d.dst_type == LCE_HIP_I8) {
-    // int8 plans: thr_q = [lo | hi], the per-channel range of the TRANSFORMED value y = float(x) * mul + bias over the
-    // clamped accumulator x in [clamp_min, clamp_max], intersected with int8's range.  y is monotone in x (each
-    // rounding is), so med3(y(x), lo, hi) == saturate(y(med3(x, clamp_min, clamp_max))) for every x: the pointwise
-    // kernel spends one clamp instead of two (lce_kernels_pointwise.h)
-    p.thr_q.assign((size_t)2 * p.npad, 0.0f);
-    auto transformed = [](float mul, float bias, int32_t x) { volatile float pr = (float)x * mul; volatile float r = pr + bias; return (float)r; };
-    auto set_range = [&](int i, float mul, float bias) {
-      const float a0 = transformed(mul, bias, p.clamp_min), a1 = transformed(mul, bias, p.clamp_max);
-      float lo = std::min(a0, a1), hi = std::max(a0, a1);
-      if (!(lo == lo) || !(hi == hi)) { lo = -128.0f; hi = 127.0f; }   // NaN parameters: unspecified in the reference
-      p.thr_q[i] = std::max(-128.0f, std::min(127.0f, lo));
-      p.thr_q[p.npad + i] = std::max(-128.0f, std::min(127.0f, hi));
-    };
-    for (int i = 0; i < n; ++i) set_range(i, p.mul[i], p.bias[i]);
-    // Can the epilogues round with floor(y + 0.5) (one v_cvt_rpi_i32_f32 per value, exact for every float: tools/probes/cvt_rpi.hip)
-    // instead of round-half-away (output_transform.h:31-44)?  The two differ only where the clamped y is an exact NEGATIVE tie
-    // (-k - 0.5).  y = fl(fl(x * mul) + bias) takes finitely many values on a plan -- x runs over the values the accumulator can hold
-    // inside the clamps: the EVEN integers (x = K_bt - <a, w> = 2 * popcount) and the two clamp ends -- so every one of them is
-    // checked, for every channel.  Layers do hold ties (y lives on the grid of its operands' ulps: 2^-17 near |y| = 100 with
-    // multipliers well below 1, 2^-10 where x * mul reaches 10^4), so a channel that ties is given NEIGHBOURING parameters -- the
-    // bias up to four grid steps lower, the multiplier up to two ulps either side -- which turn its ties into non-ties that round the
-    // way the reference rounds the tie, and the whole channel is enumerated again against the reference's own arithmetic with the
-    // ORIGINAL parameters: equal int8 for every x, and no negative tie left (so the round-half-away instances agree on the adjusted
-    // parameters too).  No neighbour passes (multipliers like 0.25 with integer biases: positive and negative ties all over the
-    // channel): the plan keeps the exact instances and the original parameters.
-    p.int8_floor_ok = !p.int8_exact_pref && !getenv("LCE_PLAN_INT8_EXACT");   // (the env: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
-    p.int8_bias_adjusted = 0;
-    const int32_t x_lo = std::max<int32_t>(0, p.clamp_min), x_hi = (int32_t)std::min<int64_t>(2 * (int64_t)p.backtransform_add, p.clamp_max);
-    const bool even_only = cin_g % 2 == 0;   // (an odd channel count under zero padding: border pixels drop an odd number of terms)
-    auto sat8_half_away = [](float y) { const float r = std::round(y); return (int)std::max(-128.0f, std::min(127.0f, r)); };
-    // The accumulator values a channel is checked on, in order: x_lo, the even values above it, x_hi.  y is monotone in x (each rounding
-    // is), so the values whose y lies strictly inside the clamps are one run of them -- found by bisection -- and every value outside
-    // it produces the clamp itself: the run, one value either side of it and the two ends are all that needs checking.
-    const int32_t first_even = even_only ? ((x_lo + 2) & ~1) : x_lo + 1;
-    const int32_t n_mid = even_only ? (x_hi > first_even ? (x_hi - 1 - first_even) / 2 + 1 : 0) : std::max(0, x_hi - 1 - x_lo);
-    const int32_t n_x = x_hi > x_lo ? n_mid + 2 : 1;
-    auto x_at = [&](int32_t k) { return k == 0 ? x_lo : k == n_x - 1 ? x_hi : first_even + (even_only ? 2 : 1) * (k - 1); };
-    auto inner_run = [&](float mul, float bias, float lo, float hi, int32_t* k0, int32_t* k1) {
-      const bool inc = transformed(mul, bias, x_hi) >= transformed(mul, bias, x_lo);
-      auto below = [&](int32_t k) { const float y = transformed(mul, bias, x_at(k)); return inc ? y <= lo : y >= hi; };        // before the run
-      auto not_past = [&](int32_t k) { const float y = transformed(mul, bias, x_at(k)); return inc ? y < hi : y > lo; };       // before its end
-      int32_t a = 0, b = n_x;
-      while (a < b) { const int32_t m = a + (b - a) / 2; if (below(m)) a = m + 1; else b = m; }
-      *k0 = a;
-      b = n_x;
-      while (a < b) { const int32_t m = a + (b - a) / 2; if (not_past(m)) a = m + 1; else b = m; }
-      *k1 = a;                                                                                                                  // [k0, k1)
-    };
-    const bool check_all = getenv("LCE_PLAN_INT8_FULL") != nullptr;   // (testing aid: every value instead of the run -- tests compare the two)
-    auto channel_ok = [&](int i, float mul, float bias, int32_t* bad_x) {
-      const float a0 = transformed(mul, bias, p.clamp_min), a1 = transformed(mul, bias, p.clamp_max);
-      if (!(a0 == a0) || !(a1 == a1)) return false;
-      const float lo = std::max(-128.0f, std::min(127.0f, std::min(a0, a1))), hi = std::max(-128.0f, std::min(127.0f, std::max(a0, a1)));
-      auto value_ok = [&](int32_t x) {
-        float yc = transformed(mul, bias, x);
-        yc = yc < lo ? lo : (yc > hi ? hi : yc);
-        const bool negative_tie = yc < 0.0f && yc - std::floor(yc) == 0.5f;
-        if (!(yc == yc) || negative_tie ||      // (NaN: infinite multipliers -- unspecified in the reference, the exact instances)
-            (int)std::floor((double)yc + 0.5) != sat8_half_away(transformed(p.mul[i], p.bias[i], x))) {
-          if (bad_x) *bad_x = x;
-          return false;
-        }
-        return true;
-      };
-      // the run inside the candidate's clamps and the run inside int8's range under the reference's parameters, one value either side
-      int32_t k0, k1, r0, r1;
-      inner_run(mul, bias, lo, hi, &k0, &k1);
-      inner_run(p.mul[i], p.bias[i], -128.5f, 127.5f, &r0, &r1);
-      k0 = std::max(0, std::min(k0, r0) - 1);
-      k1 = std::min(n_x, std::max(k1, r1) + 1);
-      if (check_all) { k0 = 0; k1 = n_x; }
-      if (!value_ok(x_lo) || !value_ok(x_hi)) return false;
-      for (int32_t k = k0; k < k1; ++k)
-        if (!value_ok(x_at(k))) return false;
-      return true;
-    };
-    struct Adjusted { int i; float mul, bias; };
-    std::vector<Adjusted> adjusted;
-    for (int i = 0; i < n && p.int8_floor_ok; ++i) {
-      int32_t bad = 0;
-      if (channel_ok(i, p.mul[i], p.bias[i], &bad)) continue;
-      // the grid step of y around the tie: the coarser of the product's and the bias's ulp (a smaller step is absorbed by the sum's rounding)
-      const float y_bad = transformed(p.mul[i], p.bias[i], bad), pr_bad = std::fabs((float)bad * p.mul[i]);
-      const float big = std::max(std::max(pr_bad, std::fabs(p.bias[i])), std::fabs(y_bad));
-      const float step = std::max(std::nextafter(big, INFINITY) - big, std::ldexp(1.0f, -20));
-      bool found = false;
-      for (int dm = 0; dm <= 4 && !found; ++dm) {            // multiplier: 0, +1, -1, +2, -2 ulps
-        float m2 = p.mul[i];
-        for (int s = 0; s < (dm + 1) / 2; ++s) m2 = std::nextafter(m2, (dm & 1) ? INFINITY : -INFINITY);
-        for (int k = dm == 0 ? 1 : 0; k <= 4 && !found; ++k) {
-          const float b2 = p.bias[i] - (float)k * step;
-          if (channel_ok(i, m2, b2, nullptr)) { adjusted.push_back({i, m2, b2}); found = true; }
-        }
-      }
-      if (!found) {
-        if (getenv("LCE_PLAN_DEBUG"))
-          fprintf(stderr, "[lce plan] int8: channel %d, accumulator %d -> y = %.9g: an exact negative tie that no neighbouring (multiplier, bias) resolves, round-half-away instances\n",
-                  i, bad, (double)y_bad);
-        p.int8_floor_ok = false;
-      }
-    }
-    if (p.int8_floor_ok) {
-      for (const auto& a : adjusted) { p.mul_q[a.i] = a.mul; p.bias_q[a.i] = a.bias; set_range(a.i, a.mul, a.bias); }
-      p.int8_bias_adjusted = (int)adjusted.size();
-      if (getenv("LCE_PLAN_DEBUG") && !adjusted.empty()) fprintf(stderr, "[lce plan] int8: floor rounding, %zu channel(s) with adjusted parameters\n", adjusted.size());
-    }
-    return;
-  }
+  if (d.dst_type == LCE_HIP_I8) { prepare_int8_epilogue(p); return; }
   // bit = (accum > thr)  <=>  2*accum > 2*thr, and the kernel's accumulator IS 2*accum (an integer
   // in [0, 2*K_bt]); clamp so the float is exact, keep the always / never cases
   const int64_t a = p.backtransform_add;
@@ -1280,7 +1300,17 @@ static void use_wstream_plan(HostPlan& p) {
   p.kernel_name = nm;
 }
 
+static std::string select_kernel_impl(HostPlan& p, int64_t pixels);
+
 std::string select_kernel(HostPlan& p, int64_t pixels) {
+  const std::string err = select_kernel_impl(p, pixels);
+  // int8 plans of the matrix-core kernels: the epilogue's constants follow the kernel that was selected (its arithmetic decides what
+  // can be proven); cheap (a bisection per channel), so simply redone at every selection
+  if (err.empty() && p.d.dst_type == LCE_HIP_I8 && p.use_mfma && p.have_weights && !p.wq.empty()) prepare_int8_epilogue(p);
+  return err;
+}
+
+static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
   const lce_hip_bconv2d_desc& d = p.d;
   const bool bp = d.dst_type == LCE_HIP_BITPACKED;
   p.ch = (p.cwg % 4 == 0) ? 4 : (p.cwg % 2 == 0) ? 2 : 1;

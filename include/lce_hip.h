@@ -197,8 +197,9 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *              "stream_pixel_phases", "stream_flat", "compute_units", "wstream_blocks" = "0".."4", "wstream_images": tuning / testing
  *              aids of the two streaming kernels;
  *   "int8_rounding" = "auto" | "exact": int8 outputs of the streaming / weight-streaming / pointwise kernels round with floor(y + 0.5)
- *              (one instruction) on plans where the planner proves that equal to the reference's round-half-away for every value the
- *              accumulator can take (csrc/lce_plan.cpp, pack_for_mfma), with round-half-away otherwise; "exact": always the latter;
+ *              and (the first two) transform with one fma -- one instruction each -- on plans where the planner proves the bytes equal
+ *              to the reference's two roundings + round-half-away for every value the accumulator can take (csrc/lce_plan.cpp,
+ *              prepare_int8_epilogue), and run the reference's own sequence otherwise; "exact": always the latter;
  *   "kernel" = "auto" | "tiled" | "general"                        (valu engine);
  *   "tile"   = "auto" | valu lane tile "4x16"|"2x32"|"2x16"|"1x32"|"1x16"
  *                     | matrix-core block tile "256x256"|"256x128"|"512x64"|"128x256"|"128x128"|"256x64"|"128x64"

@@ -206,6 +206,8 @@ inline float mul_then_add(float a, float b, float c) { volatile float p = a * b;
 inline f32x2 mul_then_add2(f32x2 a, float b, float c) { f32x2 r; r[0] = mul_then_add(a[0], b, c); r[1] = mul_then_add(a[1], b, c); return r; }
 inline f32x2 add2(f32x2 a, f32x2 b) { f32x2 r; { volatile float s = a[0] + b[0]; r[0] = s; } { volatile float s = a[1] + b[1]; r[1] = s; } return r; }
 
+inline float fma1(float a, float b, float c) { return fmaf(a, b, c); }
+inline f32x2 fma2(f32x2 a, float b, float c) { f32x2 r; r[0] = fmaf(a[0], b, c); r[1] = fmaf(a[1], b, c); return r; }
 inline f32x2 mul_then_add_pk(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; r[0] = mul_then_add(a[0], b[0], c[0]); r[1] = mul_then_add(a[1], b[1], c[1]); return r; }
 inline void keep_alive(const u32x4&) {}
 
