@@ -419,7 +419,7 @@ LCE_DEVICE void cvt_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint3
 // The same eight conversions with v_cvt_rpi_i32_f32 = floor(x + 0.5) -- EXACTLY, for every float of magnitude <= 129, plain and in
 // this SDWA byte form (tools/probes/cvt_rpi.hip runs all of them) -- instead of truncation: round-half-up in one instruction per value,
 // no copysign / add in front of it.  Differs from the reference's round-half-AWAY only at exact negative ties, which the planner rules
-// out per plan before it selects a kernel built with it (lce_plan.cpp, int8_floor_rounding_is_exact).
+// out per plan before it selects a kernel built with it (lce_plan.cpp, prepare_int8_epilogue).
 LCE_DEVICE void cvt_rpi_pack8_i8(const f32x4& a, const f32x4& b, uint32_t& lo, uint32_t& hi) {
   asm("v_cvt_rpi_i32_f32_sdwa %0, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"
       "v_cvt_rpi_i32_f32_sdwa %1, %6 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD\n\t"

@@ -89,7 +89,7 @@ struct HostPlan {
   // int8 plans: floor(y + 0.5) equals the reference's round-half-away on EVERY value this plan can produce (no reachable exact negative
   // tie; pack_for_mfma checks every channel x every accumulator value inside the clamps): the streaming kernels' one-instruction rounding
   bool int8_floor_ok = false;
-  int int8_bias_adjusted = 0;       // channels whose bias the floor-rounding proof lowered by a few 2^-17 (lce_plan.cpp, pack_for_mfma)
+  int int8_bias_adjusted = 0;       // channels that the proof of the one-instruction forms gave neighbouring parameters (lce_plan.cpp, prepare_int8_epilogue)
   bool int8_exact_pref = false;            // testing aid (int8_rounding=exact): never take the floor instances
   std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
   int wq_layout = 0;                       // 0: K-major [K-step][K-half][Npad][16 B]; 1: tile-major [Npad/32][K-step][K-half][32][16 B] (wstream)

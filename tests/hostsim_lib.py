@@ -110,7 +110,7 @@ def last_int8_floor() -> int:
 
 
 def last_int8_adjusted() -> int:
-    """Channels of the last int8 plan whose bias the planner's floor-rounding proof lowered (lce_plan.cpp, pack_for_mfma)."""
+    """Channels of the last int8 plan that the planner's proof of the one-instruction forms gave neighbouring parameters (lce_plan.cpp, prepare_int8_epilogue)."""
     return int(lib().hostsim_last_int8_adjusted())
 
 
