@@ -1,6 +1,6 @@
 """The planner's choice against the measured sweep of every candidate kernel (round-4 review, item 5).
 
-profiles/r05/engine_sweep_box*.jsonl (tools/engine_sweep.py, one GPU box each): for the QuickNet / Bi-RealNet 3x3 layers -- stride 1
+profiles/r05/engine_sweep_box*.jsonl, engine_sweep_i8_box*.jsonl (tools/engine_sweep.py, one GPU box each; the int8 rows from the later three): for the QuickNet / Bi-RealNet 3x3 layers -- stride 1
 and the stride-2 layers of config 5 -- at batch 1, 16, 64 and 256 and the three output types, the time of every kernel the planner can
 choose between (block GEMM direct / workspace, the weight-stationary streaming kernel with whole-image and interleaved r-row segments,
 the weight-streaming kernel).  The kernel `auto` picks on the HOST (no GPU needed: selection is host-side) must be within 5 % of the
@@ -21,9 +21,14 @@ LAYERS = {(56, 64, 64, 1), (28, 128, 128, 1), (14, 256, 256, 1), (7, 512, 512, 1
 def _table():
     """{(hw, cin, cout, stride, batch, dst): {kernel name: mean us over the boxes that measured it}}"""
     acc = {}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "engine_sweep_box*.jsonl"))):
+    # the int8 rows: the three boxes measured AFTER the one-instruction int8 forms (DESIGN 4.15) changed the int8 epilogues' cost
+    paths = [(p, None) for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "engine_sweep_box*.jsonl")))]
+    paths += [(p, "i8") for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "engine_sweep_i8_box*.jsonl")))]
+    for path, only in paths:
         for line in open(path):
             r = json.loads(line)
+            if (r["dst"] == "i8") != (only == "i8"):
+                continue
             key = (r["hw"], r["cin"], r["cout"], r["stride"], r["batch"], r["dst"])
             for cand, name in r["kernel"].items():
                 acc.setdefault(key, {}).setdefault(name, []).append(r["us"][cand])

@@ -6,7 +6,7 @@ The table this writes (JSON lines: one per (layer, batch, dst), `us` per candida
 `auto` picks must be within 5 % of the best candidate's time recorded here.  Timed from a captured HIP graph of >= 20
 launches that cycle through > 256 MB of operand sets (bench.py's method for short layers).
 
-usage: engine_sweep.py OUT.jsonl [--quick] [--only HWxCINxCOUT[sS]] ..."""
+usage: engine_sweep.py OUT.jsonl [--quick] [--dst=f32|i8|bp] [--only HWxCINxCOUT[sS]] ..."""
 import importlib
 import json
 import os
@@ -89,6 +89,7 @@ def main():
     out_path = sys.argv[1]
     quick = "--quick" in sys.argv
     only = [a for a in sys.argv[2:] if not a.startswith("--")]
+    dsts = [a.split("=")[1] for a in sys.argv[2:] if a.startswith("--dst=")] or DSTS
     dev = torch.device("cuda:0")
     layers = LAYERS
     if only:
@@ -98,7 +99,7 @@ def main():
     with open(out_path, "a") as f:
         for (hw, cin, cout, st) in layers:
             for b in ([256] if quick else BATCHES):
-                for dname in DSTS:
+                for dname in dsts:
                     layer = SL.Layer(b, hw, hw, cin, 3, 3, cout, stride=st, padding=SL.PADDING_SAME, pad_values=1)
                     row = {"hw": hw, "cin": cin, "cout": cout, "stride": st, "batch": b, "dst": dname, "us": {}, "kernel": {}}
                     seen, cands = {}, []

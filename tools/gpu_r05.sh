@@ -213,5 +213,9 @@ pkf32)
     done
   } > $OUT/ab.txt 2>&1
   ;;
+sweepi8)
+  # the int8 rows of the calibration grid again, after the one-instruction int8 forms changed the int8 epilogues' cost
+  python tools/engine_sweep.py $OUT/engine_sweep_i8.jsonl --dst=i8 > $OUT/log.txt 2>&1; tail -2 $OUT/log.txt | cut -c1-200
+  ;;
 *) echo "unknown part $PART"; exit 2;;
 esac
