@@ -627,21 +627,22 @@ def test_conv_int8_exact_ties_3x3x256(engine, want_kernel):
 
 @pytest.mark.parametrize("engine", ["stream", "wstream", "auto"])
 def test_conv_int8_floor_rounding_with_adjusted_biases(engine):
-    """Round 5: int8 epilogues of the streaming kernels round with one v_cvt_rpi_i32_f32 (floor(y + 0.5)) on plans where the planner
-    proves that equal to round-half-away for every reachable accumulator, after lowering the bias of channels that hold an exact negative
-    tie (lce_plan.cpp, pack_for_mfma; tests/test_hostsim_kernels.py draws the same parameters and checks that adjustments do occur).
+    """Round 5: int8 epilogues of the streaming kernels transform with one fma and round with one v_cvt_rpi_i32_f32 (floor(y + 0.5)) on
+    plans where the planner proves the bytes equal to the reference's for every reachable accumulator, after giving channels that tie or
+    nearly tie neighbouring parameters (lce_plan.cpp, prepare_int8_epilogue; tests/test_hostsim_kernels.py checks that adjustments do occur).
     `int8_rounding=exact` keeps the round-half-away instances; all three must equal the oracle, byte for byte."""
-    spec = O.ConvSpec(2, 14, 14, 256, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1)
-    for seed in range(4):
-        rng = np.random.default_rng(900 + seed)
-        x, w, _, _ = synth.conv_inputs(spec, seed)
-        mul = rng.uniform(0.02, 0.09, 96).astype(np.float32) * rng.choice([-1.0, 1.0], 96).astype(np.float32)
-        bias = rng.uniform(-20.0, 20.0, 96).astype(np.float32)
-        want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=0.73, out_zero_point=3)
-        got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=0.73, zp=3, engine=engine)
-        assert np.array_equal(got, want), (seed, name)
-        got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=0.73, zp=3, engine=engine, opts=(("int8_rounding", "exact"),))
-        assert np.array_equal(got, want), (seed, name, "exact")
+    for cin, act, mul_hi, scale in ((256, O.ACT_NONE, 0.09, 0.73), (128, O.ACT_RELU, 1.5, 0.125), (512, O.ACT_RELU6, 0.4, 0.21)):
+        spec = O.ConvSpec(2, 14, 14, cin, 3, 3, 96, padding=O.PADDING_SAME, pad_values=1, activation=act)
+        for seed in range(4):
+            rng = np.random.default_rng(900 + seed)
+            x, w, _, _ = synth.conv_inputs(spec, seed)
+            mul = rng.uniform(0.02, mul_hi, 96).astype(np.float32) * rng.choice([-1.0, 1.0], 96).astype(np.float32)
+            bias = rng.uniform(-20.0, 20.0, 96).astype(np.float32)
+            want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=3)
+            got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=3, engine=engine)
+            assert np.array_equal(got, want), (cin, seed, name)
+            got, name = _gpu_conv(spec, amd.I8, x, w, mul, bias, scale=scale, zp=3, engine=engine, opts=(("int8_rounding", "exact"),))
+            assert np.array_equal(got, want), (cin, seed, name, "exact")
 
 
 def test_conv_adversarial_words():
