@@ -710,7 +710,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       if (lce_hip_status s = mfma_selftest_once(plan->device, 2)) return s;
       const lce::WsArgs G = lce::make_ws_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
-      lce::wstream_fn fn = lce::lookup_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, with_sign, h.int8_floor_ok);
+      lce::wstream_fn fn = lce::lookup_wstream(h.d.dst_type, lce::stream_chunks(h.d), h.ws_nb, with_sign, h.int8_floor_ok);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::wstream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {
@@ -727,7 +727,7 @@ static lce_hip_status run_images(lce_hip_bconv2d_plan* plan, const int32_t* inpu
       if (lce_hip_status s = mfma_selftest_once(plan->device, 1)) return s;
       const lce::StreamArgs G = lce::make_stream_args(h, nb);
       const bool with_sign = sgn != nullptr && h.d.dst_type != LCE_HIP_BITPACKED;
-      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, lce::stream_fast(G), lce::stream_clamps(G), with_sign, G.NSTRIP > 1, h.int8_floor_ok);
+      lce::stream_fn fn = lce::lookup_stream(h.d.dst_type, lce::stream_chunks(h.d), lce::stream_fast(G), lce::stream_clamps(G), with_sign, G.NSTRIP > 1, h.int8_floor_ok);
       if (!fn) return fail(LCE_HIP_ERR_UNSUPPORTED, "bconv2d_run: no kernel instance for %s", h.kernel_name.c_str());
       const size_t lds = (size_t)lce::stream_lds_bytes(h);
       if (lds > 64 * 1024 && plan->lds_opt_in != (void*)fn) {

@@ -49,7 +49,9 @@ int mfma_selftest_pointwise();
 int mfma_selftest_stream();
 
 // the streaming kernel's FAST variant's precondition (lce_kernels_stream.h)
-inline bool stream_fast(const StreamArgs& G) { return G.Cin % 64 == 0 && !G.zero_border; }
+inline bool stream_fast(const StreamArgs& G) {     // (64 / 128 / 256 / 512 channels: 192 runs the 256-channel instance, two of whose words do not exist)
+  return (G.Cin == 64 || G.Cin == 128 || G.Cin == 256 || G.Cin == 512) && !G.zero_border;
+}
 // its clamp is the identity on [0, 2 * K_bt] (activation NONE)
 inline bool stream_clamps(const StreamArgs& G) { return !(G.cmin <= 0.0f && G.cmax >= 2.0f * G.a_bt); }
 

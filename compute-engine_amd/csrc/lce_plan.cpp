@@ -337,7 +337,7 @@ bool stream_supported(const HostPlan& p) {
   // a lane stores 16 bytes of one pixel's channels: whole groups of 4 floats / 16 int8 only
   if (d.dst_type == LCE_HIP_F32 && d.channels_out % 4) return false;
   if (d.dst_type == LCE_HIP_I8 && d.channels_out % 16) return false;
-  const int kch = ceil_div(d.channels_in, 64);
+  const int kch = stream_chunks(d);
   // the filter bank must fit the register file: up to 4 chunks of 64 input channels per wave, or 8 split over a pair of
   // waves (KSPLIT, lce_kernels_stream.h)
   return kch == 1 || kch == 2 || kch == 4 || kch == 8;
@@ -353,7 +353,7 @@ static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, boo
   const lce_hip_bconv2d_desc& d = p.d;
   const int kh = d.filter_height, sh = d.stride_height;
   const int srs = (rs - 1) * sh + kh, pbs = ceil_div(rs * ow, 32);
-  const int cpw = ceil_div(d.channels_in, 64) * 2, qg = ceil_div(cpw, 4);
+  const int cpw = stream_chunks(d) * 2, qg = ceil_div(cpw, 4);
   const int64_t ipr = (int64_t)in_w * qg;
   const int pph = 1 << pph_log;
   const int64_t npx = (int64_t)rs * ow;
@@ -413,8 +413,8 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
 std::string plan_stream(HostPlan& p, int batch_chunk) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!stream_supported(p))
-    return "bconv2d: the streaming kernel runs ungrouped 3x3 convolutions without dilation, with at most 256 input "
-           "channels (64, 128 or 256 after padding; 512 on the K-split variant) and whole 16-byte groups of output channels (float: a multiple of 4, "
+    return "bconv2d: the streaming kernel runs ungrouped 3x3 convolutions without dilation, with at most 512 input "
+           "channels (on its 64-, 128-, 256- or 512-channel instance) and whole 16-byte groups of output channels (float: a multiple of 4, "
            "int8: of 16), and not the SAME-zero correction semantics";
   const uint32_t row_bytes = stream_row_bytes(p);
   if ((int64_t)batch_chunk * p.out_h * p.out_w * row_bytes >= (1ll << 31))
@@ -424,9 +424,9 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
   std::vector<int> widths;
   if (p.stream_strip_pref <= 0) widths.push_back(0);
   // (a strip width forced on a layer whose bank is not the 256-channel one: say so, instead of "the ring does not fit")
-  if (p.stream_strip_pref > 0 && ceil_div(d.channels_in, 64) != 4)
+  if (p.stream_strip_pref > 0 && stream_chunks(d) != 4)
     return "bconv2d: stream_strip: column strips exist for the 256-channel filter bank only (193..256 input channels)";
-  if (ceil_div(d.channels_in, 64) == 4 && p.stream_strip_pref != 0) {
+  if (stream_chunks(d) == 4 && p.stream_strip_pref != 0) {
     if (p.stream_strip_pref > 0) {
       if (p.stream_strip_pref % 32 != 0 || p.out_w % p.stream_strip_pref != 0)
         return "bconv2d: stream_strip must be a multiple of 32 that divides the output width";
@@ -461,7 +461,7 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
   const int nslb = ksplit ? 2 : 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
   const int wp = strips ? in_w_seg
                         : (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
-  const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16;
+  const int kch = stream_chunks(d), ps = kch * 32 + 16;
   // Ring row pitch.  An A-fragment read is one 16-byte piece per lane, lane = pixel; the LDS serves 16 lanes per pass without
   // conflicts when their 16-byte units differ mod 16.  Along a row consecutive pixels are ps / 16 (odd) units apart: fine.
   // Where a 32-pixel block wraps to the next output row the unit jumps by pitch / 16 - (OW - 1) * SW * ps / 16 instead, and
@@ -649,7 +649,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
 // ------------------------------------------------------------------------------------
 bool wstream_supported(const HostPlan& p) {
   if (!stream_supported(p)) return false;                     // 3x3, no dilation, no groups, whole 16-byte channel groups, not the correction semantics
-  const int kch = ceil_div(p.d.channels_in, 64);
+  const int kch = stream_chunks(p.d);
   return kch == 2 || kch == 4 || kch == 8;                    // the instantiated K depths (128 / 256 / 512 input channels)
 }
 
@@ -674,12 +674,12 @@ static int64_t wstream_cost(int64_t blocks, int cus, int occupancy, const std::v
 std::string plan_wstream(HostPlan& p, int batch_chunk) {
   const lce_hip_bconv2d_desc& d = p.d;
   if (!wstream_supported(p))
-    return "bconv2d: the weight-streaming kernel runs ungrouped 3x3 convolutions without dilation over 128, 256 or 512 input channels "
-           "(after padding to 64) and whole 16-byte groups of output channels (float: a multiple of 4, int8: of 16), and not the "
+    return "bconv2d: the weight-streaming kernel runs ungrouped 3x3 convolutions without dilation over 65 .. 512 input channels "
+           "(on its 128-, 256- or 512-channel instance) and whole 16-byte groups of output channels (float: a multiple of 4, int8: of 16), and not the "
            "SAME-zero correction semantics";
   if ((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p) >= (1ll << 31))
     return "bconv2d: the weight-streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
-  const int kch = ceil_div(d.channels_in, 64), ps = kch * 32 + 16, ks = 9 * kch;
+  const int kch = stream_chunks(d), ps = kch * 32 + 16, ks = 9 * kch;
   const int hp = (p.out_h - 1) * d.stride_height + d.filter_height, wp = (p.out_w - 1) * d.stride_width + d.filter_width;
   // row pitch: a skew of < 256 bytes so that a 32-pixel block that wraps to the next output row keeps hitting distinct LDS banks
   // (the streaming kernel's rule, plan_stream_geometry)
@@ -932,7 +932,7 @@ static void pack_for_mfma(HostPlan& p) {
   const int taps = d.filter_height * d.filter_width, n = d.channels_out;
   const int bn = p.mfma.bn();
   const int cin_g = d.channels_in / d.groups;
-  p.cpad = ceil_div(d.channels_in, 64) * 64;
+  p.cpad = ((p.use_stream || p.use_wstream) ? stream_chunks(d) : ceil_div(d.channels_in, 64)) * 64;   // (the streaming family's instances: 64 / 128 / 256 / 512)
   p.npad = ceil_div(n, bn) * bn;
   p.kch = d.groups > 1 ? group_chunks(d) : p.cpad / 64;
   const int kch = p.kch, ks_total = taps * kch;
@@ -1182,7 +1182,7 @@ static int64_t out_bytes_of(const HostPlan& p, int batch_chunk) {
 // The weight-stationary streaming kernel as plan_stream has just planned it (st_* fields) for launches of batch_chunk images.
 static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
   using namespace cost;
-  const int kch = ceil_div(p.d.channels_in, 64);
+  const int kch = stream_chunks(p.d);
   const bool ksplit = stream_ksplit(p);
   const double bank_kib = ksplit ? 288.0 : 72.0 * kch;                       // 4 waves x K-steps x 2 fragments x 1 KiB
   const int64_t blocks = (int64_t)p.st_gx * p.st_ny, cus = std::max(1, p.num_cus);
@@ -1217,13 +1217,18 @@ static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
   if (getenv("LCE_PLAN_DEBUG") && getenv("LCE_PLAN_DEBUG")[0] == '2')
     fprintf(stderr, "[lce plan]   rows %d il %d: blocks %lld usteps %lld prologue %.2f step %.2f production %.2f partial %.2f compute %.2f store %.2f\n", p.st_rs, p.st_gstr > 1,
             (long long)blocks, (long long)usteps, prologue_us, step_us, production_us, partial_us, compute_us, store_us);
-  return std::max(compute_us, store_us);
+  // An instance wider than the layer (129..192 channels on the 256-channel bank, 257..448 on the 512-channel one): the expansion takes
+  // the general path (word-by-word loads, partial planes) and the K loop multiplies the padding -- measured on 40x40x192 / 20x20x320 at
+  // batch 1 .. 256 (profiles/r05/engine_sweep_padded_channels.jsonl): +2 us and 5 %, on the K-split instance +4 us and 20 %.
+  const bool padded = p.d.channels_in != 64 * kch && p.d.channels_in > 32 * kch;
+  const double us = std::max(compute_us, store_us);
+  return padded ? (ksplit ? 1.2 * us + 4.0 : 1.05 * us + 2.0) : us;
 }
 
 // The weight-streaming kernel as plan_wstream has just planned it (ws_* fields).
 static double estimate_wstream_us(const HostPlan& p, int batch_chunk) {
   using namespace cost;
-  const int kch = ceil_div(p.d.channels_in, 64), ks = 9 * kch, cus = std::max(1, p.num_cus);
+  const int kch = stream_chunks(p.d), ks = 9 * kch, cus = std::max(1, p.num_cus);
   const int groups = ceil_div(batch_chunk, p.ws_ipb);
   // blocks are dispatched in index order (part-major), round-robin over the CUs: pixel blocks on the busiest CU
   std::vector<int64_t> load(cus, 0);
@@ -1283,20 +1288,20 @@ struct StreamCandidate { int rows, interleave; double us; };
 static void use_wstream_plan(HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
   const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
-  const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 1;
+  const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 1 || p.kch != stream_chunks(d);
   p.wq_layout = 1;                       // tile-major: [32-channel tile][K-step][K-half][32 x 16 B] (pack_for_mfma)
   p.mfma = want;
   p.use_mfma = true;
   p.use_wstream = true;
   p.use_stream = false;
   p.use_tiled = false;
-  p.cpad = ceil_div(d.channels_in, 64) * 64;
+  p.cpad = stream_chunks(d) * 64;
   p.npad = ceil_div(d.channels_out, 64) * 64;
   p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height, (int64_t)(p.out_h - 1) * d.stride_height + d.filter_height);
   if (repack && p.have_weights) pack_for_mfma(p);
   char nm[96];
   snprintf(nm, sizeof nm, "bconv2d_wstream<%s,3x3x%d,images%d,blocks%d>",
-           d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.ws_ipb, p.ws_nb);
+           d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * stream_chunks(d), p.ws_ipb, p.ws_nb);
   p.kernel_name = nm;
 }
 
@@ -1392,13 +1397,13 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       p.stream_interleave_pref = il_pref;
       if (!err.empty()) return err;     // (cannot happen: the same plan succeeded a moment ago)
       const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
-      const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0;
+      const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0 || p.kch != stream_chunks(d);
       p.wq_layout = 0;
       p.mfma = want;
       p.use_mfma = true;
       p.use_stream = true;
       p.use_tiled = false;
-      p.cpad = ceil_div(d.channels_in, 64) * 64;
+      p.cpad = stream_chunks(d) * 64;
       p.npad = ceil_div(d.channels_out, 64) * 64;
       p.hp = (int)std::max<int64_t>(p.pad_h + d.in_height, (int64_t)(p.out_h - 1) * d.stride_height + d.filter_height);
       if (repack && p.have_weights) pack_for_mfma(p);
@@ -1408,7 +1413,7 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       if (p.st_nstrip > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",strips%d", p.st_wso);
       if (p.st_gstr > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",il");
       snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d%s>",
-               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * ceil_div(d.channels_in, 64), p.st_rs, ph);
+               d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * stream_chunks(d), p.st_rs, ph);
       p.kernel_name = nm;
       return "";
     }
@@ -1445,7 +1450,7 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
         if (!direct) direct = true;  // reported below by direct_geometry
       }
     }
-    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0;
+    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0 || p.kch != (d.groups > 1 ? group_chunks(d) : ceil_div(d.channels_in, 64));
     p.wq_layout = 0;
     p.mfma = want;
     p.cpad = ceil_div(d.channels_in, 64) * 64;

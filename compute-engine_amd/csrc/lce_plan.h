@@ -183,7 +183,14 @@ constexpr int kStreamLdsExtra = 4 * 8192 + 4096;   // four waves' epilogue scrat
 // K-split (512 input channels): 4-KiB scratch per wave (it transposes 32 channels, not 64), the dump area, and two 4-KiB inbox
 // slots per wave for the pair's partial sums
 constexpr int kStreamLdsExtraKsplit = 4 * 4096 + 4096 + 4 * 8192;
-inline bool stream_ksplit(const HostPlan& p) { return (p.d.channels_in + 63) / 64 > 4; }
+// 64-channel chunks per tap of the streaming family's INSTANCE that runs the layer: 1, 2, 4 or 8 (its register-resident filter bank is
+// built for those; 129..192 input channels run the 256-channel instance -- the fourth chunk's codes are 0 and contribute nothing --,
+// 257..448 the 512-channel one).  0: more than 512 input channels.
+inline int stream_chunks(const lce_hip_bconv2d_desc& d) {
+  const int c = (d.channels_in + 63) / 64;
+  return c <= 2 ? c : c <= 4 ? 4 : c <= 8 ? 8 : 0;
+}
+inline bool stream_ksplit(const HostPlan& p) { return stream_chunks(p.d) > 4; }
 inline int stream_lds_extra(const HostPlan& p) { return stream_ksplit(p) ? kStreamLdsExtraKsplit : kStreamLdsExtra + 1024; }   // (+ the strips' segment table)
 inline int stream_lds_bytes(const HostPlan& p) { return p.st_ring_bytes + stream_lds_extra(p); }
 

@@ -186,9 +186,9 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *              ungrouped layers of any stride, 64 / 128 / 256 / 512 input channels after padding to 64, a multiple
  *              of 32 output channels: filter bank
  *              in registers, waves stream 32-pixel tiles; what "auto" picks for such layers)
- *              | "stream" (ungrouped 3x3 layers without dilation, 64 / 128 / 256 / 512 input channels after padding: persistent
+ *              | "stream" (ungrouped 3x3 layers without dilation, up to 512 input channels -- on the 64- / 128- / 256- / 512-channel instance: persistent
  *              blocks, the filter bank resident in registers, input rows expanded once into an LDS ring; its cheapest variant by the
- *              planner's estimate) | "wstream" (the same layers from 128 input channels on: activations stationary in LDS, weights
+ *              planner's estimate) | "wstream" (the same layers from 65 input channels on: activations stationary in LDS, weights
  *              streamed into registers during the K loop; for launches of a few block steps).  "auto" prices every kernel that can
  *              run the layer -- the streaming kernel's variants, the weight-streaming kernel, the block GEMM -- and takes the
  *              cheapest (csrc/lce_plan.cpp, estimate_*_us; LCE_PLAN_DEBUG=1 in the environment prints the prices);

@@ -146,7 +146,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     if (h.use_mfma && h.use_wstream) {
       const WsArgs G = make_ws_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      wstream_fn fn = find_wstream(h.d.dst_type, (h.d.channels_in + 63) / 64, h.ws_nb, sgn != nullptr, h.int8_floor_ok);
+      wstream_fn fn = find_wstream(h.d.dst_type, stream_chunks(h.d), h.ws_nb, sgn != nullptr, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
@@ -158,7 +158,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     } else if (h.use_mfma && h.use_stream) {
       const StreamArgs G = make_stream_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      stream_fn fn = find_stream(h.d.dst_type, (h.d.channels_in + 63) / 64, stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1, h.int8_floor_ok);
+      stream_fn fn = find_stream(h.d.dst_type, stream_chunks(h.d), stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);

@@ -572,6 +572,10 @@ STREAM_SHAPES = [
     (2, 11, 9, 200, 304, (2, 2), "ONE", O.ACT_NONE, 2, 0),      # strides; 304 channels: two channel groups (grid.y)
     (3, 10, 12, 256, 192, (1, 2), "ONE", O.ACT_NONE, 2, 5),
     (2, 13, 37, 64, 64, (2, 1), "VALID", O.ACT_RELU6, 3, 0),
+    (2, 10, 9, 192, 96, (1, 1), "ONE", O.ACT_NONE, 2, 0),       # 192 input channels on the 256-channel instance (the fourth chunk: codes 0)
+    (2, 9, 10, 320, 128, (1, 1), "ONE", O.ACT_RELU, 2, 0),      # 320 (and 384, 448) on the 512-channel K-split instance
+    (3, 7, 7, 384, 64, (1, 1), "SAME", O.ACT_NONE, 1, 0),       # ... with the exact SAME-zero border, flat blocks
+    (2, 8, 8, 448, 192, (2, 2), "ONE", O.ACT_NONE, 2, 0),
 ]
 
 
@@ -737,6 +741,8 @@ WSTREAM_SHAPES = [
     (2, 10, 12, 256, 192, (1, 2), "VALID", O.ACT_NONE, 3, (0,)),      # VALID padding, column stride 2
     (1, 4, 4, 512, 256, (1, 1), "ONE", O.ACT_NONE, 8, (0,)),          # a single half-empty pixel block
     (2, 4, 4, 128, 16, (1, 1), "SAME", O.ACT_RELU, 2, (0,)),          # sixteen output channels: one wave, a quarter of its slice
+    (2, 9, 8, 192, 128, (1, 1), "ONE", O.ACT_NONE, 2, (0,)),          # 192 input channels on the 256-channel instance
+    (2, 7, 7, 320, 256, (1, 1), "ONE", O.ACT_RELU, 2, (0, 1)),        # 320 on the 512-channel one
 ]
 
 
@@ -887,7 +893,7 @@ def test_int8_floor_proof_by_bisection_equals_the_full_enumeration(monkeypatch):
 
 def test_wstream_kernel_refuses_what_it_cannot_run():
     for spec, why in [
-        (O.ConvSpec(1, 6, 6, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "128, 256 or 512 input channels"),
+        (O.ConvSpec(1, 6, 6, 64, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "65 .. 512 input channels"),
         (O.ConvSpec(1, 6, 6, 256, 1, 1, 64), "3x3"),
         (O.ConvSpec(1, 120, 120, 256, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "does not fit"),     # one image: 122 x 122 x 144 B
     ]:
@@ -901,7 +907,7 @@ def test_stream_kernel_refuses_what_it_cannot_run():
     for spec, why in [
         (O.ConvSpec(1, 6, 6, 64, 3, 3, 70, padding=O.PADDING_SAME, pad_values=1), "16-byte groups"),      # float: Cout % 4
         (O.ConvSpec(1, 6, 6, 64, 1, 1, 64), "3x3"),
-        (O.ConvSpec(1, 6, 6, 320, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "256 after padding"),
+        (O.ConvSpec(1, 6, 6, 576, 3, 3, 64, padding=O.PADDING_SAME, pad_values=1), "at most 512 input"),
         (O.ConvSpec(1, 8, 8, 64, 3, 3, 64, 1, 1, 1, 2, 2, O.PADDING_SAME, 1), "dilation"),
         (O.ConvSpec(1, 6, 6, 128, 3, 3, 128, 2, padding=O.PADDING_SAME, pad_values=1), "ungrouped"),
     ]:

@@ -27,6 +27,7 @@ LAYERS = [  # (H = W, Cin, Cout, stride)
     (56, 64, 128, 2), (28, 128, 256, 2), (14, 256, 512, 2), (7, 512, 512, 2),         # config 5's strided layers
     (28, 256, 256, 1), (14, 512, 512, 1), (14, 128, 128, 1), (7, 256, 256, 1),        # off the bench's grid
     (40, 192, 192, 1), (20, 320, 320, 1), (112, 64, 64, 1),
+    (14, 192, 192, 1), (7, 384, 384, 1), (28, 160, 160, 1),                           # between the streaming family's instances, small images
 ]
 BATCHES = [1, 16, 64, 256]
 DSTS = ["f32", "i8", "bp"]
