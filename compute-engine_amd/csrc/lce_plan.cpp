@@ -265,7 +265,10 @@ bool pointwise_supported(const HostPlan& p, int64_t pixels, int* nc, int* nj) {
   if (d.groups != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
   if (p.out_h != (d.in_height - 1) / d.stride_height + 1 || p.out_w != (d.in_width - 1) / d.stride_width + 1) return false;
   if (d.channels_out % 32 != 0) return false;
-  const int c = ceil_div(d.channels_in, 64);
+  int c = ceil_div(d.channels_in, 64);
+  // (129..192 channels: the four-K-step instances -- the fourth step's activations are masked to code 0 as a partial last step is, and its
+  //  weights lie past the end of the three-step image: the range check returns zeros)
+  if (c == 3) c = 4;
   if (c != 1 && c != 2 && c != 4 && c != 8) return false;
   const int t = d.channels_out / 32;
   int j = t % 4 == 0 ? 4 : t % 2 == 0 ? 2 : 1;

@@ -817,6 +817,25 @@ def test_streaming_family_on_channel_counts_between_its_instances(shape, engine)
             assert rname.startswith("bconv2d_mfma") and np.array_equal(ref.view(np.uint8), got.view(np.uint8)), rname
 
 
+@pytest.mark.parametrize("shape", [(64, 28, 192, 128, 1), (32, 14, 160, 256, 2), (128, 7, 130, 64, 1)], ids=lambda s: "%dx%dx%dx%d_s%d" % s)
+def test_pointwise_kernel_on_129_to_192_channels(shape):
+    """Round 5: 1x1 layers with 129..192 input channels run the pointwise kernel's four-K-step instances (the fourth step is empty: masked
+    activations, weights past the end of the image read as zeros).  All images, three output types, vs the oracle."""
+    b, hw, cin, cout, st = shape
+    spec = O.ConvSpec(b, hw, hw, cin, 1, 1, cout, 1, st, st, 1, 1, O.PADDING_VALID, 0, O.ACT_RELU, O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, b + hw + cin, negative_mul_fraction=0.25)
+    thr = O.thresholds_converter(spec, mul, bias)
+    scale, zp = synth.int8_quant_params(hw + cin)
+    for dst, odst in ((amd.F32, O.DST_F32), (amd.I8, O.DST_I8), (amd.BITPACKED, O.DST_BITPACKED)):
+        kw = dict(mul=mul, bias=bias) if dst != amd.BITPACKED else dict(thr=thr)
+        if dst == amd.I8:
+            kw.update(scale=scale, zp=zp)
+        got, name = _gpu_conv(spec, dst, x, w, engine="pointwise", **kw)
+        assert name.startswith("bconv2d_pointwise<") and ",K4x64," in name.replace("<", ",") , name
+        want = O.bconv2d(spec, odst, x, w, mul, bias, thresholds=thr, out_scale=float(scale), out_zero_point=zp, threads=NTHREADS)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), name
+
+
 @pytest.mark.parametrize("shape", [(256, 28, 128, 128, 1, 4), (256, 56, 64, 128, 2, 4), (256, 56, 256, 256, 1, 8), (201, 28, 128, 128, 1, 7)],
                          ids=lambda s: "%dx%dx%dx%d_s%d_rows%d" % s)
 def test_streaming_kernel_interleaved_runs_full_size(shape):

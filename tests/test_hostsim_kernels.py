@@ -256,7 +256,7 @@ def test_mfma_engine_batch_chunking_and_pointwise():
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (128, 128), (256, 256), (32, 64), (96, 96), (40, 160), (200, 64), (256, 32),
-                                      (512, 64), (480, 128), (449, 32)])
+                                      (512, 64), (480, 128), (449, 32), (192, 64), (160, 96), (130, 32)])     # (129..192: the fourth K-step is empty)
 @pytest.mark.parametrize("act", [O.ACT_NONE, O.ACT_RELU], ids=["none", "relu"])
 def test_pointwise_streaming_kernel(cin, cout, act):
     """The 1x1 streaming kernel (lce_kernels_pointwise.h; filter bank in registers, waves walking 32-pixel tiles
@@ -282,7 +282,7 @@ def test_pointwise_streaming_kernel(cin, cout, act):
         H.set_pointwise(0)
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 256), (200, 96), (512, 128)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 256), (200, 96), (512, 128), (192, 128)])
 @pytest.mark.parametrize("stride", [(2, 2), (1, 2), (3, 2)], ids=lambda s: "s%dx%d" % s)
 def test_pointwise_kernel_strided(cin, cout, stride):
     """Strided 1x1 layers (the shortcut convolutions of ResNet-style binary nets): output pixel (b, oy, ox) reads input
