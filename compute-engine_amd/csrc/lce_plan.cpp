@@ -1440,7 +1440,15 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
     } else if (p.engine_pref != 2) {
       // auto / engine=direct without a tile: the direct variant when a good tile exists
       MfmaCfg dc;
-      if (choose_direct_cfg(p, &dc)) {
+      // (auto: a launch of at most half a round of blocks with a deep K loop -- >= 27 K-steps: 3x3 over 192+ channels -- runs at the
+      //  latency of one block's K loop, and the workspace GEMM's is shorter: its A fragments come from the expanded workspace, no halo
+      //  expansion in front of the first MFMA.  profiles/r05/engine_sweep_*.jsonl, batch 1 / 16: direct / workspace = 1.03 ... 1.26 on
+      //  every such row, 0.99 at worst; with more blocks the direct variant wins by 10 ... 50 %.)
+      const int ks_deep = d.filter_height * d.filter_width * ceil_div(d.channels_in / std::max(1, d.groups), 64);
+      auto tiny_deep = [&](const MfmaCfg& c) {
+        return p.engine_pref == 0 && ks_deep >= 27 && ((pixels + c.bm() - 1) / c.bm()) * ceil_div(d.channels_out, c.bn()) <= 128;
+      };
+      if (choose_direct_cfg(p, &dc) && !tiny_deep(dc)) {
         want = dc;
         direct = true;
       } else if (p.engine_pref == 3) {
