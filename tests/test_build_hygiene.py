@@ -6,6 +6,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "compute-engine_amd", "csrc")
 STRUCTURAL = {"LCE_USE_SYSTEM_TFLITE", "LCE_EXPERIMENT", "LCE_PRODUCT_BUILD", "LCE_HAS_EXPERIMENT_SWITCH"}
@@ -60,3 +62,19 @@ def test_a_stray_switch_is_a_compile_error():
         assert r.returncode != 0 and "LCE_EXPERIMENT" in r.stderr, sw
         assert cc("-DLCE_EXPERIMENT", "-D" + sw).returncode == 0, sw
     assert cc("-DLCE_PRODUCT_BUILD", "-DLCE_EXPERIMENT").returncode != 0
+
+
+@pytest.mark.parametrize("tu", ["lce_tu_stream", "lce_tu_wstream", "lce_tu_pointwise"])
+def test_no_streaming_kernel_instance_uses_scratch_memory(tu):
+    """Round 5 (review item 7): the code objects of the built product library -- their own metadata, tools/co_resources.py -- hold no
+    kernel of the streaming families with a private-segment (scratch) size above 0: no VGPR spill goes to memory."""
+    import subprocess
+    import sys
+    obj = os.path.join(ROOT, "compute-engine_amd", "csrc", "obj", tu + ".o")
+    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("the product library's objects / the LLVM tools are not here")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "co_resources.py"), obj], capture_output=True, text=True, check=True).stdout
+    rows = [l for l in out.splitlines() if " scratch " in l]
+    assert len(rows) >= 40, out[-400:]
+    bad = [l for l in rows if int(l.split(" scratch ")[1].split()[0]) != 0]
+    assert not bad, "\n".join(bad)
