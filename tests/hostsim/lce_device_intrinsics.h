@@ -92,7 +92,7 @@ inline thread_local ThreadCtx* g_ctxp = &g_main_ctx;  // the running fiber's
 #define g_ctx (*::lce_dev::g_ctxp)
 
 struct FiberSet {
-  static constexpr size_t kStack = 4u << 20;          // per fiber, reserved lazily
+  static constexpr size_t kStack = 1u << 20;          // per fiber, reserved lazily; its lowest page is a guard (an overflow faults instead of running into the neighbour)
   struct Fiber { void* sp = nullptr; ThreadCtx ctx; bool done = false; };
   std::vector<Fiber> f;
   std::function<void(int)> body;
@@ -147,6 +147,7 @@ inline void run_fibers(int n, Setup&& setup, std::function<void(int)> body) {
   if (s.stacks == (uint8_t*)MAP_FAILED) __builtin_trap();
   for (int t = 0; t < n; ++t) {
     setup(t, s.f[t].ctx);
+    mprotect(s.stacks + (size_t)t * FiberSet::kStack, 4096, PROT_NONE);
     // the frame lce_fiber_switch pops: six callee-saved registers, then the entry point as its return address; above it one slot
     // so that the entry point starts with the stack alignment of a called function
     uint64_t* top = (uint64_t*)(s.stacks + (size_t)(t + 1) * FiberSet::kStack);
