@@ -12,7 +12,8 @@ obj = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 with tempfile.TemporaryDirectory() as d:
     fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
-    subprocess.run([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+    # (an explicit output file: without one llvm-objcopy rewrites its INPUT in place, and make would see a newer object)
+    subprocess.run([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")], check=True)
     subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                     "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
     notes = subprocess.run([LLVM + "llvm-readelf", "--notes", co], capture_output=True, text=True).stdout

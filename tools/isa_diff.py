@@ -16,7 +16,7 @@ TUS = ["lce_tu_valu", "lce_tu_mfma_ws", "lce_tu_mfma_direct", "lce_tu_mfma_2d", 
 
 def disassemble(obj, tmp):
     fb, co = os.path.join(tmp, "x.fb"), os.path.join(tmp, "x.co")
-    subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj], check=True)
+    subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fb}", obj, fb + ".copy.o"], check=True)   # (an output file: objcopy would rewrite its input otherwise)
     subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fb}",
                     "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
     text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
