@@ -517,6 +517,34 @@ def test_run_dual_is_run_followed_by_lcequantize(shape, engine, kernel):
         amd.check(amd.lib().lce_hip_bconv2d_run_dual(pb._h, xd.data_ptr(), bits.data_ptr(), bits.data_ptr(), None))
 
 
+@pytest.mark.parametrize("shape,pv", [((6, 14, 14, 200, 256), 1), ((4, 12, 10, 192, 64), 1), ((5, 7, 7, 448, 128), 1), ((6, 14, 14, 256, 256), 0),
+                                      ((3, 28, 224, 200, 64), 1)], ids=lambda v: str(v) if isinstance(v, int) else "x".join(map(str, v)))
+@pytest.mark.parametrize("dst", ["f32", "i8"])
+def test_run_dual_on_the_general_path_instances_of_the_streaming_kernel(shape, pv, dst):
+    """The streaming kernel's general-path instances WITH the second output on the 256- / 512-channel banks -- partial word planes (200,
+    192, 448 channels), the exact SAME-zero border, column strips -- are the ones at the register file's limit (`kTight`: they read the
+    transposed tile inside phase C, round 5).  Both outputs bit-equal to run + LceQuantize and to the oracle."""
+    b, h, w_, cin, cout = shape
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, padding=O.PADDING_SAME, pad_values=pv, activation=O.ACT_RELU, semantics=O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, sum(shape), negative_mul_fraction=0.3)
+    scale, zp = (0.37, 3) if dst == "i8" else (1.0, 0)
+    plan = amd.Bconv2dPlan(_params(spec, amd.I8 if dst == "i8" else amd.F32, out_scale=scale, out_zero_point=zp))
+    plan.set_weights(w, mul, bias)
+    plan.set_option("engine", "stream")
+    xd = torch.from_numpy(x).to(DEV)
+    y = plan.run(xd)
+    y2, bits = plan.run_dual(xd)
+    torch.cuda.synchronize()
+    assert plan.kernel_name().startswith("bconv2d_stream<"), plan.kernel_name()
+    assert torch.equal(y.view(torch.uint8), y2.view(torch.uint8)), plan.kernel_name()
+    want = O.bconv2d(spec, O.DST_I8 if dst == "i8" else O.DST_F32, x, w, mul, bias, out_scale=scale, out_zero_point=zp, threads=4)
+    assert np.array_equal(y.cpu().numpy().view(np.uint8), want.view(np.uint8)), plan.kernel_name()
+    if dst == "i8":
+        assert torch.equal(bits, amd.bitpack(y, zero_point=zp)), plan.kernel_name()
+    else:
+        assert torch.equal(bits, amd.bitpack(y)), plan.kernel_name()
+
+
 def test_run_host_pipelines_large_batches_and_binds_the_plan_to_its_device():
     """lce_hip_bconv2d_run_host cuts a big batch into slices (H2D | kernel | D2H on three streams): same bits
     as the device-resident run, from pageable and from page-locked (lce_hip_host_register) buffers."""
