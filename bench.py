@@ -52,6 +52,20 @@ VALU_BMAC_PEAK = 8.1e14                                # measured v_xor+v_bcnt c
 L0 = dict(in_h=56, in_w=56, channels_in=256, filter_h=3, filter_w=3, channels_out=256)
 
 
+def roofline_fields(parts, sec):
+    """the BINDING roofline of a measurement and both individual fractions.  `parts` = one (algorithmic
+    bytes, binary MACs) pair per launch (a stack: one per layer): a launch cannot finish before max(bytes / 8 TB/s,
+    2 * bMAC / 10 PFLOP/s), a stack not before the sum of that over its layers.  `frac` is that bound / the measured
+    time; `bound` names the roofline that binds (for a stack: the one binding most of the bound's time)."""
+    t_h = [b / (HBM_PEAK_GBS * 1e9) for b, _ in parts]
+    t_m = [2.0 * m / (MFMA_FP4_PEAK_TFLOPS * 1e12) for _, m in parts]
+    t_bound = sum(max(a, b) for a, b in zip(t_h, t_m))
+    by_hbm = sum(a for a, b in zip(t_h, t_m) if a >= b)
+    return {"bound": "hbm" if by_hbm >= t_bound - by_hbm else "mfma", "frac": t_bound / sec,
+            "hbm_frac": sum(t_h) / sec, "mfma_frac": sum(t_m) / sec,
+            "GBps_algorithmic": sum(b for b, _ in parts) / sec / 1e9}
+
+
 def _event_time(torch, dev, fn, steps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -173,7 +187,7 @@ def small_layer_entry(torch, dev, s_eager, plan, x, out, steps, rot=None):
     return s_, how
 
 
-def cpu_baseline(target_seconds=8.0):
+def cpu_baseline(target_seconds=12.0, reps=5):
     """Time the CPU oracle -- BOTH portable formulations of the reference (the direct
     loop of core/bconv2d/reference.h and the indirect BGEMM of core/indirect_bgemm/kernel_4x2_portable.h) --
     on the L0 layer: one image on one thread each (as the reference runs them), then the faster one with
@@ -186,23 +200,31 @@ def cpu_baseline(target_seconds=8.0):
     one = O.ConvSpec(batch=1, padding=O.PADDING_SAME, pad_values=1, **L0)
     x1, w, mul, bias = synth.conv_inputs(one, 1)
     single = {}
+    def median_time(fn, *a, **kw):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn(*a, **kw)
+            ts.append(time.perf_counter() - t)
+        return sorted(ts)[len(ts) // 2], ts
     for name, fn in (("BConv2DReference-shaped (direct loop)", O.bconv2d), ("Kernel4x2Portable-shaped (indirect BGEMM)", O.bconv2d_indirect)):
-        fn(one, O.DST_F32, x1, w, mul, bias, threads=1)
-        t = time.perf_counter()
-        fn(one, O.DST_F32, x1, w, mul, bias, threads=1)
-        single[name] = time.perf_counter() - t
+        fn(one, O.DST_F32, x1, w, mul, bias, threads=1)             # (untimed first call)
+        single[name], _ = median_time(fn, one, O.DST_F32, x1, w, mul, bias, threads=1)
     best_name = min(single, key=single.get)
     best = O.bconv2d if best_name.startswith("BConv2DReference") else O.bconv2d_indirect
+    # a bounded sample: the whole batch where one repetition stays under target / reps seconds, fewer images otherwise
     per_image_parallel = single[best_name] / max(1, cores) * 1.3
-    n = int(max(cores, min(256, target_seconds / max(per_image_parallel, 1e-6))))
+    n = int(max(1, min(256, (target_seconds / reps) / max(per_image_parallel, 1e-6))))
+    n = min(256, max(n, min(cores, 256)))
     spec = O.ConvSpec(batch=n, padding=O.PADDING_SAME, pad_values=1, **L0)
     x = synth.random_words(synth.rng(2), spec.input_shape(), spec.channels_in)
-    t = time.perf_counter()
-    best(spec, O.DST_F32, x, w, mul, bias, threads=cores)
-    dt = time.perf_counter() - t
+    best(spec, O.DST_F32, x, w, mul, bias, threads=cores)           # (untimed: thread pool start, page faults of the output)
+    dt, all_dt = median_time(best, spec, O.DST_F32, x, w, mul, bias, threads=cores)
     return {"value": spec.binary_macs / dt, "unit": "binary-MAC/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of 256 images of the same layer, float output, {dt:.1f} s wall, {best_name}; {lib_note}",
-            "single_thread_one_image": {k: {"ms": v * 1e3, "bmac_per_s": one.binary_macs / v} for k, v in single.items()}}
+            "sample": f"{n} of 256 images of the same layer, float output, median of {reps} repetitions of {dt:.2f} s wall "
+                      f"(min {min(all_dt):.2f}, max {max(all_dt):.2f}), {best_name}; {lib_note}",
+            "repetitions": reps,
+            "single_thread_one_image": {k: {"ms": v * 1e3, "bmac_per_s": one.binary_macs / v, "median_of": reps} for k, v in single.items()}}
 
 
 def _free_port():
@@ -303,6 +325,8 @@ def main():
                     help="measure roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) "
                          "over the same layer (rank 0, N == 1)")
     ap.add_argument("--spinup-ms", type=float, default=40.0, help="untimed clock spin-up before the warmup steps")
+    ap.add_argument("--one-operand-set", action="store_true",
+                    help="time the headline on ONE input / output set (rounds 1-5) instead of a rotation of >= 4 sets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--extra-json", default=os.path.join(ROOT, "gpurun_out", "bench_extra.json"),
@@ -359,7 +383,13 @@ def main():
     _, my_batch = shard.shard_range(global_batch, world, rank)
     spec = SL.Layer(batch=my_batch, padding=SL.PADDING_SAME, pad_values=1, **L0)
     # warm up + per-step time from stream events (a step = every kernel of one LceBconv2d call)
-    step_sec, kname, plan, x, out = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev)
+    step_sec, kname, plan, x, out, rot = time_layer(amd, torch, spec, amd.F32, args.steps, args.warmup, 0, dev, rotate=True)
+    # The headline's launches cycle through >= 4 operand sets (3.4 GB) like every `extra` layer's (round-5 review: with ONE set the
+    # 25.7 MB input of launch k + 1 is still in the 256 MB Infinity Cache from launch k -- 3 % of the bytes): every launch reads its
+    # input from HBM.  `--one-operand-set` restores the round-5 loop; the line says which it was.
+    if args.one_operand_set:
+        rot = None
+    step = (lambda: plan.run(x, out)) if rot is None else (lambda: rot.run(plan))
 
     # the contract's timed region: barrier + sync, exactly K steps, sync + barrier, MAX over ranks
     def barrier():
@@ -375,15 +405,15 @@ def main():
     # (profiles/r02/l0_clock_ramp.txt: 20 timed steps right after 5 warmups 0.274 ms, after 50 warmups 0.241 ms,
     # same box, same binary).  A fixed stretch of the same layer brings every run, short or long, to the state a
     # serving process is in; the timed region below is still exactly W warmup + K timed steps.
-    spin_launches = spin_up(torch, dev, lambda: plan.run(x, out))
+    spin_launches = spin_up(torch, dev, step)
     for _ in range(args.warmup):
-        plan.run(x, out)
+        step()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
     evs[0].record()                    # same stream the plan launches on (torch's current stream)
     for i in range(args.steps):
-        plan.run(x, out)
+        step()
         evs[i + 1].record()
     torch.cuda.synchronize(dev)
     elapsed_local = time.perf_counter() - t0
@@ -403,7 +433,8 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import layer_chain
-            chain4 = layer_chain.LayerChain(amd, torch, SL.quicknet_layers(args.batch, (6, 8, 12, 6)), dev, dst="f32", seed=4000)
+            # (this rank's share of the batch: 256 under weak scaling and for config 4 as stated, --gpus 8 --global-batch 2048)
+            chain4 = layer_chain.LayerChain(amd, torch, SL.quicknet_layers(my_batch, (6, 8, 12, 6)), dev, dst="f32", seed=4000)
             chain4.run_chain()
             torch.cuda.synchronize(dev)
             spin_up(torch, dev, chain4.run_chain)
@@ -423,16 +454,18 @@ def main():
         per_rank4 = shard.gather_over_ranks(local4, dist, cdev)
         if all(v == v for v in per_rank4):
             worst = max(per_rank4)
+            shares = [shard.shard_range(global_batch, world, r)[1] for r in range(world)]
             config4 = {"workload": "BASELINE configs[3]: QuickNetLarge's 32 LceBconv2d layers, float outputs + fused sign words, "
-                                   "device-resident chain, batch %d per GPU" % args.batch,
-                       "global_batch": args.batch * world, "chain_ms": worst / args.steps * 1e3,
-                       "images_per_s": args.batch * world * args.steps / worst,
-                       "per_rank_chain_ms": [v / args.steps * 1e3 for v in per_rank4]}
+                                   "device-resident chain, batch %s per GPU" % (shares[0] if len(set(shares)) == 1 else shares),
+                       "global_batch": global_batch, "chain_ms": worst / args.steps * 1e3,
+                       "images_per_s": global_batch * args.steps / worst,
+                       "per_rank_chain_ms": [v / args.steps * 1e3 for v in per_rank4],
+                       "per_rank_images_per_s": [n * args.steps / v for n, v in zip(shares, per_rank4)]}
         else:
             config4 = {"error": "a rank could not run the chain", "per_rank_seconds": per_rank4}
         del chain4
 
-    per_image_bmacs = spec.binary_macs // max(1, my_batch)
+    per_image_bmacs = SL.Layer(batch=1, padding=SL.PADDING_SAME, pad_values=1, **L0).binary_macs
     total_bmacs = per_image_bmacs * global_batch * args.steps
     value = total_bmacs / elapsed
     abytes = spec.algorithmic_bytes(SL.DST_F32)
@@ -459,6 +492,9 @@ def main():
         "rccl_world_size": dist.get_world_size() if dist is not None else 1,
         "collective_backend": ("gloo (--share-gpu test aid)" if args.share_gpu else "nccl (RCCL)") if dist is not None else None,
         "per_rank_ms_per_step": [v / args.steps * 1e3 for v in per_rank],
+        # every rank's OWN rate (its images' bMAC over its own elapsed time) and their sum: what the N ranks did side by side, next to
+        # `value` = the whole job over the SLOWEST rank's time.  (Scaling efficiency is the driver's to compute from the per-N lines.)
+        "per_rank_value": [per_image_bmacs * shard.shard_range(global_batch, world, r)[1] * args.steps / v for r, v in enumerate(per_rank)],
         "kernel": kname + ("+expand_fp4" if mfma and not direct else ""),
     }
     if verified is not None:
@@ -490,6 +526,9 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_launch": abytes, "kernel": kname,
+                              "operands": (rot.describe() if rot is not None else
+                                           "one set; the 25.7 MB input of each launch is served by the Infinity Cache"),
+                              "mfma_frac": 2.0 * spec.binary_macs / (MFMA_FP4_PEAK_TFLOPS * 1e12) / k_sec,
                               "kernel_ms": k_sec * 1e3, "expand_fp4_ms": e_sec * 1e3,
                               "kernel_ms_source": ("phase=gemm re-run, HIP events" if mfma and not direct else
                                                    "HIP events around the timed region / steps (one launch per step)"),
@@ -567,19 +606,22 @@ def measure_traffic(kname, batch):
 
 
 def compact_extra(extra):
-    """{name: [us, fraction of the HBM roofline or null]} for single launches; stacks: [us of the convolutions alone, fraction,
-    us of the device-resident chain].  `_format` says so in the line itself."""
-    out = {"_format": "name: [us, hbm_frac] (stacks: [convolutions_only us, hbm_frac, device_resident_chain us]); full entries in extra_detail_file"}
+    """{name: [us, frac of the BINDING roofline, "hbm" | "mfma", hbm_frac, mfma_frac]} for single launches; stacks:
+    [us of the convolutions alone, frac, us of the device-resident chain, bound, hbm_frac, mfma_frac].  `_format` says so in the line."""
+    out = {"_format": "name: [us, frac, bound, hbm_frac, mfma_frac]; stacks: [convolutions_only us, frac, device_resident_chain us, bound, "
+                      "hbm_frac, mfma_frac]; frac = max(bytes / 8 TB/s, 2 bMAC / 10 PF) summed over the launches / time; every "
+                      "entry >= 20 launches; full entries in extra_detail_file"}
     r3 = lambda v: None if v is None else round(float(v), 3)
     for name, e in extra.items():
         if not isinstance(e, dict):
             continue
+        tail = [e.get("bound"), r3(e.get("hbm_frac")), r3(e.get("mfma_frac"))]
         if "error" in e:
             out[name] = "error"
         elif "convolutions_only_ms" in e:
-            out[name] = [r3(e["convolutions_only_ms"] * 1e3), r3(e.get("hbm_frac")), r3(e.get("device_resident_chain_ms", 0.0) * 1e3)]
+            out[name] = [r3(e["convolutions_only_ms"] * 1e3), r3(e.get("frac")), r3(e.get("device_resident_chain_ms", 0.0) * 1e3)] + tail
         elif "ms" in e:
-            out[name] = [r3(e["ms"] * 1e3), r3(e.get("hbm_frac"))]
+            out[name] = [r3(e["ms"] * 1e3), r3(e.get("frac"))] + (tail if e.get("bound") else [])
         elif "ms_per_invoke_device_resident" in e:
             out[name] = [r3(e["ms_per_invoke_device_resident"] * 1e3), None]
     return out
@@ -589,12 +631,13 @@ def extra_measurements(amd, torch, spec, args, dev):
     """Everything else BASELINE.json names, on the same GPU (N == 1 only): never part of `value`."""
     import layer_chain
     extra = {}
-    st, wu = max(5, args.steps // 5), 3
+    # (every extra entry is the mean of >= 20 launches: the driver's --steps 20 used to leave them 5, round-5 review)
+    st, wu = max(20, args.steps), 3
     sc, zp = 0.125, 3
-    hbm = lambda b, s: {"GBps_algorithmic": b / s / 1e9, "hbm_frac": b / s / 1e9 / HBM_PEAK_GBS}
+    hbm = lambda b, s, m=0: roofline_fields([(b, m)], s)     # bound / frac / hbm_frac / mfma_frac of one launch
     for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
         s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp, rotate=True)
-        extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_),
+        extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_, spec.binary_macs),
                      "operands": rot_.describe()}
         del _p, _x, _o, rot_
     # the other matrix-core variant (FP4 workspace + GEMM whose tiles span images) and the xor-popcount
@@ -612,7 +655,7 @@ def extra_measurements(amd, torch, spec, args, dev):
         s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
         del rot_
         extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
-                                                **hbm(sp.algorithmic_bytes(SL.DST_F32), s_), **how}
+                                                **hbm(sp.algorithmic_bytes(SL.DST_F32), s_, sp.binary_macs), **how}
         # ... and the 1x1 int8 + RELU layers of config 5's flavour (the HBM-bound cases)
         sp1 = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
                        channels_out=c, activation=SL.ACT_RELU)
@@ -620,7 +663,7 @@ def extra_measurements(amd, torch, spec, args, dev):
         s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
         del rot_
         extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sp1.binary_macs / s_, "kernel": kn,
-                                                       **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_), **how}
+                                                       **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_, sp1.binary_macs), **how}
         del pl_, x_, o_
 
     # ... and the strided 1x1 shortcut convolutions of ResNet-style binary nets (round 3: on the pointwise kernel)
@@ -634,7 +677,7 @@ def extra_measurements(amd, torch, spec, args, dev):
         pix_out = args.batch * sps.out_h * sps.out_w
         by = pix_out * sps.in_words * 4 + sps.channels_out * sps.in_words * 4 + sps.channels_out * 8 + pix_out * sps.channels_out
         extra[f"pointwise_stride2_{hw}x{hw}x{c}_to_{2 * c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sps.binary_macs / s_, "kernel": kn,
-                                                                         **hbm(by, s_), **how}
+                                                                         **hbm(by, s_, sps.binary_macs), **how}
         del pl_, x_, o_
 
     # the north star's synthetic 224x224xC feature maps (3x3, C -> C, float output), 16 images = the pixel count of the
@@ -644,7 +687,7 @@ def extra_measurements(amd, torch, spec, args, dev):
                        channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
         s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spf, amd.F32, st, wu, 224 + c, dev, rotate=True)
         extra[f"feature_map_224x224x{c}_f32_batch{spf.batch}"] = {"ms": s_ * 1e3, "bmac_per_s": spf.binary_macs / s_, "kernel": kn,
-                                                                 **hbm(spf.algorithmic_bytes(SL.DST_F32), s_),
+                                                                 **hbm(spf.algorithmic_bytes(SL.DST_F32), s_, spf.binary_macs),
                                                                  "operands": rot_.describe()}
         del _p, _x, _o, rot_
 
@@ -663,7 +706,8 @@ def extra_measurements(amd, torch, spec, args, dev):
             ch.run_chain(fused=True)    # (untimed: a plan's first call of each kind selects and uploads)
             fused = _event_time(torch, dev, lambda: ch.run_chain(fused=True), st)
             entry = {"layers": len(layers), "batch": args.batch, "convolutions_only_ms": convs * 1e3,
-                     "bmac_per_s": ch.binary_macs / convs, **hbm(ch.algorithmic_bytes(), convs),
+                     "bmac_per_s": ch.binary_macs / convs,
+                     **roofline_fields([(L.algorithmic_bytes(SL.DST_F32 if dst == "f32" else SL.DST_I8), L.binary_macs) for L in layers], convs),
                      "device_resident_chain_ms": fused * 1e3}
             ch.run_chain(fused=False)
             entry["chain_with_separate_lcequantize_ms"] = _event_time(torch, dev, lambda: ch.run_chain(fused=False), st) * 1e3
@@ -683,6 +727,7 @@ def extra_measurements(amd, torch, spec, args, dev):
             # back to back exactly as eager launches do, between two replays the GPU idles ~9 us)
             spin_up(torch, dev, graph.replay)
             entry["device_resident_chain_hip_graph_ms"] = _event_time(torch, dev, graph.replay, st) * 1e3
+            entry["launches_timed"] = st
             entry["kernels"] = sorted(set(ch.kernel_names()))
             entry["kernels_device_resident_chain"] = sorted(set(ch.kernel_names(fused=True)))
             extra[name] = entry

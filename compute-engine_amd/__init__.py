@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "lce_hip_bitpacked_size", "lce_hip_bitpack", "lce_hip_unpack",
     "lce_hip_bconv2d_plan_create", "lce_hip_bconv2d_plan_destroy", "lce_hip_bconv2d_plan_output_shape",
     "lce_hip_bconv2d_plan_padding", "lce_hip_bconv2d_plan_set_weights", "lce_hip_bconv2d_plan_folded",
-    "lce_hip_bconv2d_plan_set_option", "lce_hip_bconv2d_plan_kernel_name", "lce_hip_bconv2d_plan_kernel_name_dual", "lce_hip_bconv2d_run",
+    "lce_hip_bconv2d_plan_set_option", "lce_hip_bconv2d_plan_kernel_name", "lce_hip_bconv2d_plan_kernel_name_dual", "lce_hip_bconv2d_plan_int8_epilogue", "lce_hip_bconv2d_run",
     "lce_hip_bconv2d_run_dual", "lce_hip_bconv2d_plan_device", "lce_hip_bconv2d_run_host", "lce_hip_bmaxpool_output_shape", "lce_hip_bmaxpool",
     "lce_hip_prepare_binary_filter", "lce_hip_prepare_fuse_post_op", "lce_hip_prepare_can_fuse_activation",
     "lce_hip_prepare_bitpacked_output", "lce_hip_prepare_bitpack_filter",
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         l.lce_hip_bconv2d_plan_kernel_name.argtypes = [C.c_void_p]
         l.lce_hip_bconv2d_plan_kernel_name_dual.restype = C.c_char_p
         l.lce_hip_bconv2d_plan_kernel_name_dual.argtypes = [C.c_void_p]
+        l.lce_hip_bconv2d_plan_int8_epilogue.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         l.lce_hip_bconv2d_plan_destroy.restype = None
         l.lce_hip_bconv2d_plan_destroy.argtypes = [C.c_void_p]
         l.lce_hip_bconv2d_plan_create.argtypes = [C.POINTER(Bconv2dDesc), C.POINTER(C.c_void_p)]
@@ -226,6 +227,12 @@ class Bconv2dPlan:
         if dual:
             return lib().lce_hip_bconv2d_plan_kernel_name_dual(self._h).decode()
         return lib().lce_hip_bconv2d_plan_kernel_name(self._h).decode()
+
+    def int8_epilogue(self):
+        """(one_instruction_forms, adjusted_channels) of the kernel the next run launches: ``lce_hip_bconv2d_plan_int8_epilogue``."""
+        forms, adjusted = C.c_int32(), C.c_int32()
+        check(lib().lce_hip_bconv2d_plan_int8_epilogue(self._h, C.byref(forms), C.byref(adjusted)))
+        return bool(forms.value), int(adjusted.value)
 
     def run_ptr(self, input_dev: int, output_dev: int, stream: int = 0):
         check(lib().lce_hip_bconv2d_run(self._h, C.c_void_p(input_dev), C.c_void_p(output_dev),

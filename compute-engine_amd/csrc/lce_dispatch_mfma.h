@@ -33,10 +33,8 @@ mfma_fn find_mfma_v(int dst, int bm, int bn, bool zero_pad_correction) {
   }
 }
 
-inline mfma_fn find_mfma(int dst, int bm, int bn, bool zero_pad_correction = false, bool direct = false, bool tile2d = false) {
-  if (direct && tile2d) return find_mfma_v<true, true>(dst, bm, bn, zero_pad_correction);
-  return direct ? find_mfma_v<true, false>(dst, bm, bn, zero_pad_correction)
-                : find_mfma_v<false, false>(dst, bm, bn, zero_pad_correction);
-}
+// (the three variants are stitched together by lookup_mfma, lce_kernel_types.h: an inline function HERE that named all three would
+//  instantiate -- and emit -- every variant's kernels in each of the three translation units; until round 6 one did, and the library
+//  carried the block GEMM three times)
 
 }  // namespace lce

@@ -25,17 +25,15 @@ template <int DST, bool CLAMP, bool SIGN, bool I8F = false>
 stream_fn stream_by_fast(int kch, bool fast, bool strips) {
   return fast ? stream_by_kch<DST, true, CLAMP, SIGN, I8F>(kch, strips) : stream_by_kch<DST, false, CLAMP, SIGN, I8F>(kch, strips);
 }
-// i8_floor: the int8 instances whose rounding is floor(x + 0.5) (the planner's int8_floor_ok)
-inline stream_fn find_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips = false, bool i8_floor = false) {
-  switch (dst) {
-    case LCE_HIP_F32:
-      if (clamp) return sign ? stream_by_fast<kDstFloat, true, true>(kch, fast, strips) : stream_by_fast<kDstFloat, true, false>(kch, fast, strips);
-      return sign ? stream_by_fast<kDstFloat, false, true>(kch, fast, strips) : stream_by_fast<kDstFloat, false, false>(kch, fast, strips);
-    case LCE_HIP_I8:
-      if (i8_floor) return sign ? stream_by_fast<kDstInt8, false, true, true>(kch, fast, strips) : stream_by_fast<kDstInt8, false, false, true>(kch, fast, strips);
-      return sign ? stream_by_fast<kDstInt8, false, true>(kch, fast, strips) : stream_by_fast<kDstInt8, false, false>(kch, fast, strips);
-    default: return stream_by_fast<kDstBitpacked, false, false>(kch, fast, strips);
-  }
+// One PART of the table = the instances of one (output type, float clamp / int8 rounding form): the product build compiles each part in
+// its own translation unit (lce_tu_stream_*.hip; the 90 instances in one unit took 8 minutes to compile, the parts build side by side).
+template <int DST, bool CLAMP, bool I8F>
+stream_fn find_stream_part(int kch, bool fast, bool sign, bool strips) {
+  if constexpr (DST == kDstBitpacked) return stream_by_fast<kDstBitpacked, false, false>(kch, fast, strips);
+  else return sign ? stream_by_fast<DST, CLAMP, true, I8F>(kch, fast, strips) : stream_by_fast<DST, CLAMP, false, I8F>(kch, fast, strips);
 }
+// (No function here names ALL parts: a non-template inline function that did -- the former find_stream -- instantiates every kernel in
+//  every translation unit that includes this header, used or not: __global__ instantiations are always emitted.  The lookups that
+//  stitch the parts together are lookup_stream / lookup_wstream / lookup_mfma in lce_kernel_types.h.)
 
 }  // namespace lce

@@ -28,14 +28,11 @@ wstream_fn wstream_by_kch(int kch, int nb) {
     default: return nullptr;
   }
 }
-inline wstream_fn find_wstream(int dst, int kch, int nb, bool sign, bool i8_floor = false) {
-  switch (dst) {
-    case LCE_HIP_F32: return sign ? wstream_by_kch<kDstFloat, true, false>(kch, nb) : wstream_by_kch<kDstFloat, false, false>(kch, nb);
-    case LCE_HIP_I8:
-      if (i8_floor) return sign ? wstream_by_kch<kDstInt8, true, true>(kch, nb) : wstream_by_kch<kDstInt8, false, true>(kch, nb);
-      return sign ? wstream_by_kch<kDstInt8, true, false>(kch, nb) : wstream_by_kch<kDstInt8, false, false>(kch, nb);
-    default: return wstream_by_kch<kDstBitpacked, false, false>(kch, nb);
-  }
+// One PART of the table = the instances of one (output type, int8 rounding form); a translation unit of the product build each
+// (lce_tu_wstream_*.hip).
+template <int DST, bool I8F>
+wstream_fn find_wstream_part(int kch, int nb, bool sign) {
+  if constexpr (DST == kDstBitpacked) return wstream_by_kch<kDstBitpacked, false, false>(kch, nb);
+  else return sign ? wstream_by_kch<DST, true, I8F>(kch, nb) : wstream_by_kch<DST, false, I8F>(kch, nb);
 }
-
 }  // namespace lce

@@ -20,8 +20,15 @@
 #include "lce_tu_mfma_direct.hip"
 #include "lce_tu_mfma_2d.hip"
 #include "lce_tu_pointwise.hip"
-#include "lce_tu_stream.hip"
-#include "lce_tu_wstream.hip"
+#include "lce_tu_stream_f32.hip"
+#include "lce_tu_stream_f32_clamp.hip"
+#include "lce_tu_stream_i8.hip"
+#include "lce_tu_stream_i8_floor.hip"
+#include "lce_tu_stream_bitpacked.hip"
+#include "lce_tu_wstream_f32.hip"
+#include "lce_tu_wstream_i8.hip"
+#include "lce_tu_wstream_i8_floor.hip"
+#include "lce_tu_wstream_bitpacked.hip"
 #endif
 #include "lce_plan.h"
 #include "lce_prepare.h"
@@ -613,7 +620,7 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     else if (!strcmp(value, "pointwise")) h.engine_pref = 4;
     else if (!strcmp(value, "stream")) h.engine_pref = 5;
     else if (!strcmp(value, "wstream")) h.engine_pref = 6;
-    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|pointwise|stream");
+    else return fail(LCE_HIP_ERR_INVALID, "plan_set_option: engine must be auto|valu|mfma|direct|pointwise|stream|wstream");
   } else if (!strcmp(key, "phase")) {
     // profiling aid for the matrix-core engine: time its two kernels separately
     if (!strcmp(value, "all")) h.phase = 0;
@@ -663,6 +670,21 @@ const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan) {
   const int chunk = lce::max_batch_per_launch(plan->host);
   if (ensure_selected(plan, chunk) != LCE_HIP_OK) return "";
   return plan->host.kernel_name.c_str();
+}
+
+lce_hip_status lce_hip_bconv2d_plan_int8_epilogue(lce_hip_bconv2d_plan* plan, int32_t* one_instruction_forms, int32_t* adjusted_channels) {
+  if (!plan) return fail(LCE_HIP_ERR_INVALID, "plan_int8_epilogue: null plan");
+  if (one_instruction_forms) *one_instruction_forms = 0;
+  if (adjusted_channels) *adjusted_channels = 0;
+  const lce::HostPlan& h = plan->host;
+  if (h.d.dst_type != LCE_HIP_I8 || !h.have_weights) return LCE_HIP_OK;
+  if (lce_hip_status s = ensure_selected(plan, lce::max_batch_per_launch(h))) return s;
+  // (only the streaming / weight-streaming / pointwise kernels have the proven forms; the block GEMM and the xor-popcount engine run
+  //  the reference's sequence whatever the proof said)
+  const bool forms = h.use_mfma && (h.use_stream || h.use_wstream || h.use_pointwise) && h.int8_floor_ok;
+  if (one_instruction_forms) *one_instruction_forms = forms ? 1 : 0;
+  if (adjusted_channels) *adjusted_channels = forms ? h.int8_bias_adjusted : 0;
+  return LCE_HIP_OK;
 }
 
 // Images [first, first + count) of the plan's batch; input_dev / output_dev / sign_dev point at image 0.

@@ -6,6 +6,7 @@
 // tables those lookups are made of; the host simulation of the CPU tests includes it directly.
 #pragma once
 #include <stdint.h>
+#include "../../include/lce_hip.h"
 #include "lce_kernel_args.h"
 
 namespace lce {
@@ -38,10 +39,32 @@ inline mfma_fn lookup_mfma(int dst, int bm, int bn, bool zero_pad_correction, bo
 int launch_expand_fp4(unsigned grid_x, void* stream, const uint32_t* in, void* workspace, const MfmaArgs& G, uint64_t chunks);
 // lce_tu_pointwise.hip
 pointwise_fn lookup_pointwise(int dst, int nc, int nj, bool strided, bool i8_floor);
-// lce_tu_stream.hip
-stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips, bool i8_floor);
-// lce_tu_wstream.hip
-wstream_fn lookup_wstream(int dst, int kch, int nb, bool sign, bool i8_floor);
+// lce_tu_stream_{f32,f32_clamp,i8,i8_floor,bitpacked}.hip: the weight-stationary kernel's instance table, one part per translation unit
+// (lce_dispatch_stream.h, find_stream_part)
+stream_fn lookup_stream_f32(int kch, bool fast, bool sign, bool strips);         // float output, the clamp is the identity
+stream_fn lookup_stream_f32_clamp(int kch, bool fast, bool sign, bool strips);   // float output with a fused activation's clamp
+stream_fn lookup_stream_i8(int kch, bool fast, bool sign, bool strips);          // int8 output, the reference's rounding sequence
+stream_fn lookup_stream_i8_floor(int kch, bool fast, bool sign, bool strips);    // int8 output, the proven one-instruction forms
+stream_fn lookup_stream_bitpacked(int kch, bool fast, bool strips);
+inline stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips, bool i8_floor) {
+  switch (dst) {
+    case LCE_HIP_F32: return clamp ? lookup_stream_f32_clamp(kch, fast, sign, strips) : lookup_stream_f32(kch, fast, sign, strips);
+    case LCE_HIP_I8: return i8_floor ? lookup_stream_i8_floor(kch, fast, sign, strips) : lookup_stream_i8(kch, fast, sign, strips);
+    default: return lookup_stream_bitpacked(kch, fast, strips);
+  }
+}
+// lce_tu_wstream_{f32,i8,i8_floor,bitpacked}.hip: the weight-streaming kernel's, likewise (lce_dispatch_wstream.h, find_wstream_part)
+wstream_fn lookup_wstream_f32(int kch, int nb, bool sign);
+wstream_fn lookup_wstream_i8(int kch, int nb, bool sign);
+wstream_fn lookup_wstream_i8_floor(int kch, int nb, bool sign);
+wstream_fn lookup_wstream_bitpacked(int kch, int nb);
+inline wstream_fn lookup_wstream(int dst, int kch, int nb, bool sign, bool i8_floor) {
+  switch (dst) {
+    case LCE_HIP_F32: return lookup_wstream_f32(kch, nb, sign);
+    case LCE_HIP_I8: return i8_floor ? lookup_wstream_i8_floor(kch, nb, sign) : lookup_wstream_i8(kch, nb, sign);
+    default: return lookup_wstream_bitpacked(kch, nb);
+  }
+}
 int mfma_selftest_wstream();
 // known-answer test of the unscaled FP4 MFMA as each of those two translation units compiled it (lce_mfma_selftest.h):
 // 0 = as assumed, 1 = wrong products, < 0 = -(hipError_t)

@@ -32,9 +32,20 @@ static int pad_before(int stride, int dilation, int in, int filter, int out) {
   return total / 2;
 }
 
+// The A/B and debugging aids of the planner come from the environment ONCE per plan, here, where the plan is created -- the selection
+// path (select_kernel, run at every batch-size change) reads fields, never the environment.
+static void read_debug_environment(HostPlan& p) {
+  const char* dbg = getenv("LCE_PLAN_DEBUG");
+  p.dbg_level = dbg ? std::max(1, atoi(dbg)) : 0;
+  p.dbg_no_wstream = getenv("LCE_PLAN_NO_WSTREAM") != nullptr;
+  p.dbg_int8_exact = getenv("LCE_PLAN_INT8_EXACT") != nullptr;
+  p.dbg_int8_full = getenv("LCE_PLAN_INT8_FULL") != nullptr;
+}
+
 std::string validate_and_infer(HostPlan& p) {
   const lce_hip_bconv2d_desc& d = p.d;
   char buf[256];
+  read_debug_environment(p);
   // an EMPTY batch is legal (the reference's loops simply do not run, reference.h:84); every
   // other extent must be positive
   if (d.batch < 0 || d.in_height < 1 || d.in_width < 1 || d.channels_in < 1 ||
@@ -265,11 +276,10 @@ bool pointwise_supported(const HostPlan& p, int64_t pixels, int* nc, int* nj) {
   if (d.groups != 1 || p.pad_h != 0 || p.pad_w != 0) return false;
   if (p.out_h != (d.in_height - 1) / d.stride_height + 1 || p.out_w != (d.in_width - 1) / d.stride_width + 1) return false;
   if (d.channels_out % 32 != 0) return false;
-  int c = ceil_div(d.channels_in, 64);
   // (129..192 channels: the four-K-step instances -- the fourth step's activations are masked to code 0 as a partial last step is, and its
-  //  weights lie past the end of the three-step image: the range check returns zeros)
-  if (c == 3) c = 4;
-  if (c != 1 && c != 2 && c != 4 && c != 8) return false;
+  //  weights are the all-zero fourth K-step that pack_for_mfma appends to the three-step image)
+  const int c = pointwise_bank_steps(ceil_div(d.channels_in, 64));
+  if (c == 0) return false;
   const int t = d.channels_out / 32;
   int j = t % 4 == 0 ? 4 : t % 2 == 0 ? 2 : 1;
   if (c == 8 || d.dst_type == LCE_HIP_F32) j = std::min(j, 2);   // (float: 16 row stores of a 128-channel tile + the bank do not fit 256 VGPRs)
@@ -539,7 +549,7 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     p.st_spb = (int)spb; p.st_gx = (int)ceil_div((int)s, (int)spb); p.st_rows = rows; p.st_ring_bytes = (int)ring;
     p.st_batch = batch_chunk;
     p.wp = wp;
-    if (const char* dbg = getenv("LCE_PLAN_DEBUG")) if (atoi(dbg) >= 2) fprintf(stderr, "[lce plan] stream geometry: rows/segment %d, ring %d rows x %d B = %lld B (+%d), blocks %d x %d, segments/block %lld\n", rs, rows, pitch, (long long)ring, stream_lds_extra(p), p.st_gx, ny, (long long)spb);
+    if (p.dbg_level >= 2) fprintf(stderr, "[lce plan] stream geometry: rows/segment %d, ring %d rows x %d B = %lld B (+%d), blocks %d x %d, segments/block %lld\n", rs, rows, pitch, (long long)ring, stream_lds_extra(p), p.st_gx, ny, (long long)spb);
     p.st_pitch = pitch;
     // ---- the tables: [sched | lim | ctx] ----
     const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
@@ -844,7 +854,7 @@ static void prepare_int8_epilogue(HostPlan& p) {
     p.thr_q[p.npad + i] = std::max(-128.0f, std::min(127.0f, hi));
   };
   for (int i = 0; i < n; ++i) set_range(i, p.mul[i], p.bias[i], false);
-  p.int8_floor_ok = !p.int8_exact_pref && !getenv("LCE_PLAN_INT8_EXACT");   // (the env: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
+  p.int8_floor_ok = !p.int8_exact_pref && !p.dbg_int8_exact;   // (LCE_PLAN_INT8_EXACT, read at plan creation: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
   p.int8_bias_adjusted = 0;
   const int32_t x_lo = std::max<int32_t>(0, p.clamp_min), x_hi = (int32_t)std::min<int64_t>(2 * (int64_t)p.backtransform_add, p.clamp_max);
   const bool even_only = cin_g % 2 == 0;   // (an odd channel count under zero padding: border pixels drop an odd number of terms)
@@ -867,7 +877,7 @@ static void prepare_int8_epilogue(HostPlan& p) {
     while (a < b) { const int32_t m = a + (b - a) / 2; if (not_past(m)) a = m + 1; else b = m; }
     *k1 = a;                                                                                                // [k0, k1)
   };
-  const bool check_all = getenv("LCE_PLAN_INT8_FULL") != nullptr;   // (testing aid: every value instead of the run -- tests compare the two)
+  const bool check_all = p.dbg_int8_full;   // (LCE_PLAN_INT8_FULL, read at plan creation; testing aid: every value instead of the run -- tests compare the two)
   auto channel_ok = [&](int i, float mul, float bias, int32_t* bad_x) {
     const float a0 = proven_form(mul, bias, p.clamp_min), a1 = proven_form(mul, bias, p.clamp_max);
     if (!(a0 == a0) || !(a1 == a1)) return false;
@@ -916,7 +926,7 @@ static void prepare_int8_epilogue(HostPlan& p) {
       }
     }
     if (!found) {
-      if (getenv("LCE_PLAN_DEBUG"))
+      if (p.dbg_level >= 1)
         fprintf(stderr, "[lce plan] int8: channel %d, accumulator %d -> y = %.9g: no neighbouring (multiplier, bias) reproduces the reference there, round-half-away instances\n",
                 i, bad, (double)y_bad);
       p.int8_floor_ok = false;
@@ -926,7 +936,7 @@ static void prepare_int8_epilogue(HostPlan& p) {
     for (const auto& a : adjusted) { p.mul_q[a.i] = a.mul; p.bias_q[a.i] = a.bias; }
     for (int i = 0; i < n; ++i) set_range(i, p.mul_q[i], p.bias_q[i], true);
     p.int8_bias_adjusted = (int)adjusted.size();
-    if (getenv("LCE_PLAN_DEBUG") && !adjusted.empty()) fprintf(stderr, "[lce plan] int8: one-instruction forms, %zu channel(s) with adjusted parameters\n", adjusted.size());
+    if (p.dbg_level >= 1 && !adjusted.empty()) fprintf(stderr, "[lce plan] int8: one-instruction forms, %zu channel(s) with adjusted parameters\n", adjusted.size());
   }
 }
 
@@ -939,7 +949,11 @@ static void pack_for_mfma(HostPlan& p) {
   p.npad = ceil_div(n, bn) * bn;
   p.kch = d.groups > 1 ? group_chunks(d) : p.cpad / 64;
   const int kch = p.kch, ks_total = taps * kch;
-  p.wq.assign((size_t)ks_total * p.npad * 32, 0);
+  // 1x1 layers of 129..192 input channels run the pointwise kernel's FOUR-K-step instances (pointwise_supported): the image carries that
+  // fourth K-step as zero codes (it used to end after three, and the kernel's bank loads -- plain pointer loads, no range check -- read
+  // Npad * 32 bytes past the allocation: the advisor's round-5 finding).  The block GEMM walks p.kch steps and never looks at it.
+  const int ks_alloc = (taps == 1 && d.groups == 1 && p.wq_layout == 0) ? pointwise_bank_steps(kch) : ks_total;
+  p.wq.assign((size_t)std::max(ks_total, ks_alloc) * p.npad * 32, 0);
   for (int oc = 0; oc < n; ++oc) {
     const int g = oc / p.npg, chunk0 = (g * cin_g) / 64;    // the kernel starts the group's K loop at this chunk
     for (int t = 0; t < taps; ++t)
@@ -1217,7 +1231,7 @@ static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
     bytes_per_us += 0.42e6 * std::min(1.0, std::max(0.0, (64.0e6 - window) / 48.0e6));
   }
   const double store_us = kLaunchUs + prologue_us + step_us + (double)out_bytes_of(p, batch_chunk) / bytes_per_us;
-  if (getenv("LCE_PLAN_DEBUG") && getenv("LCE_PLAN_DEBUG")[0] == '2')
+  if (p.dbg_level >= 2)
     fprintf(stderr, "[lce plan]   rows %d il %d: blocks %lld usteps %lld prologue %.2f step %.2f production %.2f partial %.2f compute %.2f store %.2f\n", p.st_rs, p.st_gstr > 1,
             (long long)blocks, (long long)usteps, prologue_us, step_us, production_us, partial_us, compute_us, store_us);
   // An instance wider than the layer (129..192 channels on the 256-channel bank, 257..448 on the 512-channel one): the expansion takes
@@ -1371,15 +1385,25 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       cands[i].us = estimate_stream_us(p, batch_chunk);
       if (best < 0 || cands[i].us < cands[best].us) best = (int)i;
     }
+    if (best < 0 && il_pref == 1) {
+      // stream_interleave=1 and nothing to interleave (every interleaved candidate came out as one segment per block, or could not be
+      // planned): the consecutive-segment plan is the same launch -- take it instead of refusing engine=stream / dropping the family
+      cands.push_back(StreamCandidate{rows_pref, 0, 0.0});
+      p.stream_rows_pref = rows_pref;
+      p.stream_interleave_pref = 0;
+      const std::string err = plan_stream(p, batch_chunk);
+      if (err.empty()) { cands.back().us = estimate_stream_us(p, batch_chunk); best = (int)cands.size() - 1; }
+      else { cands.back().us = -1.0; if (first_err.empty()) first_err = err; }
+    }
     p.stream_rows_pref = rows_pref;
     p.stream_interleave_pref = il_pref;
     double best_us = best >= 0 ? cands[best].us : 1e30;
     bool take_wstream = false;
-    const bool debug = getenv("LCE_PLAN_DEBUG") != nullptr;      // (the estimates of every candidate, on stderr: tools/planner_regret.py)
+    const bool debug = p.dbg_level >= 1;      // (LCE_PLAN_DEBUG, read at plan creation: the estimates of every candidate, on stderr: tools/planner_regret.py)
     if (debug)
       for (const StreamCandidate& c : cands) fprintf(stderr, "[lce plan] stream rows=%d il=%d: %.2f us\n", c.rows, c.interleave, c.us);
     if (auto_rule) {
-      if (wstream_supported(p) && !getenv("LCE_PLAN_NO_WSTREAM") && plan_wstream(p, batch_chunk).empty()) {   // (the variable: an A/B aid, as LCE_PLAN_DEBUG)
+      if (wstream_supported(p) && !p.dbg_no_wstream && plan_wstream(p, batch_chunk).empty()) {   // (LCE_PLAN_NO_WSTREAM, read at plan creation: an A/B aid)
         const double us = estimate_wstream_us(p, batch_chunk);
         if (debug) fprintf(stderr, "[lce plan] wstream images=%d blocks=%d: %.2f us\n", p.ws_ipb, p.ws_nb, us);
         if (us < best_us) { best_us = us; take_wstream = true; }

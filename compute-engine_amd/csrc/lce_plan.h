@@ -122,6 +122,12 @@ struct HostPlan {
   uint32_t ws_tab_part = 0, ws_tab_ctx = 0;  // byte offsets inside st_tabs
   int64_t ws_cost = 0;                       // the planner's cycle estimate of a launch (plan_wstream)
 
+  // A/B and debugging aids, read from the environment once, when the plan is created (validate_and_infer) -- never on the selection path
+  int dbg_level = 0;                         // LCE_PLAN_DEBUG=1|2: every candidate's price (2: and its terms) on stderr
+  bool dbg_no_wstream = false;               // LCE_PLAN_NO_WSTREAM: the weight-streaming kernel is not among auto's candidates
+  bool dbg_int8_exact = false;               // LCE_PLAN_INT8_EXACT: as the option int8_rounding=exact, for whole stacks
+  bool dbg_int8_full = false;                // LCE_PLAN_INT8_FULL: the int8 proof enumerates every accumulator value (tests compare it with the bisection)
+
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
   std::vector<float> mul_p, bias_p;        // NT*TN, padded
@@ -160,6 +166,10 @@ bool direct_geometry(const HostPlan& p, const MfmaCfg& c, int* tpi, int* halo_ro
 MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk);
 // 1x1 streaming kernel: can it run this convolution (fills nc / nj), and its launch constants.
 bool pointwise_supported(const HostPlan& p, int64_t pixels, int* nc, int* nj);
+// K-steps of the pointwise INSTANCE that runs a 1x1 layer of `chunks` 64-channel chunks: 1, 2, 4 or 8 (3 chunks -- 129..192 channels --
+// run the four-step instances: the fourth step's activations are masked to code 0 and pack_for_mfma appends a fourth, all-zero K-step to
+// the weight image, so the kernel's register-resident bank is loaded from inside the allocation).  0: no instance.
+inline int pointwise_bank_steps(int chunks) { return chunks <= 2 ? chunks : chunks <= 4 ? 4 : chunks == 8 ? 8 : 0; }
 // a 1x1 launch with fewer wave-tiles (32 pixels x 128 channels) than this runs 64 channels per block
 constexpr int64_t pw_small_launch_tiles = 16384;
 PwArgs make_pw_args(const HostPlan& p, int batch_chunk);

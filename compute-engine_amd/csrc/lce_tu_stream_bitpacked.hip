@@ -4,6 +4,6 @@
 #include "lce_mfma_selftest.h"
 
 namespace lce {
-stream_fn lookup_stream(int dst, int kch, bool fast, bool clamp, bool sign, bool strips, bool i8_floor) { return find_stream(dst, kch, fast, clamp, sign, strips, i8_floor); }
+stream_fn lookup_stream_bitpacked(int kch, bool fast, bool strips) { return find_stream_part<kDstBitpacked, false, false>(kch, fast, false, strips); }
 int mfma_selftest_stream() { return run_mfma_unscaled_selftest<1>(); }
 }  // namespace lce

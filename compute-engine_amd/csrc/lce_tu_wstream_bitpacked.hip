@@ -4,6 +4,6 @@
 #include "lce_mfma_selftest.h"
 
 namespace lce {
-wstream_fn lookup_wstream(int dst, int kch, int nb, bool sign, bool i8_floor) { return find_wstream(dst, kch, nb, sign, i8_floor); }
+wstream_fn lookup_wstream_bitpacked(int kch, int nb) { return find_wstream_part<kDstBitpacked, false>(kch, nb, false); }
 int mfma_selftest_wstream() { return run_mfma_unscaled_selftest<2>(); }
 }  // namespace lce

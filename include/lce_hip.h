@@ -218,6 +218,15 @@ const char* lce_hip_bconv2d_plan_kernel_name(lce_hip_bconv2d_plan* plan);
  * kept for callers of round 4's ABI, returns what lce_hip_bconv2d_plan_kernel_name returns. */
 const char* lce_hip_bconv2d_plan_kernel_name_dual(lce_hip_bconv2d_plan* plan);
 
+/* What the int8 epilogue of the kernel the next run will launch does (int8 plans with weights set; otherwise both outputs are 0):
+ * *one_instruction_forms = 1 when it transforms with one fma and / or rounds with floor(y + 0.5) -- forms the planner has proven
+ * byte-identical to the reference's two roundings + round-half-away (core/bconv2d/output_transform.h:31-44,125-144) for every value the
+ * accumulator can take on this plan -- and 0 when it runs the reference's own sequence; *adjusted_channels = the number of output
+ * channels whose folded multiplier / bias that proof replaced by NEIGHBOURING floats (<= 2 ulps / 4 grid steps; the bytes written are
+ * still the reference's on the original parameters).  "int8_rounding" = "exact" forces 0 / 0.  Either pointer may be NULL. */
+lce_hip_status lce_hip_bconv2d_plan_int8_epilogue(lce_hip_bconv2d_plan* plan, int32_t* one_instruction_forms,
+                                                  int32_t* adjusted_channels);
+
 /* Replaces bconv2d::Eval (bconv2d.cc:550-564) -> BConv2DReference /
  * BConv2DOptimizedBGEMM / BConv2DOptimizedIndirectBGEMM (core/bconv2d/ headers) with
  * device-resident tensors: input int32 [B,H,W,ceil(Cin/32)], output per dst_type.

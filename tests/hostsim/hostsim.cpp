@@ -3,13 +3,16 @@
 // the real planner (lce_plan.cpp), mirroring the launch logic of lce_hip_api.hip.
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
 #include <vector>
 
-#include "lce_dispatch.h"
+#include "lce_kernel_types.h"   // the kernel instances live in hs_tu_*.cpp (the product build's cut); here only their lookups
 #include "lce_kernels.h"
+#include "lce_kernels_mfma.h"     // expand_fp4
 #include "lce_plan.h"
 
 using namespace lce;
@@ -73,6 +76,31 @@ void launch_block_lockstep(int grid_x, int grid_y, int block, size_t lds_bytes, 
       [&](int) { body(); });
   }
 }
+
+// An EXACT-size copy of a device upload whose last byte is followed by an inaccessible page: a kernel body that reads past the buffer
+// faults here instead of reading whatever the heap holds behind it (the pointwise kernel loads its filter bank with plain pointer
+// loads, no range check: round 5 shipped a four-K-step instance on a three-K-step image and the simulation, with 64 bytes of slack
+// on a std::vector, read the heap just as the GPU read its neighbour allocation).
+class GuardedBytes {
+ public:
+  explicit GuardedBytes(const std::vector<uint8_t>& v) {
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    body_ = (v.size() + page - 1) / page * page;
+    map_ = (uint8_t*)mmap(nullptr, body_ + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (map_ == MAP_FAILED) { map_ = nullptr; return; }
+    mprotect(map_ + body_, page, PROT_NONE);
+    data_ = map_ + body_ - v.size();          // the copy ENDS at the guard page (16-byte aligned: the images are multiples of 32 bytes)
+    if (!v.empty()) memcpy(data_, v.data(), v.size());
+    page_ = page;
+  }
+  ~GuardedBytes() { if (map_) munmap(map_, body_ + page_); }
+  GuardedBytes(const GuardedBytes&) = delete;
+  GuardedBytes& operator=(const GuardedBytes&) = delete;
+  const uint8_t* data() const { return data_; }
+ private:
+  uint8_t *map_ = nullptr, *data_ = nullptr;
+  size_t body_ = 0, page_ = 0;
+};
 
 std::string g_err;
 void* g_sign_out = nullptr;   // second output of the next hostsim_bconv2d call (float output, matrix-core engine)
@@ -146,7 +174,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     if (h.use_mfma && h.use_wstream) {
       const WsArgs G = make_ws_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      wstream_fn fn = find_wstream(h.d.dst_type, stream_chunks(h.d), h.ws_nb, sgn != nullptr, h.int8_floor_ok);
+      wstream_fn fn = lookup_wstream(h.d.dst_type, stream_chunks(h.d), h.ws_nb, sgn != nullptr, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
@@ -158,7 +186,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
     } else if (h.use_mfma && h.use_stream) {
       const StreamArgs G = make_stream_args(h, nb);
       uint32_t* sgn = g_sign_out && h.d.dst_type != LCE_HIP_BITPACKED ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr;
-      stream_fn fn = find_stream(h.d.dst_type, stream_chunks(h.d), stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1, h.int8_floor_ok);
+      stream_fn fn = lookup_stream(h.d.dst_type, stream_chunks(h.d), stream_fast(G), stream_clamps(G), sgn != nullptr, G.NSTRIP > 1, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       std::vector<uint8_t> wq = h.wq;
       wq.resize(wq.size() + 64, 0);
@@ -168,18 +196,18 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
         fn(G, (const uint8_t*)in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), sched.data(), out, sgn);
       });
     } else if (h.use_mfma && h.use_pointwise) {
-      pointwise_fn fn = find_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1, h.int8_floor_ok);
+      pointwise_fn fn = lookup_pointwise(h.d.dst_type, h.pw_nc, h.pw_nj, h.d.stride_height != 1 || h.d.stride_width != 1, h.int8_floor_ok);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const PwArgs P = make_pw_args(h, nb);
-      std::vector<uint8_t> wq = h.wq;
-      wq.resize(wq.size() + 64, 0);
+      const GuardedBytes wq(h.wq);      // exact size, guard page behind it (no slack: the bank loads are unchecked pointer loads)
+      if (!wq.data()) { g_err = "hostsim: mmap failed"; return 3; }
       // a small grid: waves loop over several tiles
       launch_block_lockstep(std::min((P.tiles + 3) / 4, 2), h.d.channels_out / (32 * h.pw_nj), 256, (size_t)(4 * h.pw_nj * 4096), [&] {
         fn(P, in, wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), out,
            g_sign_out ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr);
       });
     } else if (h.use_mfma) {
-      mfma_fn fn = find_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
+      mfma_fn fn = lookup_mfma(h.d.dst_type, h.mfma.bm(), h.mfma.bn(), h.zero_pad_mode == lce::kZeroPadCorrection,
                              h.use_direct, h.use_direct && h.tile_tx > 0);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const MfmaArgs G = make_mfma_args(h, nb);
@@ -199,7 +227,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
         fn(A, G, (const uint8_t*)work.data(), wq.data(), h.mul_q.data(), h.bias_q.data(), h.thr_q.data(), zpc, out, g_sign_out ? (uint32_t*)g_sign_out + (size_t)b0 * h.out_h * h.out_w * h.wout : nullptr);
       });
     } else if (h.use_tiled) {
-      tiled_fn fn = find_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
+      tiled_fn fn = lookup_tiled(h.d.dst_type, h.tile.tm, h.tile.tn, h.ch);
       if (!fn) { g_err = "no kernel instance for " + h.kernel_name; return 3; }
       const int64_t tasks = (int64_t)A.PT * A.NT;
       const int wpb = 4;
@@ -207,7 +235,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
         fn(A, in, packed.data(), h.mul_p.data(), h.bias_p.data(), h.thr_p.data(), h.oob_corr.data(), zpc, out);
       });
     } else {
-      general_fn fn = find_general(h.d.dst_type);
+      general_fn fn = lookup_general(h.d.dst_type);
       launch_sequential((A.M + 255) / 256, (h.d.channels_out + 31) / 32, 256, [&] {
         fn(A, in, filt.data(), h.mul.data(), h.bias.data(), h.thresholds.data(), zpc, out);
       });

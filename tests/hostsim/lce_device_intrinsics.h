@@ -44,9 +44,10 @@ struct f32x16 { float v[16]; float& operator[](int i) { return v[i]; } float ope
 #error "the host simulation's fiber switch is written for x86-64 (the container's and the driver's CPU)"
 #endif
 extern "C" void lce_fiber_switch(void** save_sp, void* load_sp);
+// (.weak: every translation unit of the simulation carries this definition -- the build is cut into parts -- and the linker keeps one)
 asm(R"(
 .text
-.globl lce_fiber_switch
+.weak lce_fiber_switch
 .type lce_fiber_switch,@function
 lce_fiber_switch:
   pushq %rbp

@@ -64,17 +64,44 @@ def test_a_stray_switch_is_a_compile_error():
     assert cc("-DLCE_PRODUCT_BUILD", "-DLCE_EXPERIMENT").returncode != 0
 
 
-@pytest.mark.parametrize("tu", ["lce_tu_stream", "lce_tu_wstream", "lce_tu_pointwise"])
-def test_no_streaming_kernel_instance_uses_scratch_memory(tu):
+@pytest.mark.parametrize("family,least", [("lce_tu_stream_*", 90), ("lce_tu_wstream_*", 84), ("lce_tu_pointwise", 40)])
+def test_no_streaming_kernel_instance_uses_scratch_memory(family, least):
     """Round 5 (review item 7): the code objects of the built product library -- their own metadata, tools/co_resources.py -- hold no
-    kernel of the streaming families with a private-segment (scratch) size above 0: no VGPR spill goes to memory."""
+    kernel of the streaming families with a private-segment (scratch) size above 0: no VGPR spill goes to memory.  (Round 6: the two
+    streaming families' tables are cut into several translation units -- all of a family's objects are read.)"""
     import subprocess
     import sys
-    obj = os.path.join(ROOT, "compute-engine_amd", "csrc", "obj", tu + ".o")
-    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+    objs = sorted(glob.glob(os.path.join(ROOT, "compute-engine_amd", "csrc", "obj", family + ".o")))
+    if not objs or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("the product library's objects / the LLVM tools are not here")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "co_resources.py"), obj], capture_output=True, text=True, check=True).stdout
-    rows = [l for l in out.splitlines() if " scratch " in l]
-    assert len(rows) >= 40, out[-400:]
+    rows = []
+    for obj in objs:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "co_resources.py"), obj], capture_output=True, text=True, check=True).stdout
+        rows += [l for l in out.splitlines() if " scratch " in l]
+    assert len(rows) >= least, (len(rows), rows[-3:])
     bad = [l for l in rows if int(l.split(" scratch ")[1].split()[0]) != 0]
     assert not bad, "\n".join(bad)
+
+
+def test_every_kernel_is_emitted_once():
+    """Round 6: until then a non-template inline function in each dispatch header named ALL parts of a family, so every translation
+    unit that included the header instantiated -- and emitted -- every kernel of the family (the block GEMM was in the library three
+    times, 19.6 MB).  Each kernel symbol now appears in exactly one object, and the library stays under 15 MB."""
+    import subprocess
+    objs = sorted(glob.glob(os.path.join(ROOT, "compute-engine_amd", "csrc", "obj", "lce_tu_*.o")))
+    import shutil
+    nm = shutil.which("nm")
+    if not objs or not nm:
+        pytest.skip("the product library's objects / the LLVM tools are not here")
+    seen = {}
+    for obj in objs:
+        for line in subprocess.run([nm, "--defined-only", obj], capture_output=True, text=True, check=True).stdout.splitlines():
+            parts = line.split()
+            # host-side launch stubs of the kernels: __device_stub__<mangled kernel>
+            if len(parts) == 3 and "__device_stub__" in parts[2] and "bconv2d" in parts[2]:
+                seen.setdefault(parts[2], []).append(os.path.basename(obj))
+    assert len(seen) >= 350, len(seen)
+    twice = {k: v for k, v in seen.items() if len(v) > 1}
+    assert not twice, list(twice.items())[:3]
+    lib = os.path.join(ROOT, "compute-engine_amd", "csrc", "liblce_hip.so")
+    assert os.path.getsize(lib) < 15 * 1024 * 1024, os.path.getsize(lib)

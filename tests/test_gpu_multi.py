@@ -255,3 +255,23 @@ def test_bench_multi_rank_path_with_two_ranks_sharing_one_gpu():
     chk = r["multi_gpu_self_check"]       # the sharded run was reassembled and compared on both ranks before anything was timed
     assert chk["sharded_equals_single_gpu_on_every_rank"] and chk["distinct_devices"] == 1 and len(chk["devices"]) == 2
     assert {d["rank"] for d in chk["devices"]} == {0, 1} and len({d["pid"] for d in chk["devices"]}) == 2
+
+
+def test_eight_gpu_preflight_config4_as_stated_with_two_ranks_on_one_gpu():
+    """Round 6 (review item 5): the first real 8-GPU run will be the driver's, so the exact shape of that run -- BASELINE config 4,
+    `--global-batch 2048` (strong scaling: the ranks split a fixed batch), the self-check, the sharded QuickNetLarge chain, the line's
+    fields -- runs here end to end with two ranks that share GPU 0 over gloo (`--share-gpu`; 1024 images per rank).  What this cannot
+    show is the xGMI transport; everything else of `python -m torch.distributed.run ... bench.py --gpus N --global-batch 2048` is the
+    code that runs there."""
+    r = _bench("--gpus", "2", "--share-gpu", "--global-batch", "2048", "--steps", "3", no_extra=False, timeout=1200)
+    assert r["n_gpus"] == 2 and r["rccl_world_size"] == 2 and r["steps"] == 3 and r["scaling"] == "strong"
+    assert r["config"]["global_batch"] == 2048 and r["config"]["per_gpu_batch"] == 1024
+    assert abs(r["value"] - 9 * 256 * 256 * 56 * 56 * 2048 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert len(r["per_rank_value"]) == 2 and all(v > 0 for v in r["per_rank_value"])
+    assert r["value"] <= sum(r["per_rank_value"]) * (1 + 1e-9)          # the whole job runs at the slowest rank's pace
+    chk = r["multi_gpu_self_check"]
+    assert chk["sharded_equals_single_gpu_on_every_rank"] and len(chk["devices"]) == 2
+    c4 = r["config4_quicknet_large_sharded"]
+    assert c4["global_batch"] == 2048 and len(c4["per_rank_chain_ms"]) == 2 and len(c4["per_rank_images_per_s"]) == 2
+    assert abs(c4["images_per_s"] - 2048 / (c4["chain_ms"] * 1e-3)) < 1e-6 * c4["images_per_s"]
+    assert "efficiency" not in json.dumps(r)          # (the driver computes scaling efficiency from the per-N lines; this file never does)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Registers / spills / scratch of every kernel of a BUILT translation unit, from the code object's metadata (no recompile).
-usage: co_resources.py compute-engine_amd/csrc/obj/lce_tu_stream.o [name filter]"""
+usage: co_resources.py compute-engine_amd/csrc/obj/lce_tu_stream_f32.o [name filter]"""
 import re
 import subprocess
 import sys

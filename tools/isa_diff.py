@@ -11,7 +11,7 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-TUS = ["lce_tu_valu", "lce_tu_mfma_ws", "lce_tu_mfma_direct", "lce_tu_mfma_2d", "lce_tu_pointwise", "lce_tu_stream"]
+TUS = ["lce_tu_valu", "lce_tu_mfma_ws", "lce_tu_mfma_direct", "lce_tu_mfma_2d", "lce_tu_pointwise"] + ["lce_tu_stream_" + p for p in ("f32", "f32_clamp", "i8", "i8_floor", "bitpacked")]
 
 
 def disassemble(obj, tmp):

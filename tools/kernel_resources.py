@@ -6,8 +6,10 @@ import sys
 
 # one translation unit per kernel family (csrc/Makefile); only the streaming kernel's is built with -amdgpu-mfma-vgpr-form
 #   usage: kernel_resources.py [name filter] [tu ...]     (default: every translation unit)
+VF = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 TUS = {"lce_tu_valu": [], "lce_tu_mfma_ws": [], "lce_tu_mfma_direct": [], "lce_tu_mfma_2d": [], "lce_tu_pointwise": [],
-       "lce_tu_stream": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+       **{"lce_tu_stream_" + p: VF for p in ("f32", "f32_clamp", "i8", "i8_floor", "bitpacked")},
+       **{"lce_tu_wstream_" + p: [] for p in ("f32", "i8", "i8_floor", "bitpacked")}}
 txt = ""
 for tu in (sys.argv[2:] or TUS):
     cmd = ["hipcc", "-DLCE_PRODUCT_BUILD", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", *TUS[tu], "-Icompute-engine_amd/csrc",
