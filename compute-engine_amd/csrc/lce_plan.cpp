@@ -841,6 +841,12 @@ static void prepare_int8_epilogue(HostPlan& p) {
   p.bias_q.assign(p.npad, 0.0f);
   std::copy(p.mul.begin(), p.mul.end(), p.mul_q.begin());
   std::copy(p.bias.begin(), p.bias.end(), p.bias_q.begin());
+  // Channels past the last one (the tables are padded to the block's width): their value must never count as "below the zero point" in
+  // the second output of lce_hip_bconv2d_run_dual -- LceQuantize leaves the padding bits of a row's last word 0 (bitpack.h:238-244).
+  // The block GEMM compares every lane's value with one threshold T (lce_kernels_mfma.h, bit_rows), and with mul = bias = 0 a padded
+  // lane held 0 < T for every positive zero point: ragged channel counts (Cout % 32 != 0) got ones in those bits (round 6: found by the
+  // randomized GPU test).  0 * x + inf = +inf is below no threshold; such lanes store nothing.
+  for (int i = n; i < p.npad; ++i) p.bias_q[i] = std::numeric_limits<float>::infinity();
   p.thr_q.assign((size_t)2 * p.npad, 0.0f);
   const bool one_rounding = p.use_stream || p.use_wstream;
   auto two_roundings = [](float mul, float bias, int32_t x) { volatile float pr = (float)x * mul; volatile float r = pr + bias; return (float)r; };

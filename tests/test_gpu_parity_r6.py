@@ -93,10 +93,10 @@ def _every_accumulator_inputs(spec, g):
 
 
 @pytest.mark.parametrize("engine,kernel,shape", [
-    ("stream", "bconv2d_stream<i8", (2, 54, 54, 64, 3, 32)),        # K = 576: 577 values, 2 x 18 x 18 = 648 output pixels
-    ("wstream", "bconv2d_wstream<i8", (1, 105, 105, 128, 3, 32)),   # K = 1152: 1153 values, 35 x 35 = 1225 pixels
-    ("pointwise", "bconv2d_pointwise<i8", (2, 12, 12, 256, 1, 64)),  # K = 256: 257 values, 288 pixels
-    ("pointwise-unaligned", "bconv2d_pointwise<i8", (2, 12, 12, 256, 1, 64)),   # ... the plan's block-GEMM fallback (output not 16-byte aligned)
+    ("stream", "bconv2d_stream<i8", (2, 54, 54, 64, 3, 256)),         # K = 576: 577 values, 2 x 18 x 18 = 648 output pixels
+    ("wstream", "bconv2d_wstream<i8", (19, 24, 24, 128, 3, 256)),     # K = 1152: 1153 values, 19 x 8 x 8 = 1216 pixels (whole images in LDS)
+    ("pointwise", "bconv2d_pointwise<i8", (2, 12, 12, 256, 1, 256)),  # K = 256: 257 values, 288 pixels
+    ("pointwise-unaligned", "bconv2d_pointwise<i8", (2, 12, 12, 256, 1, 256)),   # ... the plan's block-GEMM fallback (output not 16-byte aligned)
 ])
 def test_int8_adjusted_parameters_over_every_reachable_accumulator(engine, kernel, shape):
     """The advisor's round-5 finding: the proof behind the one-instruction int8 forms enumerates the accumulator values on the HOST
@@ -111,20 +111,28 @@ def test_int8_adjusted_parameters_over_every_reachable_accumulator(engine, kerne
     eng = engine.split("-")[0]
     spec = O.ConvSpec(b, h, w_, cin, k, k, cout, stride_h=k, stride_w=k, padding=O.PADDING_VALID, activation=O.ACT_NONE)
     adjusted_plans = 0
-    for seed in range(12):
+    k_total = k * k * cin
+    for seed in range(24):
         g = np.random.default_rng(4200 + seed)
-        x, w = _every_accumulator_inputs(spec, g)
-        mul = (g.uniform(0.02, 0.4, cout) * g.choice([-1.0, 1.0], cout)).astype(np.float32)
-        bias = g.uniform(-20.0, 20.0, cout).astype(np.float32)
         scale, zp = float(g.choice([0.21, 0.73, 0.125, 1.0])), int(g.integers(-20, 21))
+        # y swings over 120 .. 250 int8 steps while the accumulator goes 0 .. 2K: most of a channel's values land inside int8's range,
+        # where |y| ~ 100 lives on a 2^-17 grid and exact ties / near-ties do occur (a plan with an adjusted channel: every second to
+        # sixth draw, checked on the host -- int8_epilogue() needs no GPU)
+        span = g.uniform(120.0, 250.0, cout)
+        mul = (span / (2 * k_total) * scale * g.choice([-1.0, 1.0], cout)).astype(np.float32)
+        bias = g.uniform(-20.0, 20.0, cout).astype(np.float32)
+        probe_w = synth.random_words(g, (1, k, k, spec.in_words), cin)
         plan = amd.Bconv2dPlan(_params(spec, amd.I8, out_scale=scale, out_zero_point=zp))
-        plan.set_weights(w, mul, bias)
+        plan.set_weights(np.repeat(probe_w, cout, axis=0), mul, bias)
         plan.set_option("engine", eng)
         forms, adjusted = plan.int8_epilogue()
         assert plan.kernel_name().startswith(kernel), plan.kernel_name()
         if not (forms and adjusted > 0):
             continue
         adjusted_plans += 1
+        x, w = _every_accumulator_inputs(spec, g)            # (built only for the plans that are run: ~1 s of NumPy each)
+        plan.set_weights(w, mul, bias)
+        assert plan.int8_epilogue() == (forms, adjusted)     # (the proof depends on the parameters, not on the filter bits)
         want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=scale, out_zero_point=zp, threads=NTHREADS)
         xd = torch.from_numpy(x).to(DEV)
         if unaligned:

@@ -489,6 +489,22 @@ def test_second_output_of_an_int8_layer_is_its_lcequantize(engine, tile, k, zp):
         assert 0.02 < (want < zp).mean() < 0.98 and (want == zp).any()
 
 
+@pytest.mark.parametrize("engine", ["direct", "mfma"])
+@pytest.mark.parametrize("cout,zp", [(80, 12), (48, 1), (80, -5), (112, 127), (16, 40)])
+def test_second_output_of_an_int8_layer_with_a_ragged_channel_count(engine, cout, zp):
+    """Round 6 (found by the randomized GPU test): the padding bits of a row's last word are 0 (bitpack.h:238-244) whatever the zero
+    point -- the block GEMM compares EVERY lane with one threshold, and a padded lane (multiplier and bias 0: value 0) was "below"
+    every positive zero point.  Cout = 80: the third word holds 16 channels; the planner now gives padded lanes the bias +inf."""
+    spec = O.ConvSpec(1, 5, 6, 20, 2, 2, cout, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 1, negative_mul_fraction=0.2)
+    words = np.full(spec.output_shape(O.DST_BITPACKED), 0x5A5A5A5A, np.int32)
+    got, name = H.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=1.0 / 9.0, out_zero_point=zp, engine=engine, sign_words=words)
+    want = O.bconv2d(spec, O.DST_I8, x, w, mul, bias, out_scale=1.0 / 9.0, out_zero_point=zp)
+    assert np.array_equal(got, want), name
+    assert np.array_equal(words, O.bitpack(want, zp)), name
+    assert cout % 32 == 0 or not (words[..., -1].view(np.uint32) >> np.uint32(cout % 32)).any()
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (96, 32)])
 def test_pointwise_second_output_of_a_float_layer(cin, cout):
     spec = O.ConvSpec(3, 7, 9, cin, 1, 1, cout, activation=O.ACT_RELU)
