@@ -168,6 +168,51 @@ __device__ unsigned long long lce_phase_tl[16384 * 16];
 #define LCE_STORE_PACE 2   // s_sleep argument behind every float row store of the joint-transpose epilogue
 #endif
 template <int V> struct IntC { static constexpr int value = V; };
+
+// The 32 channel bits of every pixel row of NJ accumulator tiles -> the lanes that store them: register r of a tile holds pixel rows q
+// (lanes 0-31) and q + 4 (lanes 32-63), q = (r & 3) + 8 * (r >> 2); one compare + ballot per register and tile, v_writelane drops each
+// half into lane q / q + 4 of words[j] -- afterwards lane p < 32 owns row p.  BELOW: bit = value < thr (the second output: LceQuantize of
+// the value), else bit = value > thr (bitpacked output: accumulator > threshold, output_transform.h:160-168).
+// A v_writelane must not read an SGPR that a VALU compare wrote less than 4 wait states ago (stale lanes on gfx950, round 2).  Until
+// round 6 the pointwise and weight-streaming kernels padded every register's compares with an `s_nop 4` -- 16 per tile, 47 of the 159
+// instructions of the pointwise kernel's second-output path counting the compiler's own.  Here the ballots of register r reach their
+// lanes TWO registers later: between the compares of r and its lane writes lie the compares of r + 1 and r + 2 and -- through the
+// chain of words[j] -- the lane writes of r - 1: at least six instructions, no padding (the idiom of lce_kernels_stream.h, `hold_until`);
+// one padded point remains, for the last register.
+template <int NJ, bool BELOW>
+LCE_DEVICE void gather_tile_bits(const f32x16 (&a)[NJ], const float (&thr)[NJ], uint32_t (&words)[NJ]) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) words[j] = 0u;
+  unsigned long long p1[NJ], p2[NJ];        // the ballots of registers r - 1 and r - 2
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) p1[j] = p2[j] = 0ull;
+  auto flush = [&](auto rc, unsigned long long (&pend)[NJ]) LCE_LAMBDA_INLINE {
+    constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      words[j] = write_lane_settled<q>((uint32_t)pend[j], words[j]);
+      words[j] = write_lane_settled<q + 4>((uint32_t)(pend[j] >> 32), words[j]);
+    }
+  };
+  auto unit = [&](auto rc) LCE_LAMBDA_INLINE {
+    constexpr int r = decltype(rc)::value;
+    unsigned long long bits[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bits[j] = wave_ballot(BELOW ? a[j][r] < thr[j] : a[j][r] > thr[j]);
+    if constexpr (r >= 2) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) hold_until(p2[j], bits[0], bits[NJ - 1]);   // register r - 2's lane writes: behind THESE compares
+      flush(IntC<(r >= 2 ? r - 2 : 0)>{}, p2);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { p2[j] = p1[j]; p1[j] = bits[j]; }
+  };
+  unit(IntC<0>{}); unit(IntC<1>{}); unit(IntC<2>{}); unit(IntC<3>{}); unit(IntC<4>{}); unit(IntC<5>{}); unit(IntC<6>{}); unit(IntC<7>{});
+  unit(IntC<8>{}); unit(IntC<9>{}); unit(IntC<10>{}); unit(IntC<11>{}); unit(IntC<12>{}); unit(IntC<13>{}); unit(IntC<14>{}); unit(IntC<15>{});
+  settle_ballots(p1);                       // (register 15's compares are only 2 * NJ lane writes away: the one padded point)
+  flush(IntC<14>{}, p2);
+  flush(IntC<15>{}, p1);
+}
 struct StepSteady { static constexpr bool value = true; };
 struct StepTail { static constexpr bool value = false; };
 

@@ -150,24 +150,7 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
       // q = (r & 3) + 8 * (r >> 2): one compare + ballot per 32 channels, v_writelane drops the word into
       // the lane that stores it -- afterwards lane p < 32 owns row p (as bit_rows in lce_kernels_mfma.h)
       uint32_t words[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) words[j] = 0u;
-      auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
-        constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
-        unsigned long long bits[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bits[j] = wave_ballot(acc[j][r] > tj[j]);
-        settle_ballots(bits);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);
-          words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);
-        }
-      };
-      gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
-      gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
-      gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
-      gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
+      gather_tile_bits<NJ, false>(acc, tj, words);          // (lce_kernels_mfma.h: no hazard padding per register)
       const uint32_t m = row0 + (uint32_t)lane;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) hold[S][0][j] = words[j];
@@ -222,24 +205,10 @@ bconv2d_pointwise(const PwArgs P, const uint32_t* __restrict__ in, const uint8_t
       // "rounds below the zero point" threshold for int8), gathered like the bitpacked output above
       if (sign_words != nullptr) {
         uint32_t words[NJ];
+        float bthr[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) words[j] = 0u;
-        auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
-          constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
-          unsigned long long bits[NJ];
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) bits[j] = wave_ballot(acc[j][r] < P.bit_thr);
-          settle_ballots(bits);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);
-            words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);
-          }
-        };
-        gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
-        gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
-        gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
-        gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
+        for (int j = 0; j < NJ; ++j) bthr[j] = P.bit_thr;
+        gather_tile_bits<NJ, true>(acc, bthr, words);
         const uint32_t m = row0 + (uint32_t)lane;
         if (lane < 32 && m < (uint32_t)P.M) {
           uint32_t* o = sign_words + (size_t)m * (size_t)P.Wout + (size_t)(n0 >> 5);

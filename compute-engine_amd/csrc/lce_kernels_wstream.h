@@ -194,24 +194,7 @@ bconv2d_wstream(const WsArgs G, const uint8_t* __restrict__ xin, const uint8_t* 
   // 32 channel bits of every pixel row of accumulator tile j -> the lanes that store them (lane p < 32 owns row p):
   // register r holds rows q (lanes 0-31) and q + 4 (lanes 32-63), q = (r & 3) + 8 * (r >> 2)
   auto gather_bits = [&](const f32x16 (&a)[2], const float (&thr)[2], auto below, uint32_t (&words)[2]) LCE_LAMBDA_INLINE {
-    constexpr bool BELOW = decltype(below)::value != 0;
-    words[0] = words[1] = 0u;
-    auto gather = [&](auto rc) LCE_LAMBDA_INLINE {
-      constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
-      unsigned long long bits[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bits[j] = wave_ballot(BELOW ? a[j][r] < thr[j] : a[j][r] > thr[j]);
-      settle_ballots(bits);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        words[j] = write_lane_settled<q>((uint32_t)bits[j], words[j]);
-        words[j] = write_lane_settled<q + 4>((uint32_t)(bits[j] >> 32), words[j]);
-      }
-    };
-    gather(IntC<0>{}); gather(IntC<1>{}); gather(IntC<2>{}); gather(IntC<3>{});
-    gather(IntC<4>{}); gather(IntC<5>{}); gather(IntC<6>{}); gather(IntC<7>{});
-    gather(IntC<8>{}); gather(IntC<9>{}); gather(IntC<10>{}); gather(IntC<11>{});
-    gather(IntC<12>{}); gather(IntC<13>{}); gather(IntC<14>{}); gather(IntC<15>{});
+    gather_tile_bits<2, decltype(below)::value != 0>(a, thr, words);       // (lce_kernels_mfma.h: no hazard padding per register)
   };
   // lane p < 32 stores pixel row p's two words of this wave's 64 channels (the second one only where it exists)
   auto store_words2 = [&](rsrc_t r, uint32_t px_row, bool row_ok, const uint32_t (&words)[2]) LCE_LAMBDA_INLINE {
