@@ -1,6 +1,9 @@
-// Host-side planner for LceBconv2d on MI355X (see lce_plan.h).
+// Host-side planner for LceBconv2d on MI355X (see lce_plan.h): validation and shape inference, parameter folding, the int8 epilogue's
+// proof, weight images, and the kernel selection.  The streaming kernels' launch planners: lce_plan_stream.cpp; the cost estimates the
+// selection compares: lce_plan_cost.cpp.
 // Citations are relative to /root/reference/larq_compute_engine/.
 #include "lce_plan.h"
+#include "lce_plan_internal.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -13,8 +16,6 @@
 #include <cstdio>
 
 namespace lce {
-
-static int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // TFLite ComputeOutSize / ComputePaddingWithOffset (tensorflow v2.16.1
 // tensorflow/lite/kernels/padding.h; third-party, restated from its published
@@ -40,6 +41,8 @@ static void read_debug_environment(HostPlan& p) {
   p.dbg_no_wstream = getenv("LCE_PLAN_NO_WSTREAM") != nullptr;
   p.dbg_int8_exact = getenv("LCE_PLAN_INT8_EXACT") != nullptr;
   p.dbg_int8_full = getenv("LCE_PLAN_INT8_FULL") != nullptr;
+  static bool table_printed = false;
+  if (p.dbg_level >= 3 && !table_printed) { table_printed = true; dump_cost_table(stderr); }
 }
 
 std::string validate_and_infer(HostPlan& p) {
@@ -156,7 +159,12 @@ float int8_below_threshold(int32_t zero_point) {
   if (zero_point <= -128) return -std::numeric_limits<float>::infinity();   // no int8 is below it
   if (zero_point > 127) return std::numeric_limits<float>::infinity();      // every int8 is
   // monotone key over floats: negative floats descend with their bit pattern
-  auto from_key = [](int64_t k) { uint32_t u = k >= 0 ? (uint32_t)k : 0x80000000u | (uint32_t)(-k - 1); float f; memcpy(&f, &u, 4); return f; };
+  auto from_key = [](int64_t k) {
+    uint32_t u = k >= 0 ? (uint32_t)k : 0x80000000u | (uint32_t)(-k - 1);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
   auto to_key = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? -(int64_t)(u & 0x7fffffffu) - 1 : (int64_t)u; };
   int64_t lo = to_key(-128.0f), hi = to_key(127.0f);   // round(lo) = -128 < zero_point <= 127 = round(hi)
   while (hi - lo > 1) {
@@ -282,7 +290,8 @@ bool pointwise_supported(const HostPlan& p, int64_t pixels, int* nc, int* nj) {
   if (c == 0) return false;
   const int t = d.channels_out / 32;
   int j = t % 4 == 0 ? 4 : t % 2 == 0 ? 2 : 1;
-  if (c == 8 || d.dst_type == LCE_HIP_F32) j = std::min(j, 2);   // (float: 16 row stores of a 128-channel tile + the bank do not fit 256 VGPRs)
+  // (float: 16 row stores of a 128-channel tile + the bank do not fit 256 VGPRs)
+  if (c == 8 || d.dst_type == LCE_HIP_F32) j = std::min(j, 2);
   if (p.pw_nj_pref > 0) {
     if (t % p.pw_nj_pref != 0) return false;
     j = std::min(j, p.pw_nj_pref);          // (a tuning aid: what the instances cannot do is clamped, not refused)
@@ -337,456 +346,6 @@ PwArgs make_pw_args(const HostPlan& p, int batch_chunk) {
   return P;
 }
 
-
-// ------------------------------------------------------------------------------------
-// weight-stationary streaming kernel (lce_kernels_stream.h)
-// ------------------------------------------------------------------------------------
-bool stream_supported(const HostPlan& p) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  if (!mfma_supported(p) || d.groups != 1) return false;
-  if (d.filter_height != 3 || d.filter_width != 3) return false;          // the instantiated filter extents
-  if (d.dilation_height != 1 || d.dilation_width != 1) return false;       // tap offsets are instruction immediates
-  if (p.zero_pad_mode == kZeroPadCorrection) return false;                 // that epilogue lives in the block GEMM
-  // a lane stores 16 bytes of one pixel's channels: whole groups of 4 floats / 16 int8 only
-  if (d.dst_type == LCE_HIP_F32 && d.channels_out % 4) return false;
-  if (d.dst_type == LCE_HIP_I8 && d.channels_out % 16) return false;
-  const int kch = stream_chunks(d);
-  // the filter bank must fit the register file: up to 4 chunks of 64 input channels per wave, or 8 split over a pair of
-  // waves (KSPLIT, lce_kernels_stream.h)
-  return kch == 1 || kch == 2 || kch == 4 || kch == 8;
-}
-
-// Simulates a block's stream for segments of `rs` output rows, `spb` segments per block: what each tile step needs
-// resident, a production schedule in quotas of 256 items (one per lane; 512 where 256 would fall behind) that meets
-// it, and the ring rows that keep every row a tile step reads apart from every row it writes.
-// flat: pixel blocks are cut from the CONCATENATED pixels of the block's segments (whole images whose pixel count is not a
-// multiple of 32 -- 7x7: 49 pixels would fill 77 % of two blocks): a block may then read rows of two segments.
-// ow / in_w: output columns and input columns (halo included) of a segment -- the whole row, or one column strip of it.
-static bool simulate_stream(const HostPlan& p, int rs, int spb, int pph_log, bool flat, int ow, int in_w, int* ring_rows, std::vector<uint32_t>* sched) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  const int kh = d.filter_height, sh = d.stride_height;
-  const int srs = (rs - 1) * sh + kh, pbs = ceil_div(rs * ow, 32);
-  const int cpw = stream_chunks(d) * 2, qg = ceil_div(cpw, 4);
-  const int64_t ipr = (int64_t)in_w * qg;
-  const int pph = 1 << pph_log;
-  const int64_t npx = (int64_t)rs * ow;
-  const int64_t nblk = flat ? (spb * npx + 31) / 32 : (int64_t)spb * pbs;
-  const int64_t usteps = (nblk + pph - 1) / pph, ntile = (usteps + 3) / 4;
-  const int64_t total = (int64_t)spb * srs * ipr;
-  if (ntile < 1 || total >= (1ll << 31) || ntile > (1 << 20)) return false;
-  std::vector<int64_t> need(ntile + 2), first(ntile);
-  for (int64_t t = 0; t < ntile; ++t) {
-    int64_t hi = 0, lo = INT64_MAX;
-    for (int64_t q = 4 * t * pph; q < std::min<int64_t>(nblk, 4 * (t + 1) * pph); ++q) {
-      if (flat) {
-        const int64_t p0 = q * 32, p1 = std::min<int64_t>(q * 32 + 31, spb * npx - 1);   // first / last pixel of the block
-        lo = std::min(lo, (p0 / npx) * srs + (p0 % npx) / ow * sh);
-        hi = std::max(hi, (p1 / npx) * srs + (p1 % npx) / ow * sh + kh - 1);
-        continue;
-      }
-      const int64_t gl = q / pbs, pb = q % pbs;
-      const int64_t r_first = std::min<int64_t>(pb * 32 / ow, rs - 1), r_last = std::min<int64_t>((pb * 32 + 31) / ow, rs - 1);
-      lo = std::min(lo, gl * srs + r_first * sh);
-      hi = std::max(hi, gl * srs + r_last * sh + kh - 1);
-    }
-    need[t] = std::min(total, (hi + 1) * ipr);
-    first[t] = lo;
-  }
-  need[ntile] = need[ntile + 1] = need[ntile - 1];
-  for (int64_t t = 1; t < ntile; ++t) need[t] = std::max(need[t], need[t - 1]);
-  // latest production that still works with at most 512 items per tile step (768 on the K-split kernel, whose pixels are
-  // four items wide: it weaves a second item between the MFMAs of block steps 2 and 3) ...
-  const int64_t cap = stream_ksplit(p) ? 768 : 512;
-  std::vector<int64_t> m(ntile + 2), s(ntile + 2);
-  m[ntile + 1] = m[ntile] = need[ntile];
-  for (int64_t t = ntile - 1; t >= 0; --t) m[t] = std::max(need[t], m[t + 1] - cap);
-  // ... and going forward, the smallest quota (nothing, one item per lane, two) that keeps up with it
-  s[0] = m[0];
-  for (int64_t t = 0; t <= ntile; ++t) {
-    int64_t inc = 0;
-    while (s[t] + inc < m[t + 1]) inc += 256;
-    s[t + 1] = std::min(total, s[t] + inc);
-    if (s[t + 1] < m[t + 1] || inc > cap) return false;   // cannot happen (m is feasible by construction)
-  }
-  int64_t rows = kh;
-  for (int64_t t = 0; t < ntile; ++t)
-    if (s[t + 1] > 0) rows = std::max(rows, (s[t + 1] - 1) / ipr - first[t] + 1);
-  *ring_rows = (int)rows;
-  sched->resize(ntile + 2);
-  for (int64_t t = 0; t < ntile + 2; ++t) (*sched)[t] = (uint32_t)s[t];
-  return true;
-}
-
-static uint32_t stream_row_bytes(const HostPlan& p) {
-  return p.d.dst_type == LCE_HIP_BITPACKED ? (uint32_t)p.wout * 4u : (uint32_t)p.d.channels_out * (p.d.dst_type == LCE_HIP_I8 ? 1u : 4u);
-}
-
-static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::string* why);
-
-std::string plan_stream(HostPlan& p, int batch_chunk) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  if (!stream_supported(p))
-    return "bconv2d: the streaming kernel runs ungrouped 3x3 convolutions without dilation, with at most 512 input "
-           "channels (on its 64-, 128-, 256- or 512-channel instance) and whole 16-byte groups of output channels (float: a multiple of 4, "
-           "int8: of 16), and not the SAME-zero correction semantics";
-  const uint32_t row_bytes = stream_row_bytes(p);
-  if ((int64_t)batch_chunk * p.out_h * p.out_w * row_bytes >= (1ll << 31))
-    return "bconv2d: the streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
-  // Whole rows first; an image too wide for that (the ring holds 9-12 padded rows: 224 x 144 B x 12 does not fit) is cut into
-  // column strips of 64 or 32 output columns (round 4; instances exist for the 256-channel bank).
-  std::vector<int> widths;
-  if (p.stream_strip_pref <= 0) widths.push_back(0);
-  // (a strip width forced on a layer whose bank is not the 256-channel one: say so, instead of "the ring does not fit")
-  if (p.stream_strip_pref > 0 && stream_chunks(d) != 4)
-    return "bconv2d: stream_strip: column strips exist for the 256-channel filter bank only (193..256 input channels)";
-  if (stream_chunks(d) == 4 && p.stream_strip_pref != 0) {
-    if (p.stream_strip_pref > 0) {
-      if (p.stream_strip_pref % 32 != 0 || p.out_w % p.stream_strip_pref != 0)
-        return "bconv2d: stream_strip must be a multiple of 32 that divides the output width";
-      widths.push_back(p.stream_strip_pref);
-    } else if (p.out_w % 32 == 0 && p.out_w > 64) {
-      if (p.out_w % 64 == 0) widths.push_back(64);
-      widths.push_back(32);
-    }
-  }
-  std::string why = "bconv2d: the streaming kernel's row ring does not fit LDS for this layer";
-  for (int wso : widths)
-    if (plan_stream_geometry(p, batch_chunk, wso, &why)) return "";
-  return why;
-}
-
-// One attempt: segments of whole rows (wso == 0) or of column strips `wso` output columns wide.
-static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::string* why) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  const uint32_t row_bytes = stream_row_bytes(p);
-  const bool strips = wso > 0;
-  const int nstrip = strips ? p.out_w / wso : 1;
-  const int ow_seg = strips ? wso : p.out_w;                                                  // output columns of a segment
-  const int in_w_seg = strips ? (wso - 1) * d.stride_width + d.filter_width : d.in_width;     // input columns a ring row holds
-  const int nsl = ceil_div(d.channels_out, 64);
-  // waves of a block = (64-channel slices) x (pixel phases).  By default all four waves take slices when there are >= 3 of
-  // them; `stream_pixel_phases` forces the split (256 channels as 2 slices x 2 phases puts half the filter bank on a CU and
-  // two images' rows through it: the bank's arrival -- 295 KB per CU otherwise -- is what a single-round launch waits for)
-  int pph_log = nsl >= 3 ? 0 : nsl == 2 ? 1 : 2;
-  if (p.stream_phases_pref > 0) pph_log = std::max(pph_log, p.stream_phases_pref == 4 ? 2 : p.stream_phases_pref == 2 ? 1 : 0);
-  const bool ksplit = stream_ksplit(p);     // 512 input channels: waves = 2 slices x 2 K-halves, one pixel block per step
-  if (ksplit) pph_log = 0;
-  const int nslb = ksplit ? 2 : 4 >> pph_log, ny = ceil_div(nsl, nslb), pph = 1 << pph_log;
-  const int wp = strips ? in_w_seg
-                        : (int)std::max<int64_t>(p.pad_w + d.in_width, (int64_t)(p.out_w - 1) * d.stride_width + d.filter_width);
-  const int kch = stream_chunks(d), ps = kch * 32 + 16;
-  // Ring row pitch.  An A-fragment read is one 16-byte piece per lane, lane = pixel; the LDS serves 16 lanes per pass without
-  // conflicts when their 16-byte units differ mod 16.  Along a row consecutive pixels are ps / 16 (odd) units apart: fine.
-  // Where a 32-pixel block wraps to the next output row the unit jumps by pitch / 16 - (OW - 1) * SW * ps / 16 instead, and
-  // with pitch = wp * ps (two padding columns) two lanes of the pass collide: every wrap costs a second pass (profiles/r03
-  // PMC: 21 % of the LDS pipe's cycles on L0, 39 % on 14x14x256).  A skew of < 256 bytes per row makes the sequence continue
-  // across the wrap: SH * pitch / 16 = OW * SW * ps / 16 (mod 16).  (Solvable when SH is odd; otherwise no skew.)
-  int skew16 = 0;
-  if (d.stride_height % 2 == 1 && !strips) {     // (a strip is a multiple of 32 columns: a pixel block never wraps)
-    const int want = (int)(((int64_t)p.out_w * d.stride_width * (ps / 16)) % 16);
-    for (int k = 0; k < 16; ++k)
-      if (((int64_t)d.stride_height * ((int64_t)wp * (ps / 16) + k)) % 16 == want) { skew16 = k; break; }
-  }
-#ifdef LCE_STREAM_NO_SKEW   // (A/B aid)
-  skew16 = 0;
-#endif
-  const int pitch = wp * ps + skew16 * 16;
-  const int cus = std::max(1, p.num_cus / ny);
-  // segment size (a divisor of the output height: every segment is whole): the fewest block steps on the busiest
-  // block (ties: the longer segment, whose halo is re-expanded less)
-  // segments per block: as many as spread the launch over the CUs (a strip run may pass into the next strip or image: the
-  // kernel works out every segment's place in the output)
-  auto run_length = [&](int rseg) -> int64_t {
-    const int64_t s = (int64_t)batch_chunk * nstrip * rseg, gx = std::min<int64_t>(s, cus);
-    const int64_t spb = (s + gx - 1) / gx;
-    return strips ? std::min<int64_t>(spb, 128) : spb;      // (the kernel's per-run segment table holds 128 entries)
-  };
-  struct Cand { int rs; int64_t cost; };
-  std::vector<Cand> cands;
-  for (int rs = p.out_h; rs >= 1; --rs) {
-    if (p.out_h % rs) continue;
-    if (p.stream_rows_pref > 0 && rs != p.stream_rows_pref) continue;
-    const int64_t spb = run_length(p.out_h / rs), s = (int64_t)batch_chunk * nstrip * (p.out_h / rs);
-    const bool flat_c = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat && ksplit;   // (the K-split instances are the ones built for it)
-    const int64_t blocks = flat_c ? (spb * rs * p.out_w + 31) / 32 : spb * ceil_div(rs * ow_seg, 32);
-    const int64_t rounds = (ceil_div((int)s, (int)spb) + cus - 1) / cus;      // (strips: more blocks than CUs run in rounds)
-    const int64_t steps = (blocks + pph - 1) / pph;
-    // (ties, strips: segments of about 14 rows -- 224x224x256 measured 0.194 ms with 14-row segments, 0.201 with 28 / 56 / 112,
-    //  profiles/r04/strips_224.txt; whole rows: the longer one, whose halo rows are re-expanded less)
-    cands.push_back(Cand{rs, (steps + 4) * rounds * 4096 + (strips ? std::abs(rs - 14) : 0)});
-  }
-  if (cands.empty()) { *why = "bconv2d: stream_rows must divide the output height"; return false; }
-  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.cost < b.cost; });
-  for (const Cand& c : cands) {
-    const int rs = c.rs, rseg = p.out_h / rs, spi = nstrip * rseg;
-    const int64_t s = (int64_t)batch_chunk * spi, spb = run_length(rseg);
-    int rows = 0;
-    std::vector<uint32_t> sched;
-    // whole small images whose pixels do not fill 32-pixel blocks: cut the blocks from the block's images laid end to end
-    // (the output tensor is laid out that way: NHWC with nothing between images)
-    const bool flat = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat && ksplit;   // (the K-split instances are the ones built for it)
-    if (!simulate_stream(p, rs, (int)spb, pph_log, flat, ow_seg, in_w_seg, &rows, &sched)) continue;
-    const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
-    if (ring + stream_lds_extra(p) > 160 * 1024) continue;
-    const int pbs = ceil_div(rs * ow_seg, 32);
-    // (the strips epilogue's out-of-line path does not add the segment's place: a strip is a multiple of 32 columns, so no block is partial)
-    if (strips && (rs * ow_seg) % 32 != 0) continue;
-    const int64_t nq = flat ? (spb * (int64_t)rs * p.out_w + 31) / 32 : spb * pbs;
-    p.st_flat = flat ? 1 : 0;
-    p.st_nq = (int)nq;
-    // Interleaved runs (round 5): block b owns segments b, b + gx, b + 2 gx, ... instead of spb consecutive ones, so that at any
-    // moment the launch writes gx CONSECUTIVE segments -- one window of gx * rs * OW pixels moving through the output -- instead
-    // of gx streams a whole run apart.  Same segments, same ring schedule, same tables but for the output offsets.  (Flat runs
-    // cut pixel blocks across consecutive images: they stay consecutive.)
-    const int64_t gx_plan = ceil_div((int)s, (int)spb);
-    const int64_t gstr = (p.stream_interleave_pref > 0 && !flat && spb > 1) ? gx_plan : 1;
-    p.st_gstr = (int)gstr;
-    if (nq * 1024 > (64ll << 20)) continue;               // the context table: 1 KiB per pixel block
-    p.st_rs = rs; p.st_spi = spi; p.st_srs = (rs - 1) * d.stride_height + d.filter_height;
-    p.st_pbs = pbs; p.st_pph_log = pph_log; p.st_ny = ny;
-    p.st_qg = ceil_div(kch * 2, 4); p.st_ipr = in_w_seg * p.st_qg;
-    p.st_nstrip = nstrip; p.st_rseg = rseg; p.st_wso = ow_seg;
-    p.st_spb = (int)spb; p.st_gx = (int)ceil_div((int)s, (int)spb); p.st_rows = rows; p.st_ring_bytes = (int)ring;
-    p.st_batch = batch_chunk;
-    p.wp = wp;
-    if (p.dbg_level >= 2) fprintf(stderr, "[lce plan] stream geometry: rows/segment %d, ring %d rows x %d B = %lld B (+%d), blocks %d x %d, segments/block %lld\n", rs, rows, pitch, (long long)ring, stream_lds_extra(p), p.st_gx, ny, (long long)spb);
-    p.st_pitch = pitch;
-    // ---- the tables: [sched | lim | ctx] ----
-    const size_t n_sched = (sched.size() + 3) / 4 * 4, n_lim = ((size_t)nq + 3) / 4 * 4;
-    const size_t n_sgn = d.dst_type == LCE_HIP_BITPACKED ? 0 : (size_t)nq * 64;
-    const size_t n_seg = strips ? ((size_t)nq + 3) / 4 * 4 : 0;
-    p.st_tab_lim = (uint32_t)(n_sched * 4);
-    p.st_tab_ctx = (uint32_t)((n_sched + n_lim) * 4);
-    p.st_tab_sgn = (uint32_t)((n_sched + n_lim + (size_t)nq * 256) * 4);
-    p.st_tab_seg = (uint32_t)((n_sched + n_lim + (size_t)nq * 256 + n_sgn) * 4);
-    p.st_tabs.assign(n_sched + n_lim + (size_t)nq * 256 + n_sgn + n_seg, 0u);
-    std::copy(sched.begin(), sched.end(), p.st_tabs.begin());
-    for (size_t i = sched.size(); i < n_sched; ++i) p.st_tabs[i] = sched.back();
-    const int npx = rs * ow_seg, sh = d.stride_height, sw = d.stride_width;
-    const int64_t total_px = spb * (int64_t)npx;                             // flat: pixels of a full block's stream
-    const bool ragged = flat ? total_px % 32 != 0 : npx % 32 != 0;
-    // lanes that share a stored pixel row (lce_kernels_stream.h, LPR): the K-split kernel stores 32 channels per wave
-    const int lpr = d.dst_type == LCE_HIP_F32 ? (ksplit ? 8 : 16) : d.dst_type == LCE_HIP_I8 ? (ksplit ? 2 : 4) : 0;
-    for (int64_t q = 0; q < nq; ++q) {
-      // pixel block q = pixels [first, first + 32) of segment gl (flat: of the block's segments laid end to end)
-      const int64_t gl = flat ? 0 : q / pbs, pb = flat ? q : q % pbs;
-      const int64_t seg_px = flat ? total_px : npx;
-      const bool partial = ragged && (flat ? q == nq - 1 : pb == pbs - 1);
-      p.st_tabs[n_sched + q] = (uint32_t)std::min<int64_t>(31, seg_px - pb * 32 - 1);
-      for (int lane = 0; lane < 64; ++lane) {
-        const int l31 = lane & 31, half = lane >> 5;
-        int64_t pix = std::min<int64_t>(pb * 32 + l31, seg_px - 1);          // rows past the segment re-read its last pixel
-        const int64_t sg_ = flat ? pix / npx : gl;                           // the segment the pixel lies in
-        if (flat) pix %= npx;
-        const int64_t r = pix / ow_seg, ox = pix % ow_seg;
-        const int64_t s0 = sg_ * p.st_srs + r * sh;
-        uint32_t* e = &p.st_tabs[n_sched + n_lim + ((size_t)q * 64 + lane) * 4];
-        for (int fy = 0; fy < 3; ++fy)
-          e[fy] = (uint32_t)(((s0 + fy) % rows) * pitch + ox * sw * ps + half * 16);
-        const int rowl = lpr ? lane / lpr : l31;
-        // output pixel of the lane's first stored row, relative to the run's first pixel: segments and their pixels follow each
-        // other in memory -- or (strips) a segment's rows are OW pixels apart and a pixel block lies inside one of them
-        // (strips: relative to the SEGMENT's first pixel; the kernel adds the segment's place)
-        // (interleaved runs: the block's local segment gl is segment g0 + gl * gstr of the launch)
-        const int64_t blk_px = strips ? ((pb * 32) / ow_seg) * (int64_t)p.out_w + (pb * 32) % ow_seg : gl * gstr * npx + pb * 32;
-        e[3] = (uint32_t)((blk_px + rowl) * (int64_t)row_bytes);
-        if (partial) e[3] |= 0x80000000u;   // a partial pixel block: its stores go out of line
-        if (strips) p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + n_sgn + q] = (uint32_t)gl;
-        if (n_sgn) {
-          uint32_t& sg = p.st_tabs[n_sched + n_lim + (size_t)nq * 256 + (size_t)q * 64 + lane];
-          sg = (uint32_t)((blk_px + l31) * (int64_t)p.wout * 4);
-          if (partial) sg |= 0x80000000u;
-        }
-      }
-    }
-    return true;
-  }
-  return false;
-}
-
-StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  StreamArgs G{};
-  G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
-  G.OH = p.out_h; G.OW = p.out_w; G.N = d.channels_out; G.Npad = p.npad; G.Wout = p.wout;
-  G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h;
-  G.PW = p.st_nstrip > 1 ? 0 : p.pad_w;      // (a strip's ring row starts at its first input column, halo or padding)
-  G.NSTRIP = p.st_nstrip; G.RSEG = p.st_rseg; G.WSo = p.st_wso; G.XS0 = p.pad_w;
-  G.B = batch_chunk;
-  G.Wp = p.wp; G.pitch = p.st_pitch; G.R = p.st_rows; G.ring_bytes = p.st_ring_bytes;
-  G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
-  G.QG = p.st_qg; G.IPR = p.st_ipr; G.RS = p.st_rs; G.SPI = p.st_spi; G.SRS = p.st_srs; G.PBS = p.st_pbs;
-  G.S = batch_chunk * p.st_spi;
-  // a smaller launch than the one planned for (the last chunk of a batch): the same segments and tables, fewer per block
-  const int gx = std::min(G.S, std::max(1, p.num_cus / p.st_ny));
-  G.SPB = std::min(p.st_spb, ceil_div(G.S, std::max(1, gx)));
-  // (flat pixel blocks are cut for runs of exactly st_spb segments: a shorter run's last block would spill into the next
-  //  block's pixels, so a smaller launch keeps the planned run length and uses fewer blocks)
-  if (p.st_flat) G.SPB = p.st_spb;
-  G.GSTR = 1; G.G0M = G.SPB; G.GX = ceil_div(G.S, std::max(1, G.SPB));
-  if (p.st_gstr > 1) {
-    // interleaved runs: the tables' output offsets carry the PLANNED stride, so a smaller launch keeps it and its blocks' runs
-    // end earlier (block b: segments b, b + gstr, ... below S)
-    G.GSTR = p.st_gstr; G.G0M = 1; G.SPB = p.st_spb; G.GX = std::min(G.S, p.st_gstr);
-  }
-  G.pph_log = p.st_pph_log;
-  G.flat = p.st_flat;
-  G.NPX = p.st_rs * p.out_w;
-  G.NQ = p.st_nq;
-  G.need0 = p.st_tabs.empty() ? 0u : p.st_tabs[0];
-  G.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
-  G.w_bytes = (uint32_t)p.wq.size();
-  G.out_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p));
-  G.tab_bytes = (uint32_t)(p.st_tabs.size() * 4);
-  G.tab_lim = p.st_tab_lim;
-  G.tab_ctx = p.st_tab_ctx;
-  G.tab_sgn = p.st_tab_sgn;
-  G.tab_seg = p.st_tab_seg;
-  G.sign_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * p.wout * 4);
-  G.bit_thr = p.bit_thr;
-  G.a_bt = (float)p.backtransform_add;
-  G.cmin = (float)p.clamp_min;
-  G.cmax = (float)p.clamp_max;
-  G.div_ipr = make_fastdiv_nb((uint32_t)G.IPR);
-  G.div_qg = make_fastdiv_nb((uint32_t)G.QG);
-  G.div_srs = make_fastdiv_nb((uint32_t)G.SRS);
-  G.div_spi = make_fastdiv_nb((uint32_t)G.SPI);
-  G.div_r = make_fastdiv_nb((uint32_t)G.R);
-  G.div_rseg = make_fastdiv_nb((uint32_t)std::max(1, G.RSEG));
-  G.div_gstr = make_fastdiv_nb((uint32_t)G.GSTR);
-  return G;
-}
-
-// ------------------------------------------------------------------------------------
-// weight-streaming kernel (lce_kernels_wstream.h)
-// ------------------------------------------------------------------------------------
-bool wstream_supported(const HostPlan& p) {
-  if (!stream_supported(p)) return false;                     // 3x3, no dilation, no groups, whole 16-byte channel groups, not the correction semantics
-  const int kch = stream_chunks(p.d);
-  return kch == 2 || kch == 4 || kch == 8;                    // the instantiated K depths (128 / 256 / 512 input channels)
-}
-
-// Cycle model of one launch, used to pick the group size and (select_kernel) to rank this kernel against the weight-stationary
-// one.  Calibrated on profiles/r05/wstream_phases.txt: an MFMA of a K loop costs ~34 cycles of its SIMD whichever of the two
-// resident blocks issues it; a block's prologue (expansion of its group's images: a global round trip + ~70 VALU per item) and
-// epilogue (~450 cycles per pixel block) are hidden by the co-resident block except for the first prologue and the last epilogue.
-static int64_t wstream_cost(int64_t blocks, int cus, int occupancy, const std::vector<int>& nb_of_block, int ks, int items_per_lane) {
-  // blocks are dispatched in index order, round-robin over the CUs
-  std::vector<int64_t> load(cus, 0);
-  int64_t worst = 0, last_nb = 0;
-  for (int64_t b = 0; b < blocks; ++b) {
-    load[b % cus] += nb_of_block[b];
-    worst = std::max(worst, load[b % cus]);
-  }
-  for (int64_t b = std::max<int64_t>(0, blocks - cus); b < blocks; ++b) last_nb = std::max<int64_t>(last_nb, nb_of_block[b]);
-  const int64_t rounds = (blocks + (int64_t)cus * occupancy - 1) / ((int64_t)cus * occupancy);
-  const int64_t prologue = 2200 + 300 * items_per_lane, epilogue = 450 * last_nb;
-  return worst * ks * 2 * 34 + rounds * prologue + epilogue + (occupancy < 2 ? (blocks + cus - 1) / cus * (prologue + epilogue) : 0);
-}
-
-std::string plan_wstream(HostPlan& p, int batch_chunk) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  if (!wstream_supported(p))
-    return "bconv2d: the weight-streaming kernel runs ungrouped 3x3 convolutions without dilation over 65 .. 512 input channels "
-           "(on its 128-, 256- or 512-channel instance) and whole 16-byte groups of output channels (float: a multiple of 4, int8: of 16), and not the "
-           "SAME-zero correction semantics";
-  if ((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p) >= (1ll << 31))
-    return "bconv2d: the weight-streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
-  const int kch = stream_chunks(d), ps = kch * 32 + 16, ks = 9 * kch;
-  const int hp = (p.out_h - 1) * d.stride_height + d.filter_height, wp = (p.out_w - 1) * d.stride_width + d.filter_width;
-  // row pitch: a skew of < 256 bytes so that a 32-pixel block that wraps to the next output row keeps hitting distinct LDS banks
-  // (the streaming kernel's rule, plan_stream_geometry)
-  int skew16 = 0;
-  if (d.stride_height % 2 == 1) {
-    const int want = (int)(((int64_t)p.out_w * d.stride_width * (ps / 16)) % 16);
-    for (int k = 0; k < 16; ++k)
-      if (((int64_t)d.stride_height * ((int64_t)wp * (ps / 16) + k)) % 16 == want) { skew16 = k; break; }
-  }
-  const int pitch = wp * ps + skew16 * 16, img_pitch = hp * pitch;
-  const int qg = ceil_div(kch * 2, 4), ohw = p.out_h * p.out_w;
-  const int ny = ceil_div(ceil_div(d.channels_out, 64), 4), cus = std::max(1, p.num_cus);
-  int best_ipb = 0;
-  int64_t best_cost = 0;
-  const int nbmax = p.ws_blocks_pref > 0 ? p.ws_blocks_pref : 4;       // pixel blocks per block (tuning aid: wstream_blocks)
-  for (int ipb = 1; ipb <= std::min(batch_chunk, 64); ++ipb) {
-    if (p.ws_images_pref > 0 && ipb != p.ws_images_pref) continue;
-    const int64_t lds_images = ((int64_t)ipb * img_pitch + 1023) / 1024 * 1024;
-    if (lds_images + kWsLdsExtra > 160 * 1024) break;
-    const int occupancy = (int)std::min<int64_t>(2, (160 * 1024) / (lds_images + kWsLdsExtra));
-    const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, nbmax), groups = ceil_div(batch_chunk, ipb);
-    std::vector<int> nb_of_block;
-    for (int y = 0; y < ny; ++y)
-      for (int part = 0; part < parts; ++part)
-        for (int g = 0; g < groups; ++g) nb_of_block.push_back(nq / parts + (part < nq % parts ? 1 : 0));
-    const int items_per_lane = ceil_div(ipb * hp * wp * qg, 256);
-    const int64_t cost = wstream_cost((int64_t)nb_of_block.size(), cus, occupancy, nb_of_block, ks, items_per_lane);
-    if (best_ipb == 0 || cost < best_cost) { best_ipb = ipb; best_cost = cost; }
-  }
-  if (best_ipb == 0) return "bconv2d: one image of this layer does not fit the weight-streaming kernel's LDS (whole images are resident)";
-  const int ipb = best_ipb;
-  const int nq = ceil_div(ipb * ohw, 32), parts = ceil_div(nq, nbmax);
-  p.ws_ipb = ipb; p.ws_parts = parts; p.ws_nq = nq; p.ws_npxg = ipb * ohw; p.ws_nb = ceil_div(nq, parts); p.ws_ny = ny;
-  p.ws_hp = hp; p.ws_wp = wp; p.ws_pitch = pitch; p.ws_img_pitch = img_pitch; p.ws_qg = qg;
-  p.ws_lds_images = (int)(((int64_t)ipb * img_pitch + 1023) / 1024 * 1024);
-  p.ws_occupancy = (int)std::min<int64_t>(2, (160 * 1024) / (p.ws_lds_images + kWsLdsExtra));
-  p.ws_cost = best_cost;
-  p.st_batch = batch_chunk;
-  // ---- the tables: [part | ctx] ----
-  const size_t n_part = ((size_t)parts * 2 + 3) / 4 * 4;
-  p.ws_tab_part = 0;
-  p.ws_tab_ctx = (uint32_t)(n_part * 4);
-  p.st_tabs.assign(n_part + (size_t)nq * 256, 0u);
-  int q0 = 0;
-  for (int part = 0; part < parts; ++part) {
-    const int nb = nq / parts + (part < nq % parts ? 1 : 0);
-    p.st_tabs[2 * part] = (uint32_t)q0;
-    p.st_tabs[2 * part + 1] = (uint32_t)nb;
-    q0 += nb;
-  }
-  for (int q = 0; q < nq; ++q)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int l31 = lane & 31, half = lane >> 5;
-      const int pix = std::min(q * 32 + l31, ipb * ohw - 1);      // rows past the group re-read its last pixel (never stored)
-      const int img = pix / ohw, oy = (pix % ohw) / p.out_w, ox = pix % p.out_w;
-      uint32_t* e = &p.st_tabs[n_part + ((size_t)q * 64 + lane) * 4];
-      for (int fy = 0; fy < 3; ++fy)
-        e[fy] = (uint32_t)((int64_t)img * img_pitch + (int64_t)(oy * d.stride_height + fy) * pitch + (int64_t)ox * d.stride_width * ps + half * 16);
-    }
-  return "";
-}
-
-WsArgs make_ws_args(const HostPlan& p, int batch_chunk) {
-  const lce_hip_bconv2d_desc& d = p.d;
-  WsArgs G{};
-  G.H = d.in_height; G.W = d.in_width; G.Cw = p.cw; G.Cin = d.channels_in;
-  G.OH = p.out_h; G.OW = p.out_w; G.N = d.channels_out; G.Npad = p.npad; G.Wout = p.wout;
-  G.SH = d.stride_height; G.SW = d.stride_width; G.PH = p.pad_h; G.PW = p.pad_w;
-  G.B = batch_chunk;
-  G.IPB = p.ws_ipb; G.GROUPS = ceil_div(batch_chunk, p.ws_ipb); G.PARTS = p.ws_parts;
-  G.NPXG = p.ws_npxg; G.NQ = p.ws_nq;
-  G.Hp = p.ws_hp; G.Wp = p.ws_wp; G.pitch = p.ws_pitch; G.img_pitch = p.ws_img_pitch;
-  G.QG = p.ws_qg; G.items = p.ws_ipb * p.ws_hp * p.ws_wp * p.ws_qg;
-  G.zero_border = p.zero_pad_mode == kZeroPadExact ? 1 : 0;
-  G.noclamp = (p.clamp_min <= 0 && p.clamp_max >= 2 * p.backtransform_add) ? 1 : 0;
-  G.lds_images = (uint32_t)p.ws_lds_images;
-  G.in_bytes = (uint32_t)((int64_t)batch_chunk * d.in_height * d.in_width * p.cw * 4);
-  G.w_bytes = (uint32_t)p.wq.size();
-  G.out_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p));
-  G.sign_bytes = (uint32_t)((int64_t)batch_chunk * p.out_h * p.out_w * p.wout * 4);
-  G.tab_bytes = (uint32_t)(p.st_tabs.size() * 4);
-  G.tab_part = p.ws_tab_part;
-  G.tab_ctx = p.ws_tab_ctx;
-  G.a_bt = (float)p.backtransform_add;
-  G.cmin = (float)p.clamp_min;
-  G.cmax = (float)p.clamp_max;
-  G.bit_thr = p.bit_thr;
-  G.div_qg = make_fastdiv_nb((uint32_t)G.QG);
-  G.div_wp = make_fastdiv_nb((uint32_t)G.Wp);
-  G.div_hp = make_fastdiv_nb((uint32_t)G.Hp);
-  G.div_groups = make_fastdiv_nb((uint32_t)G.GROUPS);
-  return G;
-}
-
 static const MfmaCfg kMfmaCfgs[] = {
     {4, 2, 2, 4},  // 256 x 256, 8 waves
     {4, 2, 2, 2},  // 256 x 128, 8 waves
@@ -804,7 +363,7 @@ const MfmaCfg* mfma_cfg_by_tile(int bm, int bn) {
 
 // 64-channel chunks per tap that the blocks of a grouped convolution run: the chunks group g's channel
 // slice [g*Cin_g, (g+1)*Cin_g) touches (Cin_g is a multiple of 32, so a slice may start mid-chunk)
-static int group_chunks(const lce_hip_bconv2d_desc& d) {
+int group_chunks(const lce_hip_bconv2d_desc& d) {
   const int cin_g = d.channels_in / d.groups;
   int most = 0;
   for (int g = 0; g < d.groups; ++g)
@@ -849,8 +408,14 @@ static void prepare_int8_epilogue(HostPlan& p) {
   for (int i = n; i < p.npad; ++i) p.bias_q[i] = std::numeric_limits<float>::infinity();
   p.thr_q.assign((size_t)2 * p.npad, 0.0f);
   const bool one_rounding = p.use_stream || p.use_wstream;
-  auto two_roundings = [](float mul, float bias, int32_t x) { volatile float pr = (float)x * mul; volatile float r = pr + bias; return (float)r; };
-  auto proven_form = [&](float mul, float bias, int32_t x) { return one_rounding ? std::fmaf((float)x, mul, bias) : two_roundings(mul, bias, x); };
+  auto two_roundings = [](float mul, float bias, int32_t x) {
+    volatile float pr = (float)x * mul;
+    volatile float r = pr + bias;
+    return (float)r;
+  };
+  auto proven_form = [&](float mul, float bias, int32_t x) {
+    return one_rounding ? std::fmaf((float)x, mul, bias) : two_roundings(mul, bias, x);
+  };
   auto set_range = [&](int i, float mul, float bias, bool proven) {
     const float a0 = proven ? proven_form(mul, bias, p.clamp_min) : two_roundings(mul, bias, p.clamp_min);
     const float a1 = proven ? proven_form(mul, bias, p.clamp_max) : two_roundings(mul, bias, p.clamp_max);
@@ -860,7 +425,8 @@ static void prepare_int8_epilogue(HostPlan& p) {
     p.thr_q[p.npad + i] = std::max(-128.0f, std::min(127.0f, hi));
   };
   for (int i = 0; i < n; ++i) set_range(i, p.mul[i], p.bias[i], false);
-  p.int8_floor_ok = !p.int8_exact_pref && !p.dbg_int8_exact;   // (LCE_PLAN_INT8_EXACT, read at plan creation: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
+  // (LCE_PLAN_INT8_EXACT, read at plan creation: an A/B aid for whole stacks, tools/gpu_r05.sh i8floor)
+  p.int8_floor_ok = !p.int8_exact_pref && !p.dbg_int8_exact;
   p.int8_bias_adjusted = 0;
   const int32_t x_lo = std::max<int32_t>(0, p.clamp_min), x_hi = (int32_t)std::min<int64_t>(2 * (int64_t)p.backtransform_add, p.clamp_max);
   const bool even_only = cin_g % 2 == 0;   // (an odd channel count under zero padding: border pixels drop an odd number of terms)
@@ -883,7 +449,8 @@ static void prepare_int8_epilogue(HostPlan& p) {
     while (a < b) { const int32_t m = a + (b - a) / 2; if (not_past(m)) a = m + 1; else b = m; }
     *k1 = a;                                                                                                // [k0, k1)
   };
-  const bool check_all = p.dbg_int8_full;   // (LCE_PLAN_INT8_FULL, read at plan creation; testing aid: every value instead of the run -- tests compare the two)
+  // (LCE_PLAN_INT8_FULL, read at plan creation; testing aid: every value instead of the run -- tests compare the two)
+  const bool check_all = p.dbg_int8_full;
   auto channel_ok = [&](int i, float mul, float bias, int32_t* bad_x) {
     const float a0 = proven_form(mul, bias, p.clamp_min), a1 = proven_form(mul, bias, p.clamp_max);
     if (!(a0 == a0) || !(a1 == a1)) return false;
@@ -916,7 +483,8 @@ static void prepare_int8_epilogue(HostPlan& p) {
   for (int i = 0; i < n && p.int8_floor_ok; ++i) {
     int32_t bad = 0;
     if (channel_ok(i, p.mul[i], p.bias[i], &bad)) continue;
-    // the grid step of y around the failing value: the coarser of the product's and the bias's ulp (a smaller step is absorbed by the sum's rounding)
+    // the grid step of y around the failing value: the coarser of the product's and the bias's ulp (a smaller step is absorbed by the
+    // sum's rounding)
     const float y_bad = proven_form(p.mul[i], p.bias[i], bad), pr_bad = std::fabs((float)bad * p.mul[i]);
     const float big = std::max(std::max(pr_bad, std::fabs(p.bias[i])), std::fabs(y_bad));
     const float step = std::max(std::nextafter(big, INFINITY) - big, std::ldexp(1.0f, -20));
@@ -933,7 +501,9 @@ static void prepare_int8_epilogue(HostPlan& p) {
     }
     if (!found) {
       if (p.dbg_level >= 1)
-        fprintf(stderr, "[lce plan] int8: channel %d, accumulator %d -> y = %.9g: no neighbouring (multiplier, bias) reproduces the reference there, round-half-away instances\n",
+        fprintf(stderr,
+                "[lce plan] int8: channel %d, accumulator %d -> y = %.9g: no neighbouring (multiplier, bias) reproduces the reference "
+                "there, round-half-away instances\n",
                 i, bad, (double)y_bad);
       p.int8_floor_ok = false;
     }
@@ -942,7 +512,8 @@ static void prepare_int8_epilogue(HostPlan& p) {
     for (const auto& a : adjusted) { p.mul_q[a.i] = a.mul; p.bias_q[a.i] = a.bias; }
     for (int i = 0; i < n; ++i) set_range(i, p.mul_q[i], p.bias_q[i], true);
     p.int8_bias_adjusted = (int)adjusted.size();
-    if (p.dbg_level >= 1 && !adjusted.empty()) fprintf(stderr, "[lce plan] int8: one-instruction forms, %zu channel(s) with adjusted parameters\n", adjusted.size());
+    if (p.dbg_level >= 1 && !adjusted.empty())
+      fprintf(stderr, "[lce plan] int8: one-instruction forms, %zu channel(s) with adjusted parameters\n", adjusted.size());
   }
 }
 
@@ -951,7 +522,8 @@ static void pack_for_mfma(HostPlan& p) {
   const int taps = d.filter_height * d.filter_width, n = d.channels_out;
   const int bn = p.mfma.bn();
   const int cin_g = d.channels_in / d.groups;
-  p.cpad = ((p.use_stream || p.use_wstream) ? stream_chunks(d) : ceil_div(d.channels_in, 64)) * 64;   // (the streaming family's instances: 64 / 128 / 256 / 512)
+  // (the streaming family's instances: 64 / 128 / 256 / 512)
+  p.cpad = ((p.use_stream || p.use_wstream) ? stream_chunks(d) : ceil_div(d.channels_in, 64)) * 64;
   p.npad = ceil_div(n, bn) * bn;
   p.kch = d.groups > 1 ? group_chunks(d) : p.cpad / 64;
   const int kch = p.kch, ks_total = taps * kch;
@@ -998,7 +570,7 @@ static void pack_for_mfma(HostPlan& p) {
   }
 }
 
-static MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
+MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels) {
   // Measured on MI355X (profiles/r01/tile_sweep_*.jsonl): 4-wave blocks with two or more
   // blocks resident per CU beat the 8-wave 256x256 block (independent barriers overlap one
   // block's LDS/epilogue phases with another's MFMAs).  Pick BN by the channel count, then
@@ -1164,146 +736,8 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
 }
 
 // ------------------------------------------------------------------------------------
-// Which kernel runs a layer: a cost estimate per candidate, not a list of shapes (round 5)
+// Which kernel runs a layer: a cost estimate per candidate (lce_plan_cost.cpp), not a list of shapes (round 5)
 // ------------------------------------------------------------------------------------
-// Rounds 3-4 decided by a list of shape conditions measured at batch 256 on the bench's layers; at other batch sizes the list
-// fell through to whatever was left (profiles/r05/engine_sweep_box1.jsonl: batch 1 ... 64, the rule's pick took 1.2 - 7 x the
-// best candidate's time on 128 of 192 (layer, batch, output type) rows).  Now every candidate that can run the layer is PLANNED
-// (segments, blocks, block steps per block -- the planner's own simulation) and priced in microseconds by a small model of where
-// its time goes; the cheapest runs.  Candidates: the weight-stationary streaming kernel with the planner's own segments, or
-// with interleaved runs of r-row segments for every divisor r of the output height; the weight-streaming kernel; the block GEMM
-// (direct / workspace variant, chosen as before).  The model's constants are measured quantities (profiles/r05/README.md,
-// "cost model"): the launch floor, a block's prologue as a function of its filter bank's bytes through the CU's 51 B/clk vector
-// memory path, 33.2 cycles per FP4 MFMA at 1.2 x for the woven fillers, the epilogue's floor per block step by output type, the
-// chip's write rate by store pattern, the block GEMM's 0.14 us per K-step and 1.33 x when two blocks share a CU.
-// tests/test_planner_choice.py holds the choice to within 5 % of the best time recorded in the sweep table on every row.
-namespace cost {
-constexpr double kCyclesPerUs = 2100.0;    // the clock short launches sustain
-constexpr double kLaunchUs = 1.6;          // launch + first instruction (tools/probes/launch_floor.hip)
-constexpr double kMfmaCycles = 33.2;       // one v_mfma_f32_32x32x64_f8f6f4 with FP4 operands (tools/probes/mfma_gap.hip)
-constexpr double kVmemBytesPerClk = 51.0;  // a CU's vector memory path, loads into registers (profiles/r05/stream_phases_paced.txt)
-constexpr double kL2BytesPerUs = 27.0e6;   // what the eight L2s deliver when every CU pulls the same filter bank (75 MB in 2.8 us)
-inline double store_bytes_per_us(int dst, bool compact_window) {   // the chip's write rate by the kernel's store pattern
-  if (dst == LCE_HIP_F32) return compact_window ? 5.6e6 : 5.2e6;
-  return 5.5e6;
-}
-inline double epilogue_us_per_step(int dst) { return dst == LCE_HIP_F32 ? 1.05 : dst == LCE_HIP_I8 ? 1.0 : 0.8; }
-// what a block step of MFMAs costs over its bare matrix time, by output type (the woven epilogue, and the clock the power
-// manager grants: the more the launch writes, the lower), and how much more on launches long enough to reach the sustained state
-inline double step_factor(int dst, int64_t usteps, bool ksplit) {
-  // (K-split instances: a wave transforms and stores 32 channels of a pixel block, not 64)
-  const double base = ksplit ? (dst == LCE_HIP_F32 ? 1.15 : dst == LCE_HIP_I8 ? 1.12 : 1.05) : (dst == LCE_HIP_F32 ? 1.3 : dst == LCE_HIP_I8 ? 1.25 : 1.05);
-  const double sustained = dst == LCE_HIP_BITPACKED ? 0.1 : 0.2;
-  return base * (1.0 + sustained * std::min(1.0, (double)usteps / 100.0));
-}
-}  // namespace cost
-
-static int64_t out_bytes_of(const HostPlan& p, int batch_chunk) {
-  return (int64_t)batch_chunk * p.out_h * p.out_w * stream_row_bytes(p);
-}
-
-// The weight-stationary streaming kernel as plan_stream has just planned it (st_* fields) for launches of batch_chunk images.
-static double estimate_stream_us(const HostPlan& p, int batch_chunk) {
-  using namespace cost;
-  const int kch = stream_chunks(p.d);
-  const bool ksplit = stream_ksplit(p);
-  const double bank_kib = ksplit ? 288.0 : 72.0 * kch;                       // 4 waves x K-steps x 2 fragments x 1 KiB
-  const int64_t blocks = (int64_t)p.st_gx * p.st_ny, cus = std::max(1, p.num_cus);
-  const double bank_us = std::max(bank_kib * 1024.0 / kVmemBytesPerClk / kCyclesPerUs, (double)std::min(blocks, cus) * bank_kib * 1024.0 / kL2BytesPerUs);
-  const double prologue_us = 0.9 + bank_us + (ksplit ? 0.1 : 0.0);
-  const double mfma_us = (ksplit ? 72.0 : 18.0 * kch) * kMfmaCycles / kCyclesPerUs;    // per block step and wave
-  const int64_t usteps = ((int64_t)p.st_nq + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
-  const double step_us = std::max(step_factor(p.d.dst_type, usteps, ksplit) * mfma_us, epilogue_us_per_step(p.d.dst_type)) + (ksplit ? 0.08 : 0.0);
-  const int64_t rounds = (blocks + cus - 1) / cus;
-  // the ring's production: one quota of 256 items rides free per tile step, the rest is handled out of line
-  const double quotas = (double)p.st_spb * p.st_srs * p.st_ipr / 256.0, tiles = std::max<double>(1.0, (double)((usteps + 3) / 4));
-  const double production_us = std::max(0.0, quotas - tiles) * 0.12;
-  // a segment whose pixels do not fill its last 32-pixel block stores that block out of line, row by row
-  const bool ragged = !p.st_flat && (p.st_rs * p.st_wso) % 32 != 0;
-  const double partial_us = ragged ? (ksplit ? 0.12 : 0.2) * p.st_spb / (double)(1 << p.st_pph_log) : 0.0;
-  const double block_us = prologue_us + usteps * step_us + production_us + partial_us + 0.5;
-  const double compute_us = kLaunchUs + rounds * block_us;
-  // nothing is written before the first block step is over; from then on the chip's write rate for the pattern bounds the launch
-  // (interleaved runs: the launch writes gstr consecutive segments at a time -- the more compact that window, the closer to the
-  //  rate of one sequential stream; whole images per block: 256 streams megabytes apart)
-  double bytes_per_us = store_bytes_per_us(p.d.dst_type, false);
-  if (p.d.dst_type == LCE_HIP_F32) {
-    // (float rows: 5.0 TB/s on launches of >= 205 MB -- the power budget is shared with the matrix cores -- up to 5.65 on <= 51 MB)
-    const double mb = (double)out_bytes_of(p, batch_chunk) / 1.0e6;
-    bytes_per_us = 5.0e6 + 0.65e6 * std::min(1.0, std::max(0.0, (205.0 - mb) / 154.0));
-    // the window the launch's blocks write into at any moment: gstr consecutive segments (interleaved runs), else every block's own
-    // run -- the whole output
-    const double window = p.st_gstr > 1 ? (double)p.st_gstr * p.st_rs * p.st_wso * stream_row_bytes(p) : (double)out_bytes_of(p, batch_chunk);
-    bytes_per_us += 0.42e6 * std::min(1.0, std::max(0.0, (64.0e6 - window) / 48.0e6));
-  }
-  const double store_us = kLaunchUs + prologue_us + step_us + (double)out_bytes_of(p, batch_chunk) / bytes_per_us;
-  if (p.dbg_level >= 2)
-    fprintf(stderr, "[lce plan]   rows %d il %d: blocks %lld usteps %lld prologue %.2f step %.2f production %.2f partial %.2f compute %.2f store %.2f\n", p.st_rs, p.st_gstr > 1,
-            (long long)blocks, (long long)usteps, prologue_us, step_us, production_us, partial_us, compute_us, store_us);
-  // An instance wider than the layer (129..192 channels on the 256-channel bank, 257..448 on the 512-channel one): the expansion takes
-  // the general path (word-by-word loads, partial planes) and the K loop multiplies the padding -- measured on 40x40x192 / 20x20x320 at
-  // batch 1 .. 256 (profiles/r05/engine_sweep_padded_channels.jsonl): +2 us and 5 %, on the K-split instance +4 us and 20 %.
-  const bool padded = p.d.channels_in != 64 * kch && p.d.channels_in > 32 * kch;
-  const double us = std::max(compute_us, store_us);
-  return padded ? (ksplit ? 1.2 * us + 4.0 : 1.05 * us + 2.0) : us;
-}
-
-// The weight-streaming kernel as plan_wstream has just planned it (ws_* fields).
-static double estimate_wstream_us(const HostPlan& p, int batch_chunk) {
-  using namespace cost;
-  const int kch = stream_chunks(p.d), ks = 9 * kch, cus = std::max(1, p.num_cus);
-  const int groups = ceil_div(batch_chunk, p.ws_ipb);
-  // blocks are dispatched in index order (part-major), round-robin over the CUs: pixel blocks on the busiest CU
-  std::vector<int64_t> load(cus, 0);
-  int64_t b = 0, worst = 0;
-  int last_nb = 0;
-  for (int y = 0; y < p.ws_ny; ++y)
-    for (int part = 0; part < p.ws_parts; ++part)
-      for (int g = 0; g < groups; ++g, ++b) {
-        const int nb = p.ws_nq / p.ws_parts + (part < p.ws_nq % p.ws_parts ? 1 : 0);
-        load[b % cus] += nb;
-        worst = std::max(worst, load[b % cus]);
-        last_nb = nb;
-      }
-  const int64_t rounds = (b + (int64_t)cus * p.ws_occupancy - 1) / ((int64_t)cus * p.ws_occupancy);
-  const double crowd = std::min(1.0, (double)b / (2.0 * cus));                 // 0: blocks alone on their CUs ... 1: two per CU
-  const int items_per_lane = ceil_div(p.ws_ipb * p.ws_hp * p.ws_wp * p.ws_qg, 256);
-  const double prologue_us = (3400.0 + 600.0 * items_per_lane) / kCyclesPerUs + 0.6 * crowd;
-  // the K loops at the matrix cores' rate -- or at the rate the L2s deliver the launch's weight streams (every block pulls the
-  // whole image of its 256 channels: ks x 8 KiB)
-  // ... or, with one or two pixel blocks per block, at the latency of the weight loads (kWsPrefetch K-steps in flight)
-  const double kloop_us = std::max(std::max((double)worst * ks * 2 * (kMfmaCycles + 0.8 + 2.0 * crowd) / kCyclesPerUs, (double)b * ks * 8192.0 / kL2BytesPerUs),
-                                   0.055 * ks);
-  // K-major: a block's outputs all come at its end.  int8 / bitpacked: the transform of its pixel blocks (beside the co-resident
-  // block's); float: the stores of (most of) the launch, which the chip writes at its own rate behind the K loops
-  double tail_us;
-  if (p.d.dst_type == LCE_HIP_F32) tail_us = std::max(0.5 * last_nb, 0.8 * (double)out_bytes_of(p, batch_chunk) / 5.0e6);
-  else tail_us = (p.d.dst_type == LCE_HIP_I8 ? 0.5 + 0.45 * crowd : 0.15) * last_nb;
-  return kLaunchUs + rounds * prologue_us + (p.ws_occupancy < 2 ? 1.15 : 1.0) * kloop_us + tail_us;
-}
-
-// The block GEMM (direct or workspace variant, whichever select_kernel would take): K-steps at the LDS port's rate, two blocks
-// per CU that slow each other down, the output at the chip's write rate for block tiles.
-static double estimate_block_gemm_us(const HostPlan& p, int64_t pixels) {
-  using namespace cost;
-  const MfmaCfg c = choose_mfma_cfg(p, pixels);
-  const int64_t blocks = ((pixels + c.bm() - 1) / c.bm()) * ceil_div(p.d.channels_out, c.bn()), cus = std::max(1, p.num_cus);
-  const int ks = p.d.filter_height * p.d.filter_width * ceil_div(p.d.channels_in / std::max(1, p.d.groups), 64);
-  const double dst_f = p.d.dst_type == LCE_HIP_F32 ? 1.0 : p.d.dst_type == LCE_HIP_I8 ? 0.94 : 0.78;
-  const double area = (double)c.bm() * c.bn() / (128.0 * 128.0);
-  // a block alone on its CU runs at the latency of its K-steps (0.138 us each for 128 x 128; a smaller tile's are no shorter);
-  // a launch of many rounds at the matrix cores' / the LDS port's throughput, where the cheaper epilogues show
-  const double alone_us = (3.4 + (0.4 + 0.138 * ks) * std::max(1.0, area)) * (p.d.dst_type == LCE_HIP_BITPACKED ? 0.93 : 1.0);
-  const double round_us = (1.6 + (1.6 + 0.14 * ks) * area) * dst_f;
-  double compute_us;
-  if (blocks <= cus) compute_us = alone_us;
-  else if (blocks <= 2 * cus) compute_us = alone_us * (1.0 + 0.33 * (double)(blocks - cus) / cus);
-  else compute_us = std::max(1.33 * alone_us, 1.33 * round_us * ((double)blocks / (2.0 * cus) + 0.35));
-  const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
-  const double store_us = 2.4 + (double)out_bytes_of(p, batch_chunk) / 5.75e6;
-  return kLaunchUs + std::max(compute_us, store_us);
-}
-
 // the streaming kernel's candidates: the planner's own segments, then interleaved runs of r-row segments
 struct StreamCandidate { int rows, interleave; double us; };
 
@@ -1348,7 +782,8 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
   p.use_direct = false;
   p.use_pointwise = false;
   if (p.engine_pref == 4 && !pointwise_supported(p, pixels, &p.pw_nc, &p.pw_nj))
-    return "bconv2d: the pointwise kernel runs 1x1 ungrouped convolutions with 64, 128, 256 or 512 input channels (after padding to 64) and a multiple of 32 output channels (pointwise_channels must divide them)";
+    return "bconv2d: the pointwise kernel runs 1x1 ungrouped convolutions with 64, 128, 256 or 512 input channels (after padding to 64) "
+           "and a multiple of 32 output channels (pointwise_channels must divide them)";
   if (p.engine_pref >= 2 && !mfma_supported(p))
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   p.use_stream = false;
@@ -1379,7 +814,8 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
         if (rows_pref == 0 && ceil_div(px, 32) * 32 * 100 > px * 115) continue;
         cands.push_back(StreamCandidate{r, 1, 0.0});
       }
-    if (il_pref == 1 && cands.empty()) cands.push_back(StreamCandidate{rows_pref, 1, 0.0});   // (nothing to interleave: one segment per image)
+    // (nothing to interleave: one segment per image)
+    if (il_pref == 1 && cands.empty()) cands.push_back(StreamCandidate{rows_pref, 1, 0.0});
     int best = -1;
     std::string first_err;
     for (size_t i = 0; i < cands.size(); ++i) {
@@ -1405,11 +841,13 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
     p.stream_interleave_pref = il_pref;
     double best_us = best >= 0 ? cands[best].us : 1e30;
     bool take_wstream = false;
-    const bool debug = p.dbg_level >= 1;      // (LCE_PLAN_DEBUG, read at plan creation: the estimates of every candidate, on stderr: tools/planner_regret.py)
+    // (LCE_PLAN_DEBUG, read at plan creation: the estimates of every candidate, on stderr: tools/planner_regret.py)
+    const bool debug = p.dbg_level >= 1;
     if (debug)
       for (const StreamCandidate& c : cands) fprintf(stderr, "[lce plan] stream rows=%d il=%d: %.2f us\n", c.rows, c.interleave, c.us);
     if (auto_rule) {
-      if (wstream_supported(p) && !p.dbg_no_wstream && plan_wstream(p, batch_chunk).empty()) {   // (LCE_PLAN_NO_WSTREAM, read at plan creation: an A/B aid)
+      // (LCE_PLAN_NO_WSTREAM, read at plan creation: an A/B aid)
+      if (wstream_supported(p) && !p.dbg_no_wstream && plan_wstream(p, batch_chunk).empty()) {
         const double us = estimate_wstream_us(p, batch_chunk);
         if (debug) fprintf(stderr, "[lce plan] wstream images=%d blocks=%d: %.2f us\n", p.ws_ipb, p.ws_nb, us);
         if (us < best_us) { best_us = us; take_wstream = true; }
@@ -1491,7 +929,8 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
         if (!direct) direct = true;  // reported below by direct_geometry
       }
     }
-    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0 || p.kch != (d.groups > 1 ? group_chunks(d) : ceil_div(d.channels_in, 64));
+    const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0 ||
+                        p.kch != (d.groups > 1 ? group_chunks(d) : ceil_div(d.channels_in, 64));
     p.wq_layout = 0;
     p.mfma = want;
     p.cpad = ceil_div(d.channels_in, 64) * 64;

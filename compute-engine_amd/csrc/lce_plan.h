@@ -49,7 +49,8 @@ struct HostPlan {
 
   // OneTimeSetup results (bconv2d.cc:324-392)
   bool have_weights = false;
-  bool want_sign = false;                  // the call asks for the second (LceQuantize) output too: lce_hip_bconv2d_run_dual (the planner's auto rule looks at it)
+  // the call asks for the second (LceQuantize) output too: lce_hip_bconv2d_run_dual (the planner's auto rule looks at it)
+  bool want_sign = false;
   std::vector<float> mul, bias;            // channels_out entries
   int32_t clamp_min = 0, clamp_max = 0;
   float bit_thr = 0.0f;                    // LceQuantize of the output as a compare: bit = value < bit_thr
@@ -89,10 +90,12 @@ struct HostPlan {
   // int8 plans: floor(y + 0.5) equals the reference's round-half-away on EVERY value this plan can produce (no reachable exact negative
   // tie; pack_for_mfma checks every channel x every accumulator value inside the clamps): the streaming kernels' one-instruction rounding
   bool int8_floor_ok = false;
-  int int8_bias_adjusted = 0;       // channels that the proof of the one-instruction forms gave neighbouring parameters (lce_plan.cpp, prepare_int8_epilogue)
+  // channels that the proof of the one-instruction forms gave neighbouring parameters (lce_plan.cpp, prepare_int8_epilogue)
+  int int8_bias_adjusted = 0;
   bool int8_exact_pref = false;            // testing aid (int8_rounding=exact): never take the floor instances
   std::vector<uint8_t> wq;                 // FP4 weights [KS][Npad][32 bytes]
-  int wq_layout = 0;                       // 0: K-major [K-step][K-half][Npad][16 B]; 1: tile-major [Npad/32][K-step][K-half][32][16 B] (wstream)
+  // 0: K-major [K-step][K-half][Npad][16 B]; 1: tile-major [Npad/32][K-step][K-half][32][16 B] (wstream)
+  int wq_layout = 0;
   std::vector<float> mul_q, bias_q, thr_q; // Npad entries
 
   // weight-stationary streaming kernel (lce_kernels_stream.h); with use_mfma
@@ -103,11 +106,15 @@ struct HostPlan {
   int stream_phases_pref = 0;              // tuning aid: pixel phases per block (0 = auto, else 1, 2 or 4: 4 / phases channel slices)
   int st_rs = 0, st_spi = 0, st_srs = 0, st_pbs = 0, st_pph_log = 0, st_ny = 1, st_qg = 0, st_ipr = 0;
   int st_pitch = 0;                          // bytes per ring row slot
-  int st_nstrip = 1, st_rseg = 0, st_wso = 0;   // column strips of wide images: strips per image, row segments per image, output columns per strip
-  int stream_strip_pref = -1;                // testing aid: -1 auto, 0 never, else the strip width (a multiple of 32 that divides the output width)
-  int stream_interleave_pref = -1;           // 1: a block's segments are gx apart (interleaved runs: a compact, moving write window), 0: consecutive, -1: the cost estimate decides
+  // column strips of wide images: strips per image, row segments per image, output columns per strip
+  int st_nstrip = 1, st_rseg = 0, st_wso = 0;
+  // testing aid: -1 auto, 0 never, else the strip width (a multiple of 32 that divides the output width)
+  int stream_strip_pref = -1;
+  // 1: a block's segments are gx apart (interleaved runs: a compact, moving write window), 0: consecutive, -1: the cost estimate decides
+  int stream_interleave_pref = -1;
   int st_gstr = 1;                           // the planned segment stride of a block's run (1: consecutive segments)
-  int st_flat = 0;                           // 1: 32-pixel blocks are cut from the concatenated pixels of a block's segments (whole small images)
+  // 1: 32-pixel blocks are cut from the concatenated pixels of a block's segments (whole small images)
+  int st_flat = 0;
   int st_nq = 0;                             // pixel blocks of a full block's stream (rows of the context table)
   int st_spb = 0, st_gx = 0, st_rows = 0, st_ring_bytes = 0, st_batch = 0;   // ... for launches of st_batch images
   std::vector<uint32_t> st_tabs;           // [sched | lim | ctx]: the kernel's tables (lce_kernel_args.h, StreamArgs)
@@ -115,9 +122,11 @@ struct HostPlan {
 
   // weight-streaming kernel (lce_kernels_wstream.h); with use_mfma.  Its tables live in st_tabs as the streaming kernel's do.
   bool use_wstream = false;
-  int ws_ipb = 0, ws_parts = 0, ws_nq = 0, ws_npxg = 0, ws_nb = 0, ws_ny = 1;   // images per group, blocks per group, pixel blocks / pixels per group, most pixel blocks per block, grid.y
+  // images per group, blocks per group, pixel blocks / pixels per group, most pixel blocks per block, grid.y
+  int ws_ipb = 0, ws_parts = 0, ws_nq = 0, ws_npxg = 0, ws_nb = 0, ws_ny = 1;
   int ws_hp = 0, ws_wp = 0, ws_pitch = 0, ws_img_pitch = 0, ws_qg = 0, ws_lds_images = 0;   // LDS image geometry
-  int ws_blocks_pref = 0, ws_images_pref = 0;   // tuning aids: most pixel blocks per block (0 = 4), images per group (0 = the cost model's choice)
+  // tuning aids: most pixel blocks per block (0 = 4), images per group (0 = the cost model's choice)
+  int ws_blocks_pref = 0, ws_images_pref = 0;
   int ws_occupancy = 1;                      // blocks that fit a CU's LDS side by side (the kernel is built for two)
   uint32_t ws_tab_part = 0, ws_tab_ctx = 0;  // byte offsets inside st_tabs
   int64_t ws_cost = 0;                       // the planner's cycle estimate of a launch (plan_wstream)
@@ -126,7 +135,8 @@ struct HostPlan {
   int dbg_level = 0;                         // LCE_PLAN_DEBUG=1|2: every candidate's price (2: and its terms) on stderr
   bool dbg_no_wstream = false;               // LCE_PLAN_NO_WSTREAM: the weight-streaming kernel is not among auto's candidates
   bool dbg_int8_exact = false;               // LCE_PLAN_INT8_EXACT: as the option int8_rounding=exact, for whole stacks
-  bool dbg_int8_full = false;                // LCE_PLAN_INT8_FULL: the int8 proof enumerates every accumulator value (tests compare it with the bisection)
+  // LCE_PLAN_INT8_FULL: the int8 proof enumerates every accumulator value (tests compare it with the bisection)
+  bool dbg_int8_full = false;
 
   // tiled-kernel operands (built by pack_for_tile)
   std::vector<uint32_t> packed;            // [NT][KH*KW][Cwg][TN]
@@ -201,7 +211,8 @@ inline int stream_chunks(const lce_hip_bconv2d_desc& d) {
   return c <= 2 ? c : c <= 4 ? 4 : c <= 8 ? 8 : 0;
 }
 inline bool stream_ksplit(const HostPlan& p) { return stream_chunks(p.d) > 4; }
-inline int stream_lds_extra(const HostPlan& p) { return stream_ksplit(p) ? kStreamLdsExtraKsplit : kStreamLdsExtra + 1024; }   // (+ the strips' segment table)
+// (+ the strips' segment table)
+inline int stream_lds_extra(const HostPlan& p) { return stream_ksplit(p) ? kStreamLdsExtraKsplit : kStreamLdsExtra + 1024; }
 inline int stream_lds_bytes(const HostPlan& p) { return p.st_ring_bytes + stream_lds_extra(p); }
 
 }  // namespace lce

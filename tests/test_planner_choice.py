@@ -1,6 +1,6 @@
 """The planner's choice against the measured sweep of every candidate kernel (round-4 review, item 5).
 
-profiles/r05/engine_sweep_box*.jsonl, engine_sweep_i8_box*.jsonl (tools/engine_sweep.py, one GPU box each; the int8 rows from the later three): for the QuickNet / Bi-RealNet 3x3 layers -- stride 1
+profiles/r06/engine_sweep_r06*.jsonl (tools/engine_sweep.py, one GPU box each, re-measured in round 6 with the round's kernels): for the QuickNet / Bi-RealNet 3x3 layers -- stride 1
 and the stride-2 layers of config 5 -- at batch 1, 16, 64 and 256 and the three output types, the time of every kernel the planner can
 choose between (block GEMM direct / workspace, the weight-stationary streaming kernel with whole-image and interleaved r-row segments,
 the weight-streaming kernel).  The kernel `auto` picks on the HOST (no GPU needed: selection is host-side) must be within 5 % of the
@@ -18,29 +18,45 @@ LAYERS = {(56, 64, 64, 1), (28, 128, 128, 1), (14, 256, 256, 1), (7, 512, 512, 1
           (56, 64, 128, 2), (28, 128, 256, 2), (14, 256, 512, 2), (7, 512, 512, 2)}
 
 
-def _table():
-    """{(hw, cin, cout, stride, batch, dst): {kernel name: mean us over the boxes that measured it}}"""
-    acc = {}
-    # the int8 rows: the three boxes measured AFTER the one-instruction int8 forms (DESIGN 4.15) changed the int8 epilogues' cost
-    paths = [(p, None) for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "engine_sweep_box*.jsonl")))]
-    paths += [(p, "i8") for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "engine_sweep_i8_box*.jsonl")))]
-    for path, only in paths:
+def _load():
+    """({(hw, cin, cout, stride, batch, dst): {kernel name: mean us over the boxes that measured it}}, [meta of every table])
+
+    Round 6: the tables are profiles/r06/engine_sweep_r06*.jsonl -- every candidate measured again with this round's kernels by
+    `python tools/planner_regret.py --remeasure OUT.jsonl` (one GPU call per box), not inherited from round 5.  Each table's first line
+    records the hash of the kernel sources it was measured with (tools/kernel_hash.py)."""
+    acc, metas = {}, []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "engine_sweep_r06*.jsonl"))):
         for line in open(path):
             r = json.loads(line)
-            if (r["dst"] == "i8") != (only == "i8"):
+            if "meta" in r:
+                metas.append((os.path.basename(path), r["meta"]))
                 continue
             key = (r["hw"], r["cin"], r["cout"], r["stride"], r["batch"], r["dst"])
             for cand, name in r["kernel"].items():
                 acc.setdefault(key, {}).setdefault(name, []).append(r["us"][cand])
-    return {k: {n: sum(v) / len(v) for n, v in d.items()} for k, d in acc.items()}
+    return {k: {n: sum(v) / len(v) for n, v in d.items()} for k, d in acc.items()}, metas
 
 
-TABLE = _table()
+TABLE, METAS = _load()
 ROWS = sorted(k for k in TABLE if k[:4] in LAYERS)
 
 
 def test_the_sweep_covers_the_grid():
     assert len(ROWS) == len(LAYERS) * 4 * 3, len(ROWS)
+
+
+def test_the_sweep_was_measured_with_the_kernels_of_this_tree():
+    """The estimate's constants (csrc/lce_plan_cost.cpp) and these tables age together with the kernels: a table measured with other
+    kernel sources than the tree's proves nothing about the planner's choice NOW.  Re-measure:
+        gpurun -- 'python tools/planner_regret.py --remeasure gpurun_out/r06/engine_sweep_r06_boxN.jsonl > gpurun_out/r06/planner_regret_boxN.txt'
+    and copy both files to profiles/r06/."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_hash
+    assert METAS, "no sweep table under profiles/r06/"
+    now = kernel_hash.kernel_sources_hash()
+    stale = [name for name, m in METAS if m.get("kernel_sources_sha256") != now]
+    assert not stale, "measured with other kernel sources than this tree's (%s...): %s" % (now[:12], stale)
 
 
 @pytest.mark.parametrize("key", ROWS, ids=lambda k: "%dx%dx%d_s%d_b%d_%s" % k)

@@ -10,7 +10,7 @@ for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   [ "$flags" == "$spec" ] && flags=""
   ( hipcc -DLCE_EXPERIMENT -DLCE_UNITY $flags -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -I. -Wno-unused-result -shared \
-      -o $ROOT/build_exp/lib_$name.so lce_hip_api.hip lce_plan.cpp lce_prepare.cpp 2>&1 | grep -E " error|Error" ) &
+      -o $ROOT/build_exp/lib_$name.so lce_hip_api.hip lce_plan.cpp lce_plan_stream.cpp lce_plan_cost.cpp lce_prepare.cpp 2>&1 | grep -E " error|Error" ) &
 done
 wait
 ls -la $ROOT/build_exp/

@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 import bench  # noqa: E402
+import kernel_hash  # noqa: E402
 import synthetic_layers as SL  # noqa: E402
 
 amd = importlib.import_module("compute-engine_amd")
@@ -29,6 +30,8 @@ LAYERS = [  # (H = W, Cin, Cout, stride)
     (40, 192, 192, 1), (20, 320, 320, 1), (112, 64, 64, 1),
     (14, 192, 192, 1), (7, 384, 384, 1), (28, 160, 160, 1),                           # between the streaming family's instances, small images
 ]
+# never used to fit the cost estimate's constants (lce_plan_cost.cpp): the out-of-sample rows of tools/planner_regret.py (round 6)
+HOLDOUT = [(28, 192, 192, 1), (10, 256, 256, 1), (56, 128, 128, 1), (20, 128, 256, 2)]
 BATCHES = [1, 16, 64, 256]
 DSTS = ["f32", "i8", "bp"]
 CANDIDATES = {
@@ -92,12 +95,21 @@ def main():
     only = [a for a in sys.argv[2:] if not a.startswith("--")]
     dsts = [a.split("=")[1] for a in sys.argv[2:] if a.startswith("--dst=")] or DSTS
     dev = torch.device("cuda:0")
-    layers = LAYERS
+    layers = LAYERS + HOLDOUT
     if only:
         def key(l):
             return "%dx%dx%d" % l[:3] + ("s%d" % l[3] if l[3] > 1 else "")
-        layers = [l for l in LAYERS if key(l) in only]
+        layers = [l for l in LAYERS + HOLDOUT if key(l) in only]
+    fresh = not os.path.exists(out_path) or os.path.getsize(out_path) == 0
     with open(out_path, "a") as f:
+        if fresh:
+            # what the table was measured with: tests/test_planner_choice.py refuses a table whose kernels are not the tree's
+            props = torch.cuda.get_device_properties(dev)
+            meta = {"meta": {"kernel_sources_sha256": kernel_hash.kernel_sources_hash(), "device": props.name,
+                             "compute_units": props.multi_processor_count, "library": amd.LIB_PATH if hasattr(amd, "LIB_PATH") else None,
+                             "holdout": [list(l) for l in HOLDOUT], "quick": quick}}
+            f.write(json.dumps(meta) + "\n")
+            f.flush()
         for (hw, cin, cout, st) in layers:
             for b in ([256] if quick else BATCHES):
                 for dname in dsts:

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """The planner's auto choice against a measured sweep table (tools/engine_sweep.py), on the HOST (no GPU needed): per row the
 kernel `auto` picks now, its recorded time, the best recorded time, the regret.  LCE_PLAN_DEBUG=1 prints the estimates too.
-usage: planner_regret.py TABLE.jsonl [-v]"""
+usage: planner_regret.py TABLE.jsonl [-v]
+       planner_regret.py --remeasure OUT.jsonl [engine_sweep.py arguments]   (needs the GPU: measures every candidate again with
+                          tools/engine_sweep.py -- the constants of csrc/lce_plan_cost.cpp age with ROCm, firmware and kernels -- and
+                          then prints the regret table of the fresh measurement: the round's evidence script runs this, nothing is
+                          inherited from an earlier round)"""
 import importlib
 import json
 import os
@@ -24,9 +28,27 @@ def choice(row):
 
 
 def main():
-    rows = [json.loads(l) for l in open(sys.argv[1])]
+    if len(sys.argv) > 2 and sys.argv[1] == "--remeasure":
+        import subprocess
+        out = sys.argv[2]
+        if os.path.exists(out):
+            os.remove(out)
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "engine_sweep.py"), out] + sys.argv[3:], check=True,
+                       stdout=subprocess.DEVNULL)
+        sys.argv = [sys.argv[0], out]
+    lines = [json.loads(l) for l in open(sys.argv[1])]
+    meta = next((l["meta"] for l in lines if "meta" in l), {})
+    rows = [l for l in lines if "meta" not in l]
+    if meta:
+        import kernel_hash
+        same = meta.get("kernel_sources_sha256") == kernel_hash.kernel_sources_hash()
+        print("# table %s: %s, %s CUs, kernel sources %s (%s the tree's)" % (os.path.basename(sys.argv[1]), meta.get("device"), meta.get("compute_units"),
+                                                                            str(meta.get("kernel_sources_sha256"))[:12], "=" if same else "NOT"))
+    holdout = {tuple(l) for l in meta.get("holdout", [])}
     verbose = "-v" in sys.argv
     worst, bad, unknown = 0.0, 0, 0
+    h_rows = h_bad = 0
+    h_worst = 0.0
     for r in rows:
         name = choice(r)
         by_kernel = {}
@@ -44,9 +66,15 @@ def main():
         worst = max(worst, regret)
         if regret > 0.05:
             bad += 1
+        if (r["hw"], r["cin"], r["cout"], r["stride"]) in holdout:
+            h_rows += 1
+            h_bad += regret > 0.05
+            h_worst = max(h_worst, regret)
         if verbose or regret > 0.05:
             print("%s  %-48s %7.1f us  best %7.1f  regret %5.1f %%" % (tag, name, us, best, 100 * regret))
     print("rows %d: regret > 5 %% on %d, choice not in the table on %d, worst regret %.1f %%" % (len(rows), bad, unknown, 100 * worst))
+    if h_rows:
+        print("of which held-out layers (never used to fit the constants) %d rows: regret > 5 %% on %d, worst %.1f %%" % (h_rows, h_bad, 100 * h_worst))
 
 
 if __name__ == "__main__":
