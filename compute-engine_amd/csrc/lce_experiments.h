@@ -19,7 +19,8 @@
 // ---- "results are wrong" timing ablations ----
 #if defined(LCE_ABL_NODMA) || defined(LCE_ABL_NOBAR) || defined(LCE_ABL_NOFRAG) || defined(LCE_ABL_NOSTORE) || \
     defined(LCE_ABL_NOSLEEP) || defined(LCE_ST_NOFRAG) || defined(LCE_ST_NOEPI) || defined(LCE_ST_NOEPI_A) ||  \
-    defined(LCE_ST_NOEPI_B) || defined(LCE_ST_NOEPI_C) || defined(LCE_ST_NOPROD) || defined(LCE_PW_NOSTORE)
+    defined(LCE_ST_NOEPI_B) || defined(LCE_ST_NOEPI_C) || defined(LCE_ST_NOPROD) || defined(LCE_PW_NOSTORE) ||   \
+    defined(LCE_ST_NOBANK)
 #define LCE_HAS_EXPERIMENT_SWITCH 1
 #endif
 // ---- time-stamp builds for the phase / timeline tools (results right, kernels slower, extra debug exports), and the

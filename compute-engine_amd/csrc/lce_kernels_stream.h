@@ -268,7 +268,11 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
       //  channel tile j is the slice's tile j ^ khalf)
       const int ksl = i >> 1, ksg = KSPLIT ? (ksl / KCHW) * KCH + khalf * KCHW + ksl % KCHW : ksl;
       const int jt = KSPLIT ? (i & 1) ^ khalf : (i & 1);
+#ifdef LCE_ST_NOBANK    // timing ablation (results are wrong): the bank's loads fall off the end of their buffer -- zeros, no transfer
+      W[i >> 1][i & 1] = buf_load(rw, slice_ok && ksg < 0 ? (uint32_t)jt : kOobOffset, (u32x4*)nullptr);
+#else
       W[i >> 1][i & 1] = buf_load(rw, slice_ok ? (uint32_t)((ksg * 2 + half) * G.Npad + n0 + jt * 32 + l31) * 16u : kOobOffset, (u32x4*)nullptr);
+#endif
     }
     sched_fence();
   };

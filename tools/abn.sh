@@ -7,7 +7,8 @@ for r in $(seq 1 $ROUNDS); do
   for lib in "$@"; do
     if [ "$lib" = "base" ]; then v=$(python tools/run_one.py $ARGS 2>/dev/null | tail -1 | awk '{print $(NF-1)}');
     else v=$(LCE_HIP_LIBRARY=$PWD/$lib python tools/run_one.py $ARGS 2>/dev/null | tail -1 | awk '{print $(NF-1)}'); fi
-    line="$line $(basename $lib .so)=$(printf %.4f $v)"
+    n=$(basename $lib .so); [ "$n" = "liblce_hip" ] && n=$(basename $(dirname $lib))   # (tools/build_abl.sh: build_exp/NAME/liblce_hip.so)
+    line="$line $n=$(printf %.4f $v)"
   done
   echo "[$ARGS]$line"
 done
