@@ -5,7 +5,7 @@
 * int8 plans whose one-instruction epilogue forms run on ADJUSTED per-channel parameters (csrc/lce_plan.cpp,
   prepare_int8_epilogue), on inputs that produce EVERY accumulator value the plan can reach, for the streaming kernel, the
   weight-streaming kernel, the pointwise kernel and the pointwise plan's fallback to the block GEMM;
-* >= 300 randomized (layer, batch, output type, run / run_dual) draws where the planner's cost estimate decides, each on
+* >= 400 randomized (layer, batch, output type, run / run_dual) draws where the planner's cost estimate decides, each on
   `engine=auto` AND on every engine that accepts the shape: bytes equal to the oracle's and equal across engines."""
 import os
 
@@ -165,7 +165,7 @@ def _layer(draw):
     """(spec, dst, dual): the families whose kernel the planner's cost estimate picks -- 3x3 layers of 64..512 input channels
     (weight-stationary / weight-streaming / block GEMM), 1x1 layers (pointwise / block GEMM) -- plus odd shapes that fall to the
     general paths.  Work is bounded so that the oracle (all host cores) and the six engines take well under a second a draw."""
-    family = draw(st.sampled_from(["3x3", "3x3", "3x3", "1x1", "odd"]))
+    family = draw(st.sampled_from(["3x3", "3x3", "3x3", "1x1", "odd", "grid"]))
     batch = draw(st.sampled_from(BATCHES))
     dst = draw(st.sampled_from([O.DST_F32, O.DST_I8, O.DST_BITPACKED]))
     dual = dst != O.DST_BITPACKED and draw(st.booleans())
@@ -184,6 +184,28 @@ def _layer(draw):
         stride = draw(st.sampled_from([1, 1, 2]))
         pad = (O.PADDING_VALID, 0)
         k = 1
+    elif family == "grid":
+        # the reference's op-test grid widened (tflite/tests/bconv2d_test.cc:790-856): groups, dilation, rectangular filters and
+        # strides, both SAME-zero semantics, ragged channel counts -- with the second output and every engine on top
+        groups = draw(st.sampled_from([1, 1, 2, 4]))
+        cin = draw(st.sampled_from([32, 64, 96, 128, 160])) * groups if groups > 1 else draw(st.sampled_from([3, 20, 64, 70, 96, 192, 300]))
+        cout = draw(st.sampled_from([1, 7, 16, 33, 40, 64, 100, 136])) * groups
+        kh, kw = draw(st.integers(1, 4)), draw(st.integers(1, 4))
+        sh, sw = draw(st.integers(1, 3)), draw(st.integers(1, 3))
+        dh, dw = draw(st.integers(1, 2)), draw(st.integers(1, 3))
+        h = (kh - 1) * dh + 1 + draw(st.integers(0, 12))
+        w_ = (kw - 1) * dw + 1 + draw(st.integers(0, 12))
+        padname = draw(st.sampled_from(["VALID", "SAME0", "ONE"]))
+        sem = draw(st.sampled_from([O.SEM_REFERENCE, O.SEM_OPTIMIZED]))
+        pad = {"VALID": (O.PADDING_VALID, 0), "SAME0": (O.PADDING_SAME, 0), "ONE": (O.PADDING_SAME, 1)}[padname]
+        if padname == "SAME0":   # bconv2d.cc:188-200: what Prepare accepts
+            if sem == O.SEM_REFERENCE and (cin // groups) % 2:
+                pad = (O.PADDING_SAME, 1)
+            elif sem == O.SEM_OPTIMIZED:
+                act, dst, dual = O.ACT_NONE, O.DST_F32, dual and dst == O.DST_F32
+        batch = min(batch, 16)
+        spec = O.ConvSpec(batch, h, w_, cin, kh, kw, cout, groups, sh, sw, dh, dw, pad[0], pad[1], act, sem)
+        return spec, dst, dual, draw(st.integers(0, 10_000))
     else:
         cin = draw(st.sampled_from([20, 96, 200]))
         cout = draw(st.sampled_from([7, 33, 80]))
@@ -220,7 +242,7 @@ _seen_kernels = set()
 _draws = [0]
 
 
-@settings(max_examples=300, deadline=None, derandomize=True, database=None,
+@settings(max_examples=420, deadline=None, derandomize=True, database=None,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much])
 @given(_layer())
 def test_where_the_planner_decides(case):
@@ -230,6 +252,8 @@ def test_where_the_planner_decides(case):
     _draws[0] += 1
     x, w, mul, bias = synth.conv_inputs(spec, seed, negative_mul_fraction=0.2)
     scale, zp = synth.int8_quant_params(seed)
+    if seed % 7 == 0:           # the ends of int8's range now and then (the second output's threshold sits at them too)
+        zp = (-128, 127, -127, 126)[(seed // 7) % 4]
     thr = None
     if dst == O.DST_BITPACKED:
         thr = O.thresholds_converter(spec, mul, bias)
@@ -260,6 +284,6 @@ def test_where_the_planner_decides_reached_every_family():
     """(runs after the draws above, same process) the 300 draws exercised every kernel family."""
     if _draws[0] == 0:
         pytest.skip("the randomized test did not run in this process")
-    assert _draws[0] >= 250, _draws[0]
+    assert _draws[0] >= 350, _draws[0]
     want = {"bconv2d_stream", "bconv2d_wstream", "bconv2d_mfma_direct", "bconv2d_mfma", "bconv2d_pointwise", "bconv2d_tiled"}
     assert want <= _seen_kernels, sorted(want - _seen_kernels)

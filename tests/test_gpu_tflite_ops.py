@@ -269,3 +269,19 @@ def test_residency_can_be_switched_off():
         assert (up, down) == (4, 4), (up, down)
     finally:
         T.set_residency(True)
+
+
+@pytest.mark.parametrize("zp,scale", [(120, 0.1), (-125, 1.0 / 7.0), (3, 0.3), (-128, 0.5), (127, 0.02), (10, 2.5)])
+def test_dequantize_op_saturates_and_rounds_as_the_reference(zp, scale):
+    """Round 6 (review item 4a) at the op boundary too: Register_DEQUANTIZE's int8 branch -- offset = TfLiteRound(1 / scale), a 0 bit ->
+    min(127, zp + offset), a 1 bit -> max(-128, zp - offset) (tflite/kernels/quantization.cc:131-138) -- on zero points and scales that
+    reach both saturating branches and reciprocals that round, against the oracle's unpack."""
+    scale = float(np.float32(scale))
+    for shape in ((1, 4, 4, 33), (2, 5, 3, 64), (1, 3, 3, 100)):
+        words = synth.random_words(synth.rng(zp + shape[-1]), shape[:-1] + ((shape[-1] + 31) // 32,))
+        d = T.SingleOpModel("LceDequantize")
+        di = d.add_tensor(T.INT32, words.shape, words)
+        do = d.add_tensor(T.INT8, shape, scale=scale, zero_point=zp)
+        d.set_node([di], [do])
+        assert d.prepare() == 0 and d.invoke() == 0, d.log
+        assert np.array_equal(d.get(do), O.unpack(words, shape[-1], np.int8, scale=scale, zero_point=zp)), shape
