@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LCE_HIP_ABI_VERSION 2
+#define LCE_HIP_ABI_VERSION 3   /* 3 (round 6): + lce_hip_bconv2d_plan_int8_epilogue; additive */
 
 typedef enum lce_hip_status {
   LCE_HIP_OK = 0,

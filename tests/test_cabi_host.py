@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = amd.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.lce_hip_abi_version() == 2
+    assert lib.lce_hip_abi_version() == 3
     # the in-tree library is the product build: no timing ablation / A-B switch compiled in (csrc/lce_experiments.h)
     assert lib.lce_hip_build_flavor() == b"product"
 
