@@ -287,3 +287,33 @@ def test_where_the_planner_decides_reached_every_family():
     assert _draws[0] >= 350, _draws[0]
     want = {"bconv2d_stream", "bconv2d_wstream", "bconv2d_mfma_direct", "bconv2d_mfma", "bconv2d_pointwise", "bconv2d_tiled"}
     assert want <= _seen_kernels, sorted(want - _seen_kernels)
+
+
+# ------------------------------------------------------------------------------------ pointers a host may hand over
+
+@pytest.mark.parametrize("engine,shape", [("stream", (3, 14, 14, 256, 3, 64)), ("wstream", (3, 14, 14, 256, 3, 64)),
+                                          ("stream", (2, 20, 20, 64, 3, 32)), ("direct", (3, 14, 14, 256, 3, 64)),
+                                          ("pointwise", (2, 12, 12, 128, 1, 64))])
+def test_tensors_need_no_16_byte_alignment(engine, shape):
+    """An interpreter's arena gives 16- or 64-byte aligned tensors, but nothing in the C ABI asks for it (include/lce_hip.h: "device
+    pointers"; the reference's kernels take any pointer).  The streaming kernels store rows as 16-byte pieces through buffer
+    resources and load input words 16 bytes at a time: both work on bases that are only element-aligned (int8 output at +1 / +4,
+    float and bitpacked output at +4, input words at +4), bytes equal to the oracle's and nothing written outside the tensor."""
+    b, h, w_, cin, k, cout = shape
+    pad = (O.PADDING_SAME, 1) if k > 1 else (O.PADDING_VALID, 0)
+    spec = O.ConvSpec(b, h, w_, cin, k, k, cout, padding=pad[0], pad_values=pad[1])
+    x, w, mul, bias = synth.conv_inputs(spec, 5)
+    thr = O.thresholds_converter(spec, mul, bias)
+    xin = torch.zeros((x.size + 8,), dtype=torch.int32, device=DEV)
+    xin[1:1 + x.size] = torch.from_numpy(x.ravel()).to(DEV)                    # the input tensor starts 4 bytes into its buffer
+    for dst, odst, off in ((amd.I8, O.DST_I8, 1), (amd.I8, O.DST_I8, 4), (amd.F32, O.DST_F32, 4), (amd.BITPACKED, O.DST_BITPACKED, 4)):
+        plan = amd.Bconv2dPlan(_params(spec, dst, out_scale=0.25, out_zero_point=2))
+        plan.set_weights(w, mul, bias, thr if dst == amd.BITPACKED else None)
+        plan.set_option("engine", engine)
+        want = O.bconv2d(spec, odst, x, w, mul, bias, thresholds=thr, out_scale=0.25, out_zero_point=2)
+        buf = torch.full((want.nbytes + 64,), 0x5A, dtype=torch.uint8, device=DEV)
+        plan.run_ptr(xin.data_ptr() + 4, buf.data_ptr() + off, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[off:off + want.nbytes], want.view(np.uint8).ravel()), (plan.kernel_name(), dst, off)
+        assert (got[:off] == 0x5A).all() and (got[off + want.nbytes:] == 0x5A).all(), (plan.kernel_name(), dst, off, "wrote outside")
