@@ -31,7 +31,7 @@
 // ---- A/B variants of a code path (results right) ----
 #if defined(LCE_NO_PK_F32) || defined(LCE_MFMA_SCALED) || defined(LCE_STREAM_LDS_WAIT) || defined(LCE_STREAM_PK_F32) || \
     defined(LCE_NO_HALO_SKIP) || defined(LCE_NO_HALO_FULLWORDS) || defined(LCE_STREAM_NO_SKEW) || defined(LCE_WORDS_THROUGH) || \
-    defined(LCE_STREAM_AUTO_STRIDED) || defined(LCE_STREAM_AUTO_LOWK)
+    defined(LCE_STREAM_AUTO_STRIDED) || defined(LCE_STREAM_AUTO_LOWK) || defined(LCE_COST_TUNABLE)
 #define LCE_HAS_EXPERIMENT_SWITCH 1
 #endif
 // ---- tunables with a built-in default (the sources #define them when the command line does not) ----

@@ -788,11 +788,13 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
     return "bconv2d: the matrix-core engine cannot run this convolution (channels per group not a multiple of 64, or too deep)";
   p.use_stream = false;
   p.use_wstream = false;
+  p.est_us = -1.0;
   if (p.engine_pref == 6) {
     // weight-streaming kernel (activations stationary in LDS): the planner's FP4 weight image with 64-channel granularity
     const int batch_chunk = (int)std::max<int64_t>(1, pixels / std::max<int64_t>(1, (int64_t)p.out_h * p.out_w));
     const std::string err = plan_wstream(p, batch_chunk);
     if (!err.empty()) return err;
+    p.est_us = estimate_wstream_us(p, batch_chunk);
     use_wstream_plan(p);
     return "";
   }
@@ -857,10 +859,12 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       if (gemm_us < best_us) { best = -1; take_wstream = false; best_us = -1.0; gemm_by_estimate = true; }   // the block GEMM, below
     }
     if (take_wstream) {
+      p.est_us = best_us;
       use_wstream_plan(p);
       return "";
     }
     if (best >= 0 && best_us >= 0.0) {
+      p.est_us = best_us;
       p.stream_rows_pref = cands[best].rows;
       p.stream_interleave_pref = cands[best].interleave;
       const std::string err = plan_stream(p, batch_chunk);
@@ -896,6 +900,7 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
                              mfma_supported(p) && (gemm_by_estimate || pixels * d.channels_out >= (1 << 16)))) {
     p.use_mfma = true;
     p.use_tiled = false;
+    p.est_us = estimate_block_gemm_us(p, pixels);
     MfmaCfg want = choose_mfma_cfg(p, pixels);
     bool direct = false;
     if (p.engine_pref >= 2 && p.tile_pref.tm != 0) {

@@ -131,6 +131,10 @@ struct HostPlan {
   uint32_t ws_tab_part = 0, ws_tab_ctx = 0;  // byte offsets inside st_tabs
   int64_t ws_cost = 0;                       // the planner's cycle estimate of a launch (plan_wstream)
 
+  // the cost estimate (us per launch) of the matrix-core kernel the last select_kernel took, as lce_plan_cost.cpp priced it (-1: the
+  // selection was not priced -- the xor-popcount engine, the pointwise kernel).  tools/fit_cost.py and tools/planner_regret.py read it.
+  double est_us = -1.0;
+
   // A/B and debugging aids, read from the environment once, when the plan is created (validate_and_infer) -- never on the selection path
   int dbg_level = 0;                         // LCE_PLAN_DEBUG=1|2: every candidate's price (2: and its terms) on stderr
   bool dbg_no_wstream = false;               // LCE_PLAN_NO_WSTREAM: the weight-streaming kernel is not among auto's candidates

@@ -23,7 +23,9 @@ namespace lce {
 namespace cost {
 
 // Sources.  "sweep": profiles/r05/engine_sweep_box{1,2,3}.jsonl + engine_sweep_i8_box{4,5,6}.jsonl (six boxes, tools/engine_sweep.py),
-// re-measured in round 6: profiles/r06/engine_sweep_r06.jsonl.  Probes: tools/probes/*.hip, their outputs under profiles/.
+// re-measured in round 6: profiles/r06/engine_sweep_r06_box{1,2,3}.jsonl.  "re-fit r6": the value tools/fit_cost.py found on those three
+// tables (coordinate descent on the estimates' log error + the regret of the pick; the held-out layers of engine_sweep.py never enter
+// it).  Probes: tools/probes/*.hip, their outputs under profiles/.
 #define LCE_COST_TABLE(X)                                                                                                          \
   /* ---- the chip ---- */                                                                                                         \
   X(kCyclesPerUs, 2100.0, "cycles/us", "the clock short launches sustain: profiles/r03/stream_phases.txt (s_memtime vs events)")   \
@@ -33,83 +35,100 @@ namespace cost {
     "tools/probes/mfma_gap.hip, profiles/r03/probe_mfma_gap.txt")                                                                  \
   X(kVmemBytesPerClk, 51.0, "B/clk", "a CU's vector memory path, loads into registers: "                                           \
     "profiles/r05/stream_phases_paced.txt (288 KiB in 5.8 k cycles)")                                                              \
-  X(kL2BytesPerUs, 27.0e6, "B/us", "the eight L2s when every CU pulls the same filter bank (75 MB in 2.8 us): "                    \
-    "profiles/r05/wstream_vs_stream.txt")                                                                                          \
+  X(kL2BytesPerUs, 37.0e6, "B/us", "the eight L2s when every CU pulls the same filter bank (75 MB in 2.8 us): "                    \
+    "profiles/r05/wstream_vs_stream.txt; re-fit r6")                                                                               \
   /* ---- weight-stationary streaming kernel (lce_kernels_stream.h) ---- */                                                        \
   X(kStPrologueUs, 0.9, "us", "a block's prologue without its bank: first rows, ring columns, quota + barrier: "                   \
     "profiles/r03/stream_phases.txt")                                                                                              \
-  X(kStPrologueKsplitUs, 0.1, "us", "K-split: inbox setup on top: profiles/r04/stream_phases.txt")                                \
-  X(kStStepF32, 1.30, "x", "block step / its bare MFMA time, float output (woven epilogue + granted clock): sweep, L0 / 14x14x256 rows") \
-  X(kStStepI8, 1.25, "x", "the same, int8 output: sweep (i8 boxes 4-6)")                                                          \
-  X(kStStepBp, 1.05, "x", "the same, bitpacked output: sweep")                                                                    \
-  X(kStStepKsplitF32, 1.15, "x", "K-split instances (a wave transforms 32 channels, not 64), float: sweep, 7x7x512 / 14x14x512 rows") \
-  X(kStStepKsplitI8, 1.12, "x", "K-split, int8: sweep")                                                                           \
-  X(kStStepKsplitBp, 1.05, "x", "K-split, bitpacked: sweep")                                                                      \
+  X(kStPrologueKsplitUs, 0.1, "us", "K-split: inbox setup on top: profiles/r04/stream_phases.txt")                                 \
+  X(kStStepF32, 1.30, "x", "block step / its bare MFMA time, float output (woven epilogue + granted clock): sweep, L0 "            \
+    "/ 14x14x256 rows")                                                                                                            \
+  X(kStStepI8, 1.25, "x", "the same, int8 output: sweep (i8 boxes 4-6)")                                                           \
+  X(kStStepBp, 1.05, "x", "the same, bitpacked output: sweep")                                                                     \
+  X(kStStepKsplitF32, 1.15, "x", "K-split instances (a wave transforms 32 channels, not 64), float: sweep, 7x7x512 / "             \
+    "14x14x512 rows")                                                                                                              \
+  X(kStStepKsplitI8, 1.12, "x", "K-split, int8: sweep")                                                                            \
+  X(kStStepKsplitBp, 1.05, "x", "K-split, bitpacked: sweep")                                                                       \
   X(kStSustained, 0.2, "x", "extra on launches long enough to reach the sustained (power-limited) state, float / "                 \
     "int8: profiles/r05/bench_box_spread.txt, sweep L0 rows")                                                                      \
-  X(kStSustainedBp, 0.1, "x", "the same, bitpacked output")                                                                       \
-  X(kStSustainedSteps, 100.0, "steps", "block steps per block at which that state is reached: sweep, 56x56 rows at batch 64 vs 256") \
-  X(kStEpiFloorF32, 1.05, "us", "floor of a block step: the epilogue's own issue time, float: profiles/r05/stream_phases_lowk.txt") \
-  X(kStEpiFloorI8, 1.0, "us", "the same, int8 (after the one-instruction forms): profiles/r05/int8_floor_rounding.txt")           \
-  X(kStEpiFloorBp, 0.8, "us", "the same, bitpacked: profiles/r05/stream_phases_lowk.txt")                                         \
-  X(kStStepKsplitUs, 0.08, "us", "K-split: the pair's exchange + barrier per block step: profiles/r04/stream_phases.txt")         \
-  X(kStQuotaUs, 0.12, "us", "one out-of-line quota of 256 ring items: profiles/r03/stream_ablations.txt")                         \
-  X(kStPartialUs, 0.2, "us", "out-of-line stores of a segment's ragged last pixel block: sweep, 14x14 / 7x7 rows with 4-row segments") \
-  X(kStPartialKsplitUs, 0.12, "us", "the same, K-split instances")                                                                \
-  X(kStBlockTailUs, 0.5, "us", "drain of a block's last stores: profiles/r03/stream_phases.txt")                                  \
-  X(kStoreBytesPerUs, 5.5e6, "B/us", "the chip's write rate, int8 / bitpacked rows: profiles/r04/store_pattern_vs_l0.txt")        \
+  X(kStSustainedBp, 0.1, "x", "the same, bitpacked output")                                                                        \
+  X(kStSustainedSteps, 100.0, "steps", "block steps per block at which that state is reached: sweep, 56x56 rows at "               \
+    "batch 64 vs 256")                                                                                                             \
+  X(kStEpiFloorF32, 1.05, "us", "floor of a block step: the epilogue's own issue time, float: "                                    \
+    "profiles/r05/stream_phases_lowk.txt")                                                                                         \
+  X(kStEpiFloorI8, 1.0, "us", "the same, int8 (after the one-instruction forms): profiles/r05/int8_floor_rounding.txt")            \
+  X(kStEpiFloorBp, 0.8, "us", "the same, bitpacked: profiles/r05/stream_phases_lowk.txt")                                          \
+  X(kStStepKsplitUs, 0.08, "us", "K-split: the pair's exchange + barrier per block step: profiles/r04/stream_phases.txt")          \
+  X(kStQuotaUs, 0.12, "us", "one out-of-line quota of 256 ring items: profiles/r03/stream_ablations.txt")                          \
+  X(kStPartialUs, 0.2, "us", "out-of-line stores of a segment's ragged last pixel block: sweep, 14x14 / 7x7 rows with "            \
+    "4-row segments")                                                                                                              \
+  X(kStPartialKsplitUs, 0.12, "us", "the same, K-split instances")                                                                 \
+  X(kStBlockTailUs, 0.5, "us", "drain of a block's last stores: profiles/r03/stream_phases.txt")                                   \
+  X(kStoreBytesPerUs, 5.5e6, "B/us", "the chip's write rate, int8 / bitpacked rows: profiles/r04/store_pattern_vs_l0.txt")         \
   X(kStoreF32BytesPerUs, 5.0e6, "B/us", "float rows on launches of >= 205 MB (the power budget is shared with the "                \
     "matrix cores): profiles/r05/store_window.txt")                                                                                \
-  X(kStoreF32SmallBonus, 0.65e6, "B/us", "... rising to 5.65 TB/s on <= 51 MB: sweep, 14x14x256 / 28x28x128 float rows")          \
-  X(kStoreF32LargeMb, 205.0, "MB", "where the ramp starts")                                                                       \
-  X(kStoreF32RampMb, 154.0, "MB", "its width (205 - 51)")                                                                         \
-  X(kStoreWindowBonus, 0.42e6, "B/us", "a compact, moving write window (interleaved runs): profiles/r05/interleaved_runs.txt")    \
-  X(kStoreWindowFull, 64.0e6, "B", "window size at which the bonus is gone")                                                      \
-  X(kStoreWindowRamp, 48.0e6, "B", "... and the width of its ramp")                                                               \
+  X(kStoreF32SmallBonus, 0.65e6, "B/us", "... rising to 5.65 TB/s on <= 51 MB: sweep, 14x14x256 / 28x28x128 float rows")           \
+  X(kStoreF32LargeMb, 205.0, "MB", "where the ramp starts")                                                                        \
+  X(kStoreF32RampMb, 154.0, "MB", "its width (205 - 51)")                                                                          \
+  X(kStoreWindowBonus, 0.42e6, "B/us", "a compact, moving write window (interleaved runs): profiles/r05/interleaved_runs.txt")     \
+  X(kStoreWindowFull, 64.0e6, "B", "window size at which the bonus is gone")                                                       \
+  X(kStoreWindowRamp, 48.0e6, "B", "... and the width of its ramp")                                                                \
   X(kStPaddedMul, 1.05, "x", "an instance wider than the layer (129..192 channels on the 256-channel bank): "                      \
     "profiles/r05/engine_sweep_padded_channels.jsonl")                                                                             \
-  X(kStPaddedUs, 2.0, "us", "... and its general-path expansion")                                                                 \
-  X(kStPaddedKsplitMul, 1.2, "x", "257..448 channels on the 512-channel instance: the same file")                                 \
-  X(kStPaddedKsplitUs, 4.0, "us", "... and its expansion")                                                                        \
+  X(kStPaddedUs, 2.0, "us", "... and its general-path expansion")                                                                  \
+  X(kStPaddedKsplitMul, 1.2, "x", "257..448 channels on the 512-channel instance: the same file")                                  \
+  X(kStPaddedKsplitUs, 4.0, "us", "... and its expansion")                                                                         \
+  X(kStPaddedBpMul, 1.13, "x", "... bitpacked output on a padded instance, on top (new in round 6); re-fit r6")                    \
   /* ---- weight-streaming kernel (lce_kernels_wstream.h) ---- */                                                                  \
-  X(kWsPrologueCycles, 3400.0, "cycles", "a block's prologue: table loads + one global round trip: "                               \
-    "profiles/r05/wstream_vs_stream.txt (phases)")                                                                                 \
-  X(kWsItemCycles, 600.0, "cycles", "... per 16-byte item per lane of the image expansion")                                       \
-  X(kWsCrowdPrologueUs, 0.6, "us", "extra when two blocks share every CU")                                                        \
-  X(kWsMfmaExtraCycles, 0.8, "cycles", "per MFMA of the K loop over kMfmaCycles, a block alone on its CU")                        \
-  X(kWsMfmaCrowdCycles, 2.0, "cycles", "... more when two blocks share the CU")                                                   \
-  X(kWsKstepLatencyUs, 0.055, "us", "floor per K-step with one or two pixel blocks per block: the weight loads' "                  \
-    "latency over kWsPrefetch steps")                                                                                              \
-  X(kWsTailF32PerBlockUs, 0.5, "us", "float: transform + stores of one pixel block at the block's end")                           \
-  X(kWsTailF32StoreShare, 0.8, "x", "float: share of the launch's output written behind the K loops (K-major)")                   \
-  X(kWsTailI8Us, 0.5, "us", "int8: transform of one pixel block")                                                                 \
-  X(kWsTailI8CrowdUs, 0.45, "us", "... more beside a co-resident block")                                                          \
-  X(kWsTailBpUs, 0.15, "us", "bitpacked: ballots + one store per pixel block")                                                    \
-  X(kWsOneBlockPerCu, 1.15, "x", "K loops when only ONE block fits a CU's LDS (no co-resident block hides prologue / epilogue)")  \
+  X(kWsPrologueCycles, 3100.0, "cycles", "a block's prologue: table loads + one global round trip: "                               \
+    "profiles/r05/wstream_vs_stream.txt (phases); re-fit r6")                                                                      \
+  X(kWsItemCycles, 660.0, "cycles", "... per 16-byte item per lane of the image expansion; re-fit r6")                             \
+  X(kWsCrowdPrologueUs, 0.6, "us", "extra when two blocks share every CU")                                                         \
+  X(kWsMfmaExtraCycles, 0.8, "cycles", "per MFMA of the K loop over kMfmaCycles, a block alone on its CU")                         \
+  X(kWsMfmaCrowdCycles, 2.0, "cycles", "... more when two blocks share the CU")                                                    \
+  X(kWsKstepLatencyUs, 0.05, "us", "floor per K-step with one or two pixel blocks per block: the weight loads' "                   \
+    "latency over kWsPrefetch steps; re-fit r6")                                                                                   \
+  X(kWsTailF32PerBlockUs, 0.5, "us", "float: transform + stores of one pixel block at the block's end")                            \
+  X(kWsTailF32StoreShare, 0.6, "x", "float: share of the launch's output written behind the K loops (K-major); re-fit r6")         \
+  X(kWsTailI8Us, 0.5, "us", "int8: transform of one pixel block")                                                                  \
+  X(kWsTailI8CrowdUs, 0.45, "us", "... more beside a co-resident block")                                                           \
+  X(kWsTailBpUs, 0.15, "us", "bitpacked: ballots + one store per pixel block")                                                     \
+  X(kWsOneBlockPerCu, 1.15, "x", "K loops when only ONE block fits a CU's LDS (no co-resident block hides prologue / epilogue)")   \
   /* ---- block GEMM (lce_kernels_mfma.h) ---- */                                                                                  \
-  X(kGemmAloneFixedUs, 3.4, "us", "a block alone on its CU: halo expansion + epilogue: profiles/r03/phases_block_gemm.txt")       \
-  X(kGemmAloneSetupUs, 0.4, "us", "... ring fill")                                                                                \
-  X(kGemmAloneKstepUs, 0.138, "us", "... per K-step of a 128 x 128 tile (LDS port's rate): the same file")                        \
-  X(kGemmAloneBpMul, 0.93, "x", "... bitpacked output")                                                                           \
-  X(kGemmRoundFixedUs, 1.6, "us", "a round of blocks at throughput: per-block fixed part")                                        \
-  X(kGemmRoundSetupUs, 1.6, "us", "... per unit of tile area (128 x 128)")                                                        \
-  X(kGemmRoundKstepUs, 0.14, "us", "... per K-step and unit of area")                                                             \
-  X(kGemmI8Mul, 0.94, "x", "rounds with int8 output: sweep")                                                                      \
-  X(kGemmBpMul, 0.78, "x", "rounds with bitpacked output: sweep")                                                                 \
-  X(kGemmSharedCuMul, 1.33, "x", "two blocks per CU slow each other down (one issue port per SIMD): profiles/r02/phases_l0.txt")  \
-  X(kGemmPartialRoundMul, 0.33, "x", "between one and two blocks per CU: linear in the surplus")                                  \
-  X(kGemmRoundsOffset, 0.35, "rounds", "fill + drain of a multi-round launch")                                                    \
-  X(kGemmStoreFixedUs, 2.4, "us", "time to the first store")                                                                      \
+  X(kGemmAloneFixedUs, 3.4, "us", "a block alone on its CU: halo expansion + epilogue: profiles/r03/phases_block_gemm.txt")        \
+  X(kGemmAloneSetupUs, 0.4, "us", "... ring fill")                                                                                 \
+  X(kGemmAloneKstepUs, 0.138, "us", "... per K-step of a 128 x 128 tile (LDS port's rate): the same file")                         \
+  X(kGemmAloneBpMul, 0.93, "x", "... bitpacked output")                                                                            \
+  X(kGemmRoundFixedUs, 1.6, "us", "a round of blocks at throughput: per-block fixed part")                                         \
+  X(kGemmRoundSetupUs, 1.6, "us", "... per unit of tile area (128 x 128)")                                                         \
+  X(kGemmRoundKstepUs, 0.14, "us", "... per K-step and unit of area")                                                              \
+  X(kGemmI8Mul, 0.94, "x", "rounds with int8 output: sweep")                                                                       \
+  X(kGemmBpMul, 0.78, "x", "rounds with bitpacked output: sweep")                                                                  \
+  X(kGemmSharedCuMul, 1.33, "x", "two blocks per CU slow each other down (one issue port per SIMD): profiles/r02/phases_l0.txt")   \
+  X(kGemmPartialRoundMul, 0.33, "x", "between one and two blocks per CU: linear in the surplus")                                   \
+  X(kGemmRoundsOffset, 0.35, "rounds", "fill + drain of a multi-round launch")                                                     \
+  X(kGemmStoreFixedUs, 2.4, "us", "time to the first store")                                                                       \
   X(kGemmStoreBytesPerUs, 5.75e6, "B/us", "block tiles written at the chip's rate: profiles/r02/probe_store_overlap.txt")
 
+#ifdef LCE_COST_TUNABLE
+// The re-fit build (tests/hostsim only, never the product: csrc/lce_experiments.h): the constants are variables that
+// tools/fit_cost.py moves through set_cost_constant() while it compares the estimates with a measured sweep.
+#define LCE_COST_DECLARE(name, value, unit, source) double name = value;
+#else
 #define LCE_COST_DECLARE(name, value, unit, source) constexpr double name = value;
+#endif
 LCE_COST_TABLE(LCE_COST_DECLARE)
 #undef LCE_COST_DECLARE
 
 struct Constant { const char* name; double value; const char* unit; const char* source; };
 #define LCE_COST_ROW(name, value, unit, source) {#name, value, unit, source},
-constexpr Constant kTable[] = {LCE_COST_TABLE(LCE_COST_ROW)};
+constexpr Constant kTable[] = {LCE_COST_TABLE(LCE_COST_ROW)};      // (the values as compiled: what dump_cost_table prints)
 #undef LCE_COST_ROW
+#ifdef LCE_COST_TUNABLE
+#define LCE_COST_PTR(name, value, unit, source) &name,
+double* const kLive[] = {LCE_COST_TABLE(LCE_COST_PTR)};
+#undef LCE_COST_PTR
+#endif
 
 inline double epilogue_floor_us(int dst) { return dst == LCE_HIP_F32 ? kStEpiFloorF32 : dst == LCE_HIP_I8 ? kStEpiFloorI8 : kStEpiFloorBp; }
 // what a block step of MFMAs costs over its bare matrix time, by output type (the woven epilogue, and the clock the power manager
@@ -123,6 +142,17 @@ inline double step_factor(int dst, int64_t usteps, bool ksplit) {
 inline double ramp(double x) { return std::min(1.0, std::max(0.0, x)); }
 
 }  // namespace cost
+
+#ifdef LCE_COST_TUNABLE
+int cost_constant_count() { return (int)(sizeof cost::kTable / sizeof cost::kTable[0]); }
+const char* cost_constant_name(int i) { return i >= 0 && i < cost_constant_count() ? cost::kTable[i].name : nullptr; }
+double get_cost_constant(int i) { return i >= 0 && i < cost_constant_count() ? *cost::kLive[i] : 0.0; }
+bool set_cost_constant(int i, double v) {
+  if (i < 0 || i >= cost_constant_count()) return false;
+  *cost::kLive[i] = v;
+  return true;
+}
+#endif
 
 void dump_cost_table(FILE* f) {
   for (const cost::Constant& c : cost::kTable) fprintf(f, "[lce plan cost] %-22s %12g %-9s %s\n", c.name, c.value, c.unit, c.source);
@@ -173,7 +203,10 @@ double estimate_stream_us(const HostPlan& p, int batch_chunk) {
   // takes the general path (word-by-word loads, partial planes) and the K loop multiplies the padding
   const bool padded = p.d.channels_in != 64 * kch && p.d.channels_in > 32 * kch;
   const double us = std::max(compute_us, store_us);
-  return padded ? (ksplit ? kStPaddedKsplitMul * us + kStPaddedKsplitUs : kStPaddedMul * us + kStPaddedUs) : us;
+  if (!padded) return us;
+  // (bitpacked output: nothing but the K loop and the expansion is left of a block step, so the general expansion path shows in full)
+  const double wide = ksplit ? kStPaddedKsplitMul * us + kStPaddedKsplitUs : kStPaddedMul * us + kStPaddedUs;
+  return dst == LCE_HIP_BITPACKED ? kStPaddedBpMul * wide : wide;
 }
 
 // The weight-streaming kernel as plan_wstream has just planned it (ws_* fields).

@@ -31,6 +31,12 @@ MfmaCfg choose_mfma_cfg(const HostPlan& p, int64_t pixels);
 double estimate_stream_us(const HostPlan& p, int batch_chunk);
 double estimate_wstream_us(const HostPlan& p, int batch_chunk);
 double estimate_block_gemm_us(const HostPlan& p, int64_t pixels);
-void dump_cost_table(FILE* f);          // every constant of the estimates: name, value, unit, where it was measured (LCE_PLAN_DEBUG=3)
+void dump_cost_table(FILE* f);
+#ifdef LCE_COST_TUNABLE            // the re-fit build of tests/hostsim (tools/fit_cost.py): the constants by index, live
+int cost_constant_count();
+const char* cost_constant_name(int i);
+double get_cost_constant(int i);
+bool set_cost_constant(int i, double v);
+#endif          // every constant of the estimates: name, value, unit, where it was measured (LCE_PLAN_DEBUG=3)
 
 }  // namespace lce

@@ -14,6 +14,7 @@
 #include "lce_kernels.h"
 #include "lce_kernels_mfma.h"     // expand_fp4
 #include "lce_plan.h"
+#include "lce_plan_internal.h"
 
 using namespace lce;
 
@@ -340,5 +341,31 @@ int hostsim_bmaxpool(const uint32_t* in, int b, int h, int w, int c, int fh, int
 }
 
 uint32_t hostsim_fastdiv(uint32_t n, uint32_t d) { return fastdiv(n, make_fastdiv(d)); }
+
+// ---- the planner's cost estimate, for tools/fit_cost.py (this library is built with -DLCE_COST_TUNABLE: the constants of
+//      csrc/lce_plan_cost.cpp are variables here) ----
+int hostsim_cost_count() { return cost_constant_count(); }
+const char* hostsim_cost_name(int i) { return cost_constant_name(i); }
+double hostsim_cost_get(int i) { return get_cost_constant(i); }
+int hostsim_cost_set(int i, double v) { return set_cost_constant(i, v) ? 0 : 1; }
+// The estimate (us) and kernel name of the plan that select_kernel makes of `desc` under the given preferences (engine_pref as
+// hostsim_bconv2d; stream_rows / interleave: the streaming kernel's segment options); < 0: the configuration cannot be planned.
+double hostsim_plan_estimate(const lce_hip_bconv2d_desc* desc, int engine_pref, int stream_rows, int interleave, int num_cus,
+                             char* name_out, int name_len) {
+  HostPlan h;
+  h.d = *desc;
+  if (!validate_and_infer(h).empty()) return -2.0;
+  h.engine_pref = engine_pref;
+  h.num_cus = num_cus;
+  h.stream_rows_pref = stream_rows;
+  h.stream_interleave_pref = interleave;
+  const int chunk = max_batch_per_launch(h);
+  if (!select_kernel(h, (int64_t)chunk * h.out_h * h.out_w).empty()) return -3.0;
+  if (name_out && name_len > 0) {
+    strncpy(name_out, h.kernel_name.c_str(), name_len - 1);
+    name_out[name_len - 1] = 0;
+  }
+  return h.est_us;
+}
 
 }  // extern "C"
