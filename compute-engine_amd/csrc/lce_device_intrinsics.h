@@ -79,6 +79,13 @@ LCE_DEVICE uint32_t write_lane_settled(uint32_t value, uint32_t old) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
   return old;
 }
+// ... preceded by ONE wait state: for pipelined gathers whose worst-case distance to the compare is exactly the four instructions of
+// the rule (gather_tile_bits, lce_kernels_mfma.h) -- the margin of the old `s_nop 4` (five wait states) for one cycle.
+template <int LANE>
+LCE_DEVICE uint32_t write_lane_settled_pad1(uint32_t value, uint32_t old) {
+  asm("s_nop 0\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "n"(LANE));
+  return old;
+}
 // One padded point for a group of ballot results: the "+s" operands order every compare in front
 // of it and every write_lane_settled() of these values behind it.
 template <int N>

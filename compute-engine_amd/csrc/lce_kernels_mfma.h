@@ -176,9 +176,10 @@ template <int V> struct IntC { static constexpr int value = V; };
 // A v_writelane must not read an SGPR that a VALU compare wrote less than 4 wait states ago (stale lanes on gfx950, round 2).  Until
 // round 6 the pointwise and weight-streaming kernels padded every register's compares with an `s_nop 4` -- 16 per tile, 47 of the 159
 // instructions of the pointwise kernel's second-output path counting the compiler's own.  Here the ballots of register r reach their
-// lanes TWO registers later: between the compares of r and its lane writes lie the compares of r + 1 and r + 2 and -- through the
-// chain of words[j] -- the lane writes of r - 1: at least six instructions, no padding (the idiom of lce_kernels_stream.h, `hold_until`);
-// one padded point remains, for the last register.
+// lanes TWO registers later (the idiom of lce_kernels_stream.h, `hold_until`): a register's lane writes are held behind the compares of
+// the register two further on and -- through the chain of words[j] -- behind the lane writes of the two registers before it: in source
+// order eight or more instructions from its own compares, at worst (the compiler may hoist the independent compares) four lane writes +
+// the one wait state its first lane write carries.  One fully padded point remains, for the last register.
 template <int NJ, bool BELOW>
 LCE_DEVICE void gather_tile_bits(const f32x16 (&a)[NJ], const float (&thr)[NJ], uint32_t (&words)[NJ]) {
 #pragma unroll
@@ -190,7 +191,9 @@ LCE_DEVICE void gather_tile_bits(const f32x16 (&a)[NJ], const float (&thr)[NJ], 
     constexpr int r = decltype(rc)::value, q = (r & 3) + 8 * (r >> 2);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      words[j] = write_lane_settled<q>((uint32_t)pend[j], words[j]);
+      // (the first lane write of a word carries one wait state: whatever order the compiler gives the independent compares, these
+      //  ballots' compares lie behind at least the four lane writes of registers r - 2 and r - 1 plus this one)
+      words[j] = write_lane_settled_pad1<q>((uint32_t)pend[j], words[j]);
       words[j] = write_lane_settled<q + 4>((uint32_t)(pend[j] >> 32), words[j]);
     }
   };

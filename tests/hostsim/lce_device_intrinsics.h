@@ -230,6 +230,7 @@ inline uint32_t write_lane(uint32_t value, uint32_t old) {
   return (g_ctx.tid_x & 63) == LANE ? value : old;
 }
 template <int LANE> inline uint32_t write_lane_settled(uint32_t value, uint32_t old) { return write_lane<LANE>(value, old); }
+template <int LANE> inline uint32_t write_lane_settled_pad1(uint32_t value, uint32_t old) { return write_lane<LANE>(value, old); }
 template <int N> inline void settle_ballots(unsigned long long (&)[N]) {}
 inline void hold_until(unsigned long long&, unsigned long long, unsigned long long) {}
 inline void hold_until(unsigned long long&, float, float) {}
