@@ -553,7 +553,10 @@ def main():
             # variants) go to a file beside it.
             result["extra"] = compact_extra(full_extra)
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline()
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:   # noqa: BLE001  (the oracle library missing on the box: the GPU line still prints)
+                result["cpu_baseline"] = {"error": repr(exc)[:300]}
         if full_extra is not None and args.extra_json:
             try:
                 os.makedirs(os.path.dirname(os.path.abspath(args.extra_json)), exist_ok=True)
@@ -613,6 +616,8 @@ def compact_extra(extra):
                       "entry >= 20 launches; full entries in extra_detail_file"}
     r3 = lambda v: None if v is None else round(float(v), 3)
     for name, e in extra.items():
+        if isinstance(e, str) and name.startswith("error_in_"):
+            out[name] = e[:120]          # (a section of the extras failed: say so in the line)
         if not isinstance(e, dict):
             continue
         tail = [e.get("bound"), r3(e.get("hbm_frac")), r3(e.get("mfma_frac"))]
@@ -635,155 +640,177 @@ def extra_measurements(amd, torch, spec, args, dev):
     st, wu = max(20, args.steps), 3
     sc, zp = 0.125, 3
     hbm = lambda b, s, m=0: roofline_fields([(b, m)], s)     # bound / frac / hbm_frac / mfma_frac of one launch
-    for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
-        s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp, rotate=True)
-        extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_, spec.binary_macs),
-                     "operands": rot_.describe()}
-        del _p, _x, _o, rot_
-    # the other matrix-core variant (FP4 workspace + GEMM whose tiles span images) and the xor-popcount
-    # engine (the north star's literal formulation) on the same layer
-    s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="mfma")
-    extra["l0_f32_workspace_gemm"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn + "+expand_fp4"}
-    s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="valu")
-    extra["l0_f32_valu_engine"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
-                                   "valu_pair_frac": spec.binary_macs / s_ / VALU_BMAC_PEAK}
-    # BASELINE config 3: the four QuickNet layer shapes, one at a time ...
-    for hw, c in SL.QUICKNET_STAGES:
-        sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
-                      channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
-        s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev, rotate=True)
-        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
-        del rot_
-        extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
-                                                **hbm(sp.algorithmic_bytes(SL.DST_F32), s_, sp.binary_macs), **how}
-        # ... and the 1x1 int8 + RELU layers of config 5's flavour (the HBM-bound cases)
-        sp1 = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
-                       channels_out=c, activation=SL.ACT_RELU)
-        s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp1, amd.I8, st, wu, hw + 1, dev, sc, zp, rotate=True)
-        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
-        del rot_
-        extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sp1.binary_macs / s_, "kernel": kn,
-                                                       **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_, sp1.binary_macs), **how}
-        del pl_, x_, o_
+    def section_l0_other_outputs():
+        for nm, dst, od in (("l0_int8_out", amd.I8, SL.DST_I8), ("l0_bitpacked_out", amd.BITPACKED, SL.DST_BITPACKED)):
+            s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spec, dst, st, wu, 1, dev, sc, zp, rotate=True)
+            extra[nm] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn, **hbm(spec.algorithmic_bytes(od), s_, spec.binary_macs),
+                         "operands": rot_.describe()}
+            del _p, _x, _o, rot_
 
-    # ... and the strided 1x1 shortcut convolutions of ResNet-style binary nets (round 3: on the pointwise kernel)
-    for hw, c in SL.QUICKNET_STAGES[:3]:
-        sps = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1, channels_out=2 * c, stride=2,
-                       activation=SL.ACT_RELU)
-        s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sps, amd.I8, st, wu, hw + 2, dev, sc, zp, rotate=True)
-        s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
-        del rot_
-        # (a stride-2 1x1 layer reads only a quarter of its input pixels: count those)
-        pix_out = args.batch * sps.out_h * sps.out_w
-        by = pix_out * sps.in_words * 4 + sps.channels_out * sps.in_words * 4 + sps.channels_out * 8 + pix_out * sps.channels_out
-        extra[f"pointwise_stride2_{hw}x{hw}x{c}_to_{2 * c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sps.binary_macs / s_, "kernel": kn,
-                                                                         **hbm(by, s_, sps.binary_macs), **how}
-        del pl_, x_, o_
+    def section_l0_other_engines():
+        # the other matrix-core variant (FP4 workspace + GEMM whose tiles span images) and the xor-popcount
+        # engine (the north star's literal formulation) on the same layer
+        s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="mfma")
+        extra["l0_f32_workspace_gemm"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn + "+expand_fp4"}
+        s_, kn, *_ = time_layer(amd, torch, spec, amd.F32, st, wu, 0, dev, engine="valu")
+        extra["l0_f32_valu_engine"] = {"ms": s_ * 1e3, "bmac_per_s": spec.binary_macs / s_, "kernel": kn,
+                                       "valu_pair_frac": spec.binary_macs / s_ / VALU_BMAC_PEAK}
 
-    # the north star's synthetic 224x224xC feature maps (3x3, C -> C, float output), 16 images = the pixel count of the
-    # 56x56 layers at batch 256
-    for c in (64, 128, 256):
-        spf = SL.Layer(batch=max(1, args.batch // 16), in_h=224, in_w=224, channels_in=c, filter_h=3, filter_w=3,
-                       channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
-        s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spf, amd.F32, st, wu, 224 + c, dev, rotate=True)
-        extra[f"feature_map_224x224x{c}_f32_batch{spf.batch}"] = {"ms": s_ * 1e3, "bmac_per_s": spf.binary_macs / s_, "kernel": kn,
-                                                                 **hbm(spf.algorithmic_bytes(SL.DST_F32), s_, spf.binary_macs),
-                                                                 "operands": rot_.describe()}
-        del _p, _x, _o, rot_
+    def section_single_layers():
+        # BASELINE config 3: the four QuickNet layer shapes, one at a time ...
+        for hw, c in SL.QUICKNET_STAGES:
+            sp = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=3, filter_w=3,
+                          channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
+            s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp, amd.F32, st, wu, hw, dev, rotate=True)
+            s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+            del rot_
+            extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
+                                                    **hbm(sp.algorithmic_bytes(SL.DST_F32), s_, sp.binary_macs), **how}
+            # ... and the 1x1 int8 + RELU layers of config 5's flavour (the HBM-bound cases)
+            sp1 = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
+                           channels_out=c, activation=SL.ACT_RELU)
+            s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp1, amd.I8, st, wu, hw + 1, dev, sc, zp, rotate=True)
+            s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+            del rot_
+            extra[f"pointwise_{hw}x{hw}x{c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sp1.binary_macs / s_, "kernel": kn,
+                                                           **hbm(sp1.algorithmic_bytes(SL.DST_I8), s_, sp1.binary_macs), **how}
+            del pl_, x_, o_
 
-    # configs 3, 4 (one GPU's shard) and 5 as REAL stacks: every layer has its own plan, weights and
-    # buffers, run back to back on one stream -- (a) the convolutions alone, each on its own input;
-    # (b) the device-resident chain, each output quantized into the next layer's input by the same
-    # epilogue (lce_hip_bconv2d_run_dual); (c) the same chain with a separate LceQuantize pass per layer
-    def stack(name, layers, dst):
+
+    def section_strided_pointwise():
+        # ... and the strided 1x1 shortcut convolutions of ResNet-style binary nets (round 3: on the pointwise kernel)
+        for hw, c in SL.QUICKNET_STAGES[:3]:
+            sps = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1, channels_out=2 * c, stride=2,
+                           activation=SL.ACT_RELU)
+            s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sps, amd.I8, st, wu, hw + 2, dev, sc, zp, rotate=True)
+            s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+            del rot_
+            # (a stride-2 1x1 layer reads only a quarter of its input pixels: count those)
+            pix_out = args.batch * sps.out_h * sps.out_w
+            by = pix_out * sps.in_words * 4 + sps.channels_out * sps.in_words * 4 + sps.channels_out * 8 + pix_out * sps.channels_out
+            extra[f"pointwise_stride2_{hw}x{hw}x{c}_to_{2 * c}_int8_relu"] = {"ms": s_ * 1e3, "bmac_per_s": sps.binary_macs / s_, "kernel": kn,
+                                                                             **hbm(by, s_, sps.binary_macs), **how}
+            del pl_, x_, o_
+
+
+    def section_feature_maps():
+        # the north star's synthetic 224x224xC feature maps (3x3, C -> C, float output), 16 images = the pixel count of the
+        # 56x56 layers at batch 256
+        for c in (64, 128, 256):
+            spf = SL.Layer(batch=max(1, args.batch // 16), in_h=224, in_w=224, channels_in=c, filter_h=3, filter_w=3,
+                           channels_out=c, padding=SL.PADDING_SAME, pad_values=1)
+            s_, kn, _p, _x, _o, rot_ = time_layer(amd, torch, spf, amd.F32, st, wu, 224 + c, dev, rotate=True)
+            extra[f"feature_map_224x224x{c}_f32_batch{spf.batch}"] = {"ms": s_ * 1e3, "bmac_per_s": spf.binary_macs / s_, "kernel": kn,
+                                                                     **hbm(spf.algorithmic_bytes(SL.DST_F32), s_, spf.binary_macs),
+                                                                     "operands": rot_.describe()}
+            del _p, _x, _o, rot_
+
+
+    def section_stacks():
+        # configs 3, 4 (one GPU's shard) and 5 as REAL stacks: every layer has its own plan, weights and
+        # buffers, run back to back on one stream -- (a) the convolutions alone, each on its own input;
+        # (b) the device-resident chain, each output quantized into the next layer's input by the same
+        # epilogue (lce_hip_bconv2d_run_dual); (c) the same chain with a separate LceQuantize pass per layer
+        def stack(name, layers, dst):
+            try:
+                ch = layer_chain.LayerChain(amd, torch, layers, dev, dst=dst, seed=4000)
+                ch.run_chain()
+                ch.run_convs()
+                torch.cuda.synchronize(dev)
+                spin_up(torch, dev, ch.run_convs)
+                convs = _event_time(torch, dev, ch.run_convs, st)
+                ch.run_chain(fused=True)    # (untimed: a plan's first call of each kind selects and uploads)
+                fused = _event_time(torch, dev, lambda: ch.run_chain(fused=True), st)
+                entry = {"layers": len(layers), "batch": args.batch, "convolutions_only_ms": convs * 1e3,
+                         "bmac_per_s": ch.binary_macs / convs,
+                         **roofline_fields([(L.algorithmic_bytes(SL.DST_F32 if dst == "f32" else SL.DST_I8), L.binary_macs) for L in layers], convs),
+                         "device_resident_chain_ms": fused * 1e3}
+                ch.run_chain(fused=False)
+                entry["chain_with_separate_lcequantize_ms"] = _event_time(torch, dev, lambda: ch.run_chain(fused=False), st) * 1e3
+                # launch gaps: the chain replayed from a captured HIP graph
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    ch.run_chain()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    ch.run_chain()
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                # (the first replays after instantiation are slow; profiles/r03/graph_gaps.txt: inside a replay the kernels run
+                # back to back exactly as eager launches do, between two replays the GPU idles ~9 us)
+                spin_up(torch, dev, graph.replay)
+                entry["device_resident_chain_hip_graph_ms"] = _event_time(torch, dev, graph.replay, st) * 1e3
+                entry["launches_timed"] = st
+                entry["kernels"] = sorted(set(ch.kernel_names()))
+                entry["kernels_device_resident_chain"] = sorted(set(ch.kernel_names(fused=True)))
+                extra[name] = entry
+                del ch, graph
+            except Exception as e:   # a report line must not take the bench down
+                extra[name] = {"error": repr(e)[:300]}
+
+        stack("quicknet_16_layers", SL.quicknet_layers(args.batch), "f32")
+        stack("quicknet_large_32_layers_per_gpu_shard", SL.quicknet_layers(args.batch, (6, 8, 12, 6)), "f32")
+        stack("birealnet_style_12_layers_int8_relu", SL.birealnet_layers(args.batch), "i8")
+
+
+    def section_streams():
+        # LceQuantize stream: float32 56x56x256 feature map, batch 256
+        fx = torch.randn((args.batch, 56, 56, 256), device=dev)
+        ow = amd.bitpack(fx)
+        torch.cuda.synchronize(dev)
+        spin_up(torch, dev, lambda: amd.bitpack(fx, out=ow))
+        s_ = _event_time(torch, dev, lambda: amd.bitpack(fx, out=ow), st)
+        qb = fx.numel() * 4 + ow.numel() * 4
+        extra["lcequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
+        # LceDequantize (bits -> float) and LceBMaxPool2d (2x2 stride 2) on the same feature map
+        fo = amd.unpack(ow, 256, torch.float32)
+        torch.cuda.synchronize(dev)
+        spin_up(torch, dev, lambda: amd.unpack(ow, 256, torch.float32, out=fo))
+        s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32, out=fo), st)
+        extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
+        po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
+        torch.cuda.synchronize(dev)
+        # (a 5 us kernel: timed from a captured HIP graph, or the host's launch rate is what is measured; the launches cycle through
+        # enough input / output sets to exceed the Infinity Cache -- with one set the 26 MB input is a cache read)
+        n_sets = int(max(4, -(-ROTATE_BYTES // ((ow.numel() + po.numel()) * 4))))
+        ows = [ow] + [ow.clone() for _ in range(n_sets - 1)]
+        pos = [po] + [torch.empty_like(po) for _ in range(n_sets - 1)]
+        pool_all = lambda: [amd.bmaxpool(ows[k], 2, 2, 2, 2, amd.PADDING_VALID, out=pos[k]) for k in range(n_sets)]
+        timed_from = "hip_graph_x%d" % n_sets
         try:
-            ch = layer_chain.LayerChain(amd, torch, layers, dev, dst=dst, seed=4000)
-            ch.run_chain()
-            ch.run_convs()
-            torch.cuda.synchronize(dev)
-            spin_up(torch, dev, ch.run_convs)
-            convs = _event_time(torch, dev, ch.run_convs, st)
-            ch.run_chain(fused=True)    # (untimed: a plan's first call of each kind selects and uploads)
-            fused = _event_time(torch, dev, lambda: ch.run_chain(fused=True), st)
-            entry = {"layers": len(layers), "batch": args.batch, "convolutions_only_ms": convs * 1e3,
-                     "bmac_per_s": ch.binary_macs / convs,
-                     **roofline_fields([(L.algorithmic_bytes(SL.DST_F32 if dst == "f32" else SL.DST_I8), L.binary_macs) for L in layers], convs),
-                     "device_resident_chain_ms": fused * 1e3}
-            ch.run_chain(fused=False)
-            entry["chain_with_separate_lcequantize_ms"] = _event_time(torch, dev, lambda: ch.run_chain(fused=False), st) * 1e3
-            # launch gaps: the chain replayed from a captured HIP graph
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                ch.run_chain()
+                pool_all()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                ch.run_chain()
+                pool_all()
             graph.replay()
             torch.cuda.synchronize(dev)
-            # (the first replays after instantiation are slow; profiles/r03/graph_gaps.txt: inside a replay the kernels run
-            # back to back exactly as eager launches do, between two replays the GPU idles ~9 us)
-            spin_up(torch, dev, graph.replay)
-            entry["device_resident_chain_hip_graph_ms"] = _event_time(torch, dev, graph.replay, st) * 1e3
-            entry["launches_timed"] = st
-            entry["kernels"] = sorted(set(ch.kernel_names()))
-            entry["kernels_device_resident_chain"] = sorted(set(ch.kernel_names(fused=True)))
-            extra[name] = entry
-            del ch, graph
-        except Exception as e:   # a report line must not take the bench down
-            extra[name] = {"error": repr(e)[:300]}
+            s_ = _event_time(torch, dev, graph.replay, st) / n_sets
+        except Exception:   # (a profiler attached to the process can invalidate the capture)
+            torch.cuda.synchronize(dev)
+            timed_from, s_ = "back_to_back_launches", _event_time(torch, dev, pool_all, st) / n_sets
+        pb = ow.numel() * 4 + po.numel() * 4
+        extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(pb, s_),
+                                                    "timed_from": timed_from,
+                                                    "operands": "%d input / output sets used round-robin, %.0f MB in total" % (n_sets, n_sets * pb / 1e6)}
+        del ows, pos
+        del fx, ow, fo, po
 
-    stack("quicknet_16_layers", SL.quicknet_layers(args.batch), "f32")
-    stack("quicknet_large_32_layers_per_gpu_shard", SL.quicknet_layers(args.batch, (6, 8, 12, 6)), "f32")
-    stack("birealnet_style_12_layers_int8_relu", SL.birealnet_layers(args.batch), "i8")
-
-    # LceQuantize stream: float32 56x56x256 feature map, batch 256
-    fx = torch.randn((args.batch, 56, 56, 256), device=dev)
-    ow = amd.bitpack(fx)
-    torch.cuda.synchronize(dev)
-    spin_up(torch, dev, lambda: amd.bitpack(fx, out=ow))
-    s_ = _event_time(torch, dev, lambda: amd.bitpack(fx, out=ow), st)
-    qb = fx.numel() * 4 + ow.numel() * 4
-    extra["lcequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
-    # LceDequantize (bits -> float) and LceBMaxPool2d (2x2 stride 2) on the same feature map
-    fo = amd.unpack(ow, 256, torch.float32)
-    torch.cuda.synchronize(dev)
-    spin_up(torch, dev, lambda: amd.unpack(ow, 256, torch.float32, out=fo))
-    s_ = _event_time(torch, dev, lambda: amd.unpack(ow, 256, torch.float32, out=fo), st)
-    extra["lcedequantize_f32_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(qb, s_)}
-    po = amd.bmaxpool(ow, 2, 2, 2, 2, amd.PADDING_VALID)
-    torch.cuda.synchronize(dev)
-    # (a 5 us kernel: timed from a captured HIP graph, or the host's launch rate is what is measured; the launches cycle through
-    # enough input / output sets to exceed the Infinity Cache -- with one set the 26 MB input is a cache read)
-    n_sets = int(max(4, -(-ROTATE_BYTES // ((ow.numel() + po.numel()) * 4))))
-    ows = [ow] + [ow.clone() for _ in range(n_sets - 1)]
-    pos = [po] + [torch.empty_like(po) for _ in range(n_sets - 1)]
-    pool_all = lambda: [amd.bmaxpool(ows[k], 2, 2, 2, 2, amd.PADDING_VALID, out=pos[k]) for k in range(n_sets)]
-    timed_from = "hip_graph_x%d" % n_sets
-    try:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            pool_all()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            pool_all()
-        graph.replay()
-        torch.cuda.synchronize(dev)
-        s_ = _event_time(torch, dev, graph.replay, st) / n_sets
-    except Exception:   # (a profiler attached to the process can invalidate the capture)
-        torch.cuda.synchronize(dev)
-        timed_from, s_ = "back_to_back_launches", _event_time(torch, dev, pool_all, st) / n_sets
-    pb = ow.numel() * 4 + po.numel() * 4
-    extra["lcebmaxpool_2x2s2_256x56x56x256"] = {"ms": s_ * 1e3, **hbm(pb, s_),
-                                                "timed_from": timed_from,
-                                                "operands": "%d input / output sets used round-robin, %.0f MB in total" % (n_sets, n_sets * pb / 1e6)}
-    del ows, pos
-    del fx, ow, fo, po
+    # A report line must not take the bench down: a section that fails (out of memory on a shared box, a kernel refusing a shape)
+    # leaves an `error_in_<section>` entry and the others still run; the headline above never depends on any of them.
+    for section in (section_l0_other_outputs, section_l0_other_engines, section_single_layers, section_strided_pointwise, section_feature_maps, section_stacks, section_streams):
+        try:
+            section()
+        except Exception as exc:   # noqa: BLE001
+            extra["error_in_" + section.__name__[len("section_"):]] = repr(exc)[:300]
+            torch.cuda.synchronize(dev)
     try:
         extra["tflite_ops_chain_host_tensors"] = tflite_chain_timing()
     except Exception as exc:   # the op glue is optional for the headline
