@@ -6,10 +6,11 @@ tests/test_gpu_model_runner.py have 64 / 96 / 40 / 33 channels; the draws here r
 intermediate AND as a model output, strides, both paddings, activations and int8 zero points at the ends of the range -- the
 combinations in which the round's randomized layer test found the one real bug of the round."""
 import importlib
+import os
 
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, given, seed, settings
 from hypothesis import strategies as st
 
 import flexbuf
@@ -126,7 +127,13 @@ _fused = [0]
 _models = [0]
 
 
-@settings(max_examples=80, deadline=None, derandomize=True, database=None,
+# (a longer hunt on the GPU box: LCE_FUZZ_EXAMPLES=5000 LCE_FUZZ_SEED=1 python -m pytest <this file> -- other draws than the suite's)
+_FUZZ_N = int(os.environ.get("LCE_FUZZ_EXAMPLES", "80"))
+_FUZZ_SEED = os.environ.get("LCE_FUZZ_SEED")
+
+
+@(seed(int(_FUZZ_SEED)) if _FUZZ_SEED else (lambda f: f))
+@settings(max_examples=_FUZZ_N, deadline=None, derandomize=_FUZZ_SEED is None, database=None,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much])
 @given(_chain())
 def test_random_binary_sections_equal_the_oracle_op_by_op(case):
@@ -154,4 +161,4 @@ def test_random_binary_sections_did_fuse_quantizes():
     """(same process, after the draws) the section runner fused LceBconv2d + LceQuantize pairs in many of the models."""
     if _models[0] == 0:
         pytest.skip("the randomized test did not run in this process")
-    assert _models[0] >= 60 and _fused[0] >= 30, (_models, _fused)
+    assert _models[0] >= min(60, _FUZZ_N - 20) and _fused[0] >= min(30, _FUZZ_N // 3), (_models, _fused)

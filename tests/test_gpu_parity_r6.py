@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 import torch
-from hypothesis import HealthCheck, given, settings
+from hypothesis import HealthCheck, given, seed, settings
 from hypothesis import strategies as st
 
 import oracle_lib as O
@@ -242,7 +242,13 @@ _seen_kernels = set()
 _draws = [0]
 
 
-@settings(max_examples=420, deadline=None, derandomize=True, database=None,
+# (a longer hunt on the GPU box: LCE_FUZZ_EXAMPLES=5000 LCE_FUZZ_SEED=1 python -m pytest <this file> -- other draws than the suite's)
+_FUZZ_N = int(os.environ.get("LCE_FUZZ_EXAMPLES", "420"))
+_FUZZ_SEED = os.environ.get("LCE_FUZZ_SEED")
+
+
+@(seed(int(_FUZZ_SEED)) if _FUZZ_SEED else (lambda f: f))
+@settings(max_examples=_FUZZ_N, deadline=None, derandomize=_FUZZ_SEED is None, database=None,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much])
 @given(_layer())
 def test_where_the_planner_decides(case):
@@ -284,7 +290,7 @@ def test_where_the_planner_decides_reached_every_family():
     """(runs after the draws above, same process) the 300 draws exercised every kernel family."""
     if _draws[0] == 0:
         pytest.skip("the randomized test did not run in this process")
-    assert _draws[0] >= 350, _draws[0]
+    assert _draws[0] >= min(350, _FUZZ_N - 70), _draws[0]
     want = {"bconv2d_stream", "bconv2d_wstream", "bconv2d_mfma_direct", "bconv2d_mfma", "bconv2d_pointwise", "bconv2d_tiled"}
     assert want <= _seen_kernels, sorted(want - _seen_kernels)
 
