@@ -569,6 +569,13 @@ lce_hip_status lce_hip_bconv2d_plan_set_option(lce_hip_bconv2d_plan* plan, const
     plan->device_current = false;
     return LCE_HIP_OK;
   }
+  if (!strcmp(key, "stream_blocks_per_cu")) {   // the streaming kernel's launch: blocks per CU (2: only where the instance is compiled for it and both blocks' LDS fit)
+    if (strcmp(value, "1") && strcmp(value, "2") && strcmp(value, "auto")) return fail(LCE_HIP_ERR_INVALID, "plan_set_option: stream_blocks_per_cu must be auto, 1 or 2");
+    h.stream_occ_pref = value[0] == 'a' ? 0 : value[0] - '0';
+    plan->selected_for_pixels = -1;
+    plan->device_current = false;
+    return LCE_HIP_OK;
+  }
   if (!strcmp(key, "wstream_blocks") || !strcmp(key, "wstream_images")) {   // tuning aids for the weight-streaming kernel: pixel blocks per block (1..4), images per group; 0 = auto
     const int v = atoi(value);
     const bool blocks = key[8] == 'b';

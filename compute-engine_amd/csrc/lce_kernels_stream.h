@@ -69,8 +69,16 @@ constexpr int stream_unit_lo(int units, int i, int n) { return units * i / n; }
 // address arithmetic and the block's first output pixel differ; a strip is a multiple of 32 columns, so a pixel block never wraps.
 // I8F (int8 output): the transform is ONE fma and the rounding floor(x + 0.5), one instruction each per value (lce_kernels.h, pack8_i8_clamped):
 // selected by the planner only where that equals the reference's two roundings + round-half-away on every value the plan can produce.
+// TWO BLOCKS PER CU (round 6; bitpacked output on the 64-input-channel bank): that instance needs 229 registers and no epilogue scratch, so
+// two blocks fit a CU -- two waves per SIMD, each filling the other's stalls (a lone wave's block step takes 2.7x its MFMAs' time there:
+// compares, lane writes, waits).  The planner gives such a launch twice the blocks where both blocks' LDS fit (lce_plan_stream.cpp);
+// 56x56x64 -> 64 at batch 256: 22.4 -> 17.5 us, profiles/r06/occ2_potential.txt.  (int8 / float would need their 32 KiB of transpose
+// scratch out of the way first: the same experiment, 64 -> 256 channels where the ring is small, gained 12 % for int8.)
+constexpr int stream_blocks_per_cu(int dst, int kch, bool ksplit, bool strips) {
+  return dst == kDstBitpacked && kch == 1 && !ksplit && !strips ? 2 : 1;
+}
 template <int DST, int KH, int KW, int KCH, bool FAST, bool CLAMP, bool SIGN, bool KSPLIT = false, bool STRIPS = false, bool I8F = false>
-LCE_KERNEL void __launch_bounds__(256, 1)
+LCE_KERNEL void __launch_bounds__(256, stream_blocks_per_cu(DST, KCH, KSPLIT, STRIPS))
 bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_t* __restrict__ wq,
                const float* __restrict__ mul, const float* __restrict__ bias, const float* __restrict__ thrf,
                const uint32_t* __restrict__ tabs, void* __restrict__ out, uint32_t* __restrict__ sign_words) {
@@ -102,7 +110,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
 
   uint8_t* const lds0 = lds_base();
   constexpr int SCW = KSPLIT ? 32 : 64;                    // floats per scratch row: the channels a wave transposes and stores
-  constexpr int SCRB = 32 * SCW * 4;                       // bytes of a wave's epilogue scratch
+  // bytes of a wave's epilogue scratch (bitpacked output: ballots, no transpose -- no scratch; lce_plan.h, stream_lds_extra)
+  constexpr int SCRB = DST == kDstBitpacked && !KSPLIT ? 0 : 32 * SCW * 4;
   float* const scratch = (float*)(lds0 + G.ring_bytes) + wave * (32 * SCW);   // [32 pixel rows][SCW channels]
   const uint32_t dump = (uint32_t)G.ring_bytes + 4u * (uint32_t)SCRB + (uint32_t)lane * 64u;   // where idle lanes' items go
   // KSPLIT: every wave's inbox for its partner's partial tile, two slots of 4 KiB (block parity), behind the dump area
@@ -392,7 +401,8 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
     constexpr int ks = decltype(ksc)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if (ks < 32) keep_in_agpr(W[ks][j]);
+      // (a 256-register instance takes no "a" constraint: the compiler would split its budget 128 / 128)
+      if (ks < 32 && stream_blocks_per_cu(DST, KCH, KSPLIT, STRIPS) == 1) keep_in_agpr(W[ks][j]);
       else keep_in_vgpr(W[ks][j]);
     }
   };

@@ -739,7 +739,7 @@ MfmaArgs make_mfma_args(const HostPlan& p, int batch_chunk) {
 // Which kernel runs a layer: a cost estimate per candidate (lce_plan_cost.cpp), not a list of shapes (round 5)
 // ------------------------------------------------------------------------------------
 // the streaming kernel's candidates: the planner's own segments, then interleaved runs of r-row segments
-struct StreamCandidate { int rows, interleave; double us; };
+struct StreamCandidate { int rows, interleave; double us; int occ = 1; };
 
 // plan_wstream succeeded: the plan runs the weight-streaming kernel
 static void use_wstream_plan(HostPlan& p) {
@@ -818,11 +818,20 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       }
     // (nothing to interleave: one segment per image)
     if (il_pref == 1 && cands.empty()) cands.push_back(StreamCandidate{rows_pref, 1, 0.0});
+    // every candidate again with two blocks per CU where the instance is compiled for that (a candidate whose two blocks' LDS do not
+    // fit a CU is refused by plan_stream and drops out); stream_blocks_per_cu pins the choice
+    const int occ_pref = p.stream_occ_pref;
+    if (occ_pref == 2 || (occ_pref == 0 && stream_blocks_per_cu_max(p) >= 2)) {
+      const size_t n1 = cands.size();
+      for (size_t i = 0; i < n1; ++i) { cands.push_back(cands[i]); cands.back().occ = 2; }
+      if (occ_pref == 2) cands.erase(cands.begin(), cands.begin() + (long)n1);
+    }
     int best = -1;
     std::string first_err;
     for (size_t i = 0; i < cands.size(); ++i) {
       p.stream_rows_pref = cands[i].rows;
       p.stream_interleave_pref = cands[i].interleave;
+      p.stream_occ_pref = cands[i].occ;
       const std::string err = plan_stream(p, batch_chunk);
       if (!err.empty()) { if (first_err.empty()) first_err = err; cands[i].us = -1.0; continue; }
       if (cands[i].interleave && p.st_gstr <= 1) { cands[i].us = -1.0; continue; }      // (one segment per block: the same plan as without)
@@ -833,20 +842,24 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       // stream_interleave=1 and nothing to interleave (every interleaved candidate came out as one segment per block, or could not be
       // planned): the consecutive-segment plan is the same launch -- take it instead of refusing engine=stream / dropping the family
       cands.push_back(StreamCandidate{rows_pref, 0, 0.0});
+      cands.back().occ = occ_pref == 2 ? 2 : 1;
       p.stream_rows_pref = rows_pref;
       p.stream_interleave_pref = 0;
+      p.stream_occ_pref = cands.back().occ;
       const std::string err = plan_stream(p, batch_chunk);
       if (err.empty()) { cands.back().us = estimate_stream_us(p, batch_chunk); best = (int)cands.size() - 1; }
       else { cands.back().us = -1.0; if (first_err.empty()) first_err = err; }
     }
     p.stream_rows_pref = rows_pref;
     p.stream_interleave_pref = il_pref;
+    p.stream_occ_pref = occ_pref;
     double best_us = best >= 0 ? cands[best].us : 1e30;
     bool take_wstream = false;
     // (LCE_PLAN_DEBUG, read at plan creation: the estimates of every candidate, on stderr: tools/planner_regret.py)
     const bool debug = p.dbg_level >= 1;
     if (debug)
-      for (const StreamCandidate& c : cands) fprintf(stderr, "[lce plan] stream rows=%d il=%d: %.2f us\n", c.rows, c.interleave, c.us);
+      for (const StreamCandidate& c : cands)
+        fprintf(stderr, "[lce plan] stream rows=%d il=%d blocks/CU=%d: %.2f us\n", c.rows, c.interleave, c.occ, c.us);
     if (auto_rule) {
       // (LCE_PLAN_NO_WSTREAM, read at plan creation: an A/B aid)
       if (wstream_supported(p) && !p.dbg_no_wstream && plan_wstream(p, batch_chunk).empty()) {
@@ -867,9 +880,11 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       p.est_us = best_us;
       p.stream_rows_pref = cands[best].rows;
       p.stream_interleave_pref = cands[best].interleave;
+      p.stream_occ_pref = cands[best].occ;
       const std::string err = plan_stream(p, batch_chunk);
       p.stream_rows_pref = rows_pref;
       p.stream_interleave_pref = il_pref;
+      p.stream_occ_pref = occ_pref;
       if (!err.empty()) return err;     // (cannot happen: the same plan succeeded a moment ago)
       const MfmaCfg want = *mfma_cfg_by_tile(128, 64);
       const bool repack = p.wq.empty() || p.mfma.bn() != want.bn() || p.wq_layout != 0 || p.kch != stream_chunks(d);
@@ -887,6 +902,7 @@ static std::string select_kernel_impl(HostPlan& p, int64_t pixels) {
       if ((4 >> p.st_pph_log) < std::min(4, ceil_div(d.channels_out, 64))) snprintf(ph, sizeof ph, ",phases%d", 1 << p.st_pph_log);
       if (p.st_nstrip > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",strips%d", p.st_wso);
       if (p.st_gstr > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",il");
+      if (p.st_occ > 1) snprintf(ph + strlen(ph), sizeof ph - strlen(ph), ",x%d", p.st_occ);
       snprintf(nm, sizeof nm, "bconv2d_stream<%s,3x3x%d,rows%d%s>",
                d.dst_type == LCE_HIP_F32 ? "f32" : d.dst_type == LCE_HIP_I8 ? "i8" : "bitpacked", 64 * stream_chunks(d), p.st_rs, ph);
       p.kernel_name = nm;

@@ -113,6 +113,10 @@ struct HostPlan {
   // 1: a block's segments are gx apart (interleaved runs: a compact, moving write window), 0: consecutive, -1: the cost estimate decides
   int stream_interleave_pref = -1;
   int st_gstr = 1;                           // the planned segment stride of a block's run (1: consecutive segments)
+  // blocks per CU the launch is planned for: 0 = the cost estimate decides (1, or 2 where the instance is compiled for two and both
+  // blocks' LDS fit), 1 / 2 = tuning aid (stream_blocks_per_cu)
+  int stream_occ_pref = 0;
+  int st_occ = 1;                            // ... as planned
   // 1: 32-pixel blocks are cut from the concatenated pixels of a block's segments (whole small images)
   int st_flat = 0;
   int st_nq = 0;                             // pixel blocks of a full block's stream (rows of the context table)
@@ -216,7 +220,16 @@ inline int stream_chunks(const lce_hip_bconv2d_desc& d) {
 }
 inline bool stream_ksplit(const HostPlan& p) { return stream_chunks(p.d) > 4; }
 // (+ the strips' segment table)
-inline int stream_lds_extra(const HostPlan& p) { return stream_ksplit(p) ? kStreamLdsExtraKsplit : kStreamLdsExtra + 1024; }
+// (bitpacked output: ballots, no transpose -- its instances lay out no epilogue scratch)
+inline int stream_lds_extra(const HostPlan& p) {
+  if (stream_ksplit(p)) return kStreamLdsExtraKsplit;
+  return (p.d.dst_type == LCE_HIP_BITPACKED ? 4096 : kStreamLdsExtra) + 1024;
+}
+// Blocks of the instance that can be resident on a CU at once (lce_kernels_stream.h, stream_blocks_per_cu: bitpacked output on the
+// 64-input-channel bank is compiled for two) -- where both blocks' LDS fit, the planner launches that many per CU.
+inline int stream_blocks_per_cu_max(const HostPlan& p) {
+  return p.d.dst_type == LCE_HIP_BITPACKED && stream_chunks(p.d) == 1 ? 2 : 1;
+}
 inline int stream_lds_bytes(const HostPlan& p) { return p.st_ring_bytes + stream_lds_extra(p); }
 
 }  // namespace lce

@@ -59,6 +59,8 @@ namespace cost {
   X(kStEpiFloorI8, 1.0, "us", "the same, int8 (after the one-instruction forms): profiles/r05/int8_floor_rounding.txt")            \
   X(kStEpiFloorBp, 0.8, "us", "the same, bitpacked: profiles/r05/stream_phases_lowk.txt")                                          \
   X(kStStepKsplitUs, 0.08, "us", "K-split: the pair's exchange + barrier per block step: profiles/r04/stream_phases.txt")          \
+  X(kStTwoBlocksStepMul, 1.37, "x", "a block step beside a second resident block on the CU (two waves per SIMD; the pair's steps take "  \
+    "1.37x, not 2x, one block's): profiles/r06/occ2_potential.txt, 56x56x64 / 112x112x64 bitpacked")                               \
   X(kStQuotaUs, 0.12, "us", "one out-of-line quota of 256 ring items: profiles/r03/stream_ablations.txt")                          \
   X(kStPartialUs, 0.2, "us", "out-of-line stores of a segment's ragged last pixel block: sweep, 14x14 / 7x7 rows with "            \
     "4-row segments")                                                                                                              \
@@ -164,13 +166,15 @@ double estimate_stream_us(const HostPlan& p, int batch_chunk) {
   const int kch = stream_chunks(p.d), dst = p.d.dst_type;
   const bool ksplit = stream_ksplit(p);
   const double bank_kib = ksplit ? 288.0 : 72.0 * kch;                       // 4 waves x K-steps x 2 fragments x 1 KiB
-  const int64_t blocks = (int64_t)p.st_gx * p.st_ny, cus = std::max(1, p.num_cus);
+  // (cus: the blocks resident at once -- two per CU where the launch was planned that way)
+  const int64_t blocks = (int64_t)p.st_gx * p.st_ny, cus = (int64_t)std::max(1, p.num_cus) * std::max(1, p.st_occ);
   const double bank_us = std::max(bank_kib * 1024.0 / kVmemBytesPerClk / kCyclesPerUs,
                                   (double)std::min(blocks, cus) * bank_kib * 1024.0 / kL2BytesPerUs);
   const double prologue_us = kStPrologueUs + bank_us + (ksplit ? kStPrologueKsplitUs : 0.0);
   const double mfma_us = (ksplit ? 72.0 : 18.0 * kch) * kMfmaCycles / kCyclesPerUs;    // MFMAs per block step and wave
   const int64_t usteps = ((int64_t)p.st_nq + (1 << p.st_pph_log) - 1) >> p.st_pph_log;
-  const double step_us = std::max(step_factor(dst, usteps, ksplit) * mfma_us, epilogue_floor_us(dst)) + (ksplit ? kStStepKsplitUs : 0.0);
+  const double step_us = (std::max(step_factor(dst, usteps, ksplit) * mfma_us, epilogue_floor_us(dst)) + (ksplit ? kStStepKsplitUs : 0.0)) *
+                         (p.st_occ > 1 && blocks > cus / 2 ? kStTwoBlocksStepMul : 1.0);
   const int64_t rounds = (blocks + cus - 1) / cus;
   // the ring's production: one quota of 256 items rides free per tile step, the rest is handled out of line
   const double quotas = (double)p.st_spb * p.st_srs * p.st_ipr / 256.0, tiles = std::max<double>(1.0, (double)((usteps + 3) / 4));

@@ -102,6 +102,8 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
     return "bconv2d: the streaming kernel runs ungrouped 3x3 convolutions without dilation, with at most 512 input "
            "channels (on its 64-, 128-, 256- or 512-channel instance) and whole 16-byte groups of output channels (float: a multiple of 4, "
            "int8: of 16), and not the SAME-zero correction semantics";
+  if (p.stream_occ_pref == 2 && stream_blocks_per_cu_max(p) < 2)
+    return "bconv2d: stream_blocks_per_cu=2: only the bitpacked-output instance of the 64-input-channel bank is compiled for two blocks per CU";
   const uint32_t row_bytes = stream_row_bytes(p);
   if ((int64_t)batch_chunk * p.out_h * p.out_w * row_bytes >= (1ll << 31))
     return "bconv2d: the streaming kernel binds the whole output of a launch to one buffer resource (< 2 GiB)";
@@ -122,7 +124,8 @@ std::string plan_stream(HostPlan& p, int batch_chunk) {
       widths.push_back(32);
     }
   }
-  std::string why = "bconv2d: the streaming kernel's row ring does not fit LDS for this layer";
+  std::string why = p.stream_occ_pref == 2 ? "bconv2d: stream_blocks_per_cu=2: two blocks' row rings do not fit a CU's LDS for this layer"
+                                           : "bconv2d: the streaming kernel's row ring does not fit LDS for this layer";
   for (int wso : widths)
     if (plan_stream_geometry(p, batch_chunk, wso, &why)) return "";
   return why;
@@ -164,7 +167,9 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
   skew16 = 0;
 #endif
   const int pitch = wp * ps + skew16 * 16;
-  const int cus = std::max(1, p.num_cus / ny);
+  // blocks per CU: two where the instance is compiled for it, the plan asks for it and (below) both blocks' LDS fit
+  const int occ = !strips && p.stream_occ_pref == 2 && stream_blocks_per_cu_max(p) >= 2 ? 2 : 1;
+  const int cus = std::max(1, p.num_cus * occ / ny);
   // segment size (a divisor of the output height: every segment is whole): the fewest block steps on the busiest
   // block (ties: the longer segment, whose halo is re-expanded less)
   // segments per block: as many as spread the launch over the CUs (a strip run may pass into the next strip or image: the
@@ -202,7 +207,8 @@ static bool plan_stream_geometry(HostPlan& p, int batch_chunk, int wso, std::str
     const bool flat = !strips && rs == p.out_h && spb > 1 && (rs * p.out_w) % 32 != 0 && !p.stream_noflat && ksplit;
     if (!simulate_stream(p, rs, (int)spb, pph_log, flat, ow_seg, in_w_seg, &rows, &sched)) continue;
     const int64_t ring = ((int64_t)rows * pitch + 1023) / 1024 * 1024;
-    if (ring + stream_lds_extra(p) > 160 * 1024) continue;
+    if ((ring + stream_lds_extra(p)) * occ > 160 * 1024) continue;
+    p.st_occ = occ;
     const int pbs = ceil_div(rs * ow_seg, 32);
     // (the strips epilogue's out-of-line path does not add the segment's place: a strip is a multiple of 32 columns, so no block is
     // partial)
@@ -297,7 +303,7 @@ StreamArgs make_stream_args(const HostPlan& p, int batch_chunk) {
   G.QG = p.st_qg; G.IPR = p.st_ipr; G.RS = p.st_rs; G.SPI = p.st_spi; G.SRS = p.st_srs; G.PBS = p.st_pbs;
   G.S = batch_chunk * p.st_spi;
   // a smaller launch than the one planned for (the last chunk of a batch): the same segments and tables, fewer per block
-  const int gx = std::min(G.S, std::max(1, p.num_cus / p.st_ny));
+  const int gx = std::min(G.S, std::max(1, p.num_cus * p.st_occ / p.st_ny));
   G.SPB = std::min(p.st_spb, ceil_div(G.S, std::max(1, gx)));
   // (flat pixel blocks are cut for runs of exactly st_spb segments: a shorter run's last block would spill into the next
   //  block's pixels, so a smaller launch keeps the planned run length and uses fewer blocks)

@@ -194,6 +194,8 @@ lce_hip_status lce_hip_bconv2d_plan_folded(const lce_hip_bconv2d_plan* plan, flo
  *              cheapest (csrc/lce_plan.cpp, estimate_*_us; LCE_PLAN_DEBUG=1 in the environment prints the prices);
  *   "stream_rows" = "0" (auto) | rows per segment (a divisor of the output height), "stream_interleave" = "auto" | "0" | "1"
  *              (a block owns segments b, b + grid, ... instead of consecutive ones), "stream_strip" = "-1" (auto) | "0" | a strip width,
+ *              "stream_blocks_per_cu" = "auto" | "1" | "2" (two resident blocks per CU: the bitpacked-output instance of the 64-input-channel
+ *              bank, where both blocks' LDS fit),
  *              "stream_pixel_phases", "stream_flat", "compute_units", "wstream_blocks" = "0".."4", "wstream_images": tuning / testing
  *              aids of the two streaming kernels;
  *   "int8_rounding" = "auto" | "exact": int8 outputs of the streaming / weight-streaming / pointwise kernels round with floor(y + 0.5)

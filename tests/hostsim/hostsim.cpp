@@ -110,6 +110,7 @@ int g_stream_rows = 0;        // its segment size (0 = auto)
 int g_stream_phases = 0;      // its pixel phases per block (0 = auto)
 int g_stream_strip = -1;      // its column strips (-1 auto, 0 never, else the width)
 int g_stream_interleave = 0;  // its segment -> block map (1: interleaved runs)
+int g_stream_occ = 0;         // its blocks per CU (0 = the estimate decides, 1, 2)
 int g_pw_nj = 0;              // the pointwise kernel's 32-channel tiles per block (0 = auto)
 int g_last_int8_adjusted = 0;   // ... and the number of channels whose bias its floor-rounding proof adjusted
 int g_last_int8_floor = -1;   // the last convolution's plan: 1 = its int8 rounding ran as floor(x + 0.5), 0 = round-half-away, -1 = not an int8 matrix-core plan
@@ -125,6 +126,7 @@ void hostsim_set_stream(int num_cus, int rows) { g_num_cus = num_cus; g_stream_r
 void hostsim_set_stream_phases(int phases) { g_stream_phases = phases; }
 void hostsim_set_stream_strip(int width) { g_stream_strip = width; }
 void hostsim_set_stream_interleave(int on) { g_stream_interleave = on; }
+void hostsim_set_stream_blocks_per_cu(int n) { g_stream_occ = n; }
 void hostsim_set_pointwise(int channel_tiles) { g_pw_nj = channel_tiles; }
 int hostsim_last_int8_floor() { return g_last_int8_floor; }
 int hostsim_last_int8_adjusted() { return g_last_int8_adjusted; }
@@ -146,6 +148,7 @@ int hostsim_bconv2d(const lce_hip_bconv2d_desc* desc, const int32_t* filter, con
   h.stream_phases_pref = g_stream_phases;
   h.stream_strip_pref = g_stream_strip;
   h.stream_interleave_pref = g_stream_interleave;
+  h.stream_occ_pref = g_stream_occ;
   h.pw_nj_pref = g_pw_nj;
   h.kernel_pref = kernel_pref;
   h.tile_pref = TileShape{tm, tn};

@@ -103,6 +103,11 @@ def set_stream_interleave(on: int = 0):
     lib().hostsim_set_stream_interleave(int(on))
 
 
+def set_stream_blocks_per_cu(n: int = 0):
+    """The streaming kernel's resident blocks per CU: 0 = the cost estimate decides, 1, 2 (2: the bitpacked 64-input-channel instance)."""
+    lib().hostsim_set_stream_blocks_per_cu(int(n))
+
+
 def last_int8_floor() -> int:
     """1: the last convolution's int8 rounding ran as floor(x + 0.5) (the planner proved it equal to round-half-away on that plan),
     0: as round-half-away, -1: not an int8 plan of the streaming / pointwise kernels."""

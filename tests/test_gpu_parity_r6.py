@@ -323,3 +323,53 @@ def test_tensors_need_no_16_byte_alignment(engine, shape):
         got = buf.cpu().numpy()
         assert np.array_equal(got[off:off + want.nbytes], want.view(np.uint8).ravel()), (plan.kernel_name(), dst, off)
         assert (got[:off] == 0x5A).all() and (got[off + want.nbytes:] == 0x5A).all(), (plan.kernel_name(), dst, off, "wrote outside")
+
+
+# ------------------------------------------------------------------------------------ two resident blocks per CU (bitpacked, 64-channel bank)
+
+@pytest.mark.parametrize("shape", [
+    # batch, h = w, cin, cout, stride
+    (256, 56, 64, 64, 1),      # config 5's first 3x3 layer with bitpacked output: 512 blocks, two per CU
+    (40, 56, 64, 64, 1),       # fewer segments than 2 x CUs at whole images: shorter segments
+    (9, 112, 40, 96, 1),       # general expansion path, two channel slices x two pixel phases
+    (64, 28, 64, 256, 2),      # strides, four slices
+])
+def test_two_blocks_per_cu_equal_one_block_per_cu_and_the_oracle(shape):
+    """Round 6: `stream_blocks_per_cu` (auto / 1 / 2) changes the launch -- twice the blocks, two resident per CU, on the one instance
+    compiled for it -- never the bytes.  Full-size launches (the co-resident blocks share a CU's LDS and run their barriers
+    independently); the oracle checks a slice of the batch, the rest is compared between the launches."""
+    b, hw, cin, cout, stride = shape
+    spec = O.ConvSpec(b, hw, hw, cin, 3, 3, cout, 1, stride, stride, padding=O.PADDING_SAME, pad_values=1)
+    x, w, mul, bias = synth.conv_inputs(spec, 3 * cin + cout)
+    thr = O.thresholds_converter(spec, mul, bias)
+    xd = torch.from_numpy(x).to(DEV)
+    outs, names = {}, {}
+    for occ in ("1", "2", "auto"):
+        plan = amd.Bconv2dPlan(_params(spec, amd.BITPACKED))
+        plan.set_weights(w, None, None, thr)
+        plan.set_option("engine", "stream")
+        plan.set_option("stream_blocks_per_cu", occ)
+        out = torch.full(plan.output_shape, -7, dtype=torch.int32, device=DEV)
+        plan.run(xd, out)
+        torch.cuda.synchronize()
+        outs[occ], names[occ] = out.cpu().numpy(), plan.kernel_name()
+    assert ",x2>" in names["2"] and ",x2" not in names["1"], names
+    nb = min(b, 3)
+    sub = spec.with_batch(nb)
+    want = O.bconv2d(sub, O.DST_BITPACKED, x[:nb], w, thresholds=thr)
+    assert np.array_equal(outs["1"][:nb], want), names
+    assert np.array_equal(outs["2"], outs["1"]) and np.array_equal(outs["auto"], outs["1"]), names
+
+
+def test_two_blocks_per_cu_is_refused_where_no_instance_is_compiled_for_it():
+    """(the 128-channel bank's bitpacked instance and the 64-channel bank's int8 / float instances need more than 256 registers or
+    32 KiB of transpose scratch per block)"""
+    for dst, cin in ((amd.BITPACKED, 128), (amd.I8, 64), (amd.F32, 64)):
+        s = O.ConvSpec(4, 28, 28, cin, 3, 3, 128, padding=O.PADDING_SAME, pad_values=1)
+        x, w, mul, bias = synth.conv_inputs(s, 1)
+        plan = amd.Bconv2dPlan(_params(s, dst, out_scale=0.25, out_zero_point=2))
+        plan.set_weights(w, mul, bias, O.thresholds_converter(s, mul, bias) if dst == amd.BITPACKED else None)
+        plan.set_option("engine", "stream")
+        plan.set_option("stream_blocks_per_cu", "2")
+        with pytest.raises(amd.LceHipError, match="stream_blocks_per_cu=2"):
+            plan.run(torch.from_numpy(x).to(DEV))

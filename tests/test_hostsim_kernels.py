@@ -641,11 +641,47 @@ def test_stream_kernel_interleaved_runs(shape):
             names = _run_all_dst_mfma(spec, seed=cin + 5 * cout + b, max_batch=mb, engine="stream")
             assert all(n.startswith("bconv2d_stream<") for n in names), names
             if mb == 0:     # (a chunk so small that every block owns ONE segment has nothing to interleave)
-                assert all(n.endswith(",il>") for n in names), names
+                assert all(",il>" in n or ",il," in n for n in names), names      # (",il,x2>": two blocks per CU, bitpacked 64-channel bank)
     finally:
         H.set_stream(256, 0)
         H.set_stream_strip(-1)
         H.set_stream_interleave(0)
+
+
+@pytest.mark.parametrize("shape", [
+    # batch, h, w, cin, cout, stride, pad, compute units
+    (5, 12, 10, 64, 64, (1, 1), "ONE", 2),      # 4 blocks on 2 CUs, four pixel phases, ragged pixel blocks
+    (3, 9, 16, 40, 96, (1, 1), "SAME", 3),      # general expansion path (40 channels), exact SAME-zero, two channel slices x two phases
+    (4, 13, 11, 64, 200, (2, 2), "ONE", 2),     # strides; four slices, a ragged last word
+    (1, 8, 8, 33, 32, (1, 1), "VALID", 4),      # one image over 8 blocks
+], ids=lambda s: "%dx%dx%d_%d-%d_cu%d" % (s[0], s[1], s[2], s[3], s[4], s[7]))
+def test_stream_kernel_two_blocks_per_cu(shape):
+    """Round 6: the bitpacked-output instance of the 64-input-channel bank is compiled for two resident blocks per CU (229 registers,
+    no epilogue scratch) and the planner launches 2 x CUs blocks where both blocks' LDS fit (lce_plan_stream.cpp).  Same bytes as the
+    oracle with one and with two blocks per CU and with the estimate's own choice; the other instances refuse the option."""
+    b, h, w_, cin, cout, st, pad, cus = shape
+    padding, pad_values = PADS[pad]
+    spec = O.ConvSpec(b, h, w_, cin, 3, 3, cout, 1, st[0], st[1], 1, 1, padding, pad_values, O.ACT_NONE, O.SEM_REFERENCE)
+    x, w, mul, bias = synth.conv_inputs(spec, 7 * cin + cout, negative_mul_fraction=0.2)
+    thr = O.thresholds_converter(spec, mul, bias)
+    thr[::5] = np.iinfo(np.int32).max
+    thr[1::7] = np.iinfo(np.int32).min
+    want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
+    H.set_stream(cus, 0)
+    try:
+        for occ in (2, 1, 0):
+            H.set_stream_blocks_per_cu(occ)
+            got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, engine="stream")
+            assert np.array_equal(got, want), name
+            assert name.startswith("bconv2d_stream<bitpacked,3x3x64,") and (",x2>" in name) == (occ == 2 or (occ == 0 and ",x2>" in name)), name
+            if occ == 1:
+                assert ",x2" not in name, name
+        H.set_stream_blocks_per_cu(2)
+        with pytest.raises(RuntimeError, match="stream_blocks_per_cu=2"):
+            H.bconv2d(spec, O.DST_F32, x, w, mul, bias, engine="stream")
+    finally:
+        H.set_stream(256, 0)
+        H.set_stream_blocks_per_cu(0)
 
 
 @pytest.mark.parametrize("phases,cout,cus", [(2, 256, 2), (4, 256, 4)])

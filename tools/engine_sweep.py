@@ -45,6 +45,9 @@ CANDIDATES = {
     "stream_il7": {"engine": "stream", "stream_rows": "7", "stream_interleave": "1"},
     "stream_il14": {"engine": "stream", "stream_rows": "14", "stream_interleave": "1"},
     "wstream": {"engine": "wstream"},
+    # one / two resident blocks per CU (two: the bitpacked-output instance of the 64-input-channel bank; refused elsewhere)
+    "stream_x1": {"engine": "stream", "stream_blocks_per_cu": "1"},
+    "stream_x2": {"engine": "stream", "stream_blocks_per_cu": "2"},
 }
 
 
