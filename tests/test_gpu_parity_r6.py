@@ -157,7 +157,8 @@ def test_int8_adjusted_parameters_over_every_reachable_accumulator(engine, kerne
 # ------------------------------------------------------------------------------------ where the planner decides: randomized draws
 
 BATCHES = [1, 3, 16, 64, 201, 256]
-ENGINES = ["stream", "wstream", "direct", "mfma", "pointwise", "valu"]
+# ("stream_x2": engine=stream with two resident blocks per CU -- refused by every instance but the one compiled for it)
+ENGINES = ["stream", "stream_x2", "wstream", "direct", "mfma", "pointwise", "valu"]
 
 
 @st.composite
@@ -231,7 +232,9 @@ def _run_engine(spec, dst, dual, engine, x, w, mul, bias, thr, scale, zp):
         plan.set_weights(w, None, None, thr)
     else:
         plan.set_weights(w, mul, bias)
-    plan.set_option("engine", engine)
+    plan.set_option("engine", engine.split("_")[0])
+    if engine == "stream_x2":
+        plan.set_option("stream_blocks_per_cu", "2")
     if dual:
         y, bits = plan.run_dual(x)
         return y.cpu().numpy(), bits.cpu().numpy(), plan.kernel_name()
@@ -282,7 +285,7 @@ def test_where_the_planner_decides(case):
         if dual:
             assert np.array_equal(bits, want_bits), (engine, name, spec, dst, "second output")
         ran.append(name)
-        _seen_kernels.add(name.split("<")[0])
+        _seen_kernels.add(name.split("<")[0] + (",x2" if name.endswith(",x2>") else ""))
     assert ran
 
 
@@ -291,7 +294,7 @@ def test_where_the_planner_decides_reached_every_family():
     if _draws[0] == 0:
         pytest.skip("the randomized test did not run in this process")
     assert _draws[0] >= min(350, _FUZZ_N - 70), _draws[0]
-    want = {"bconv2d_stream", "bconv2d_wstream", "bconv2d_mfma_direct", "bconv2d_mfma", "bconv2d_pointwise", "bconv2d_tiled"}
+    want = {"bconv2d_stream", "bconv2d_stream,x2", "bconv2d_wstream", "bconv2d_mfma_direct", "bconv2d_mfma", "bconv2d_pointwise", "bconv2d_tiled"}
     assert want <= _seen_kernels, sorted(want - _seen_kernels)
 
 
