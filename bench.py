@@ -666,6 +666,13 @@ def extra_measurements(amd, torch, spec, args, dev):
             del rot_
             extra[f"quicknet_{hw}x{hw}x{c}_f32"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
                                                     **hbm(sp.algorithmic_bytes(SL.DST_F32), s_, sp.binary_macs), **how}
+            if c == 64:
+                # ... the 64-channel layer with bitpacked output: the one instance that runs two resident blocks per CU
+                s_, kn, pl_, x_, o_, rot_ = time_layer(amd, torch, sp, amd.BITPACKED, st, wu, hw + 3, dev, rotate=True)
+                s_, how = small_layer_entry(torch, dev, s_, pl_, x_, o_, st, rot_)
+                del rot_
+                extra[f"conv_{hw}x{hw}x{c}_bitpacked_out"] = {"ms": s_ * 1e3, "bmac_per_s": sp.binary_macs / s_, "kernel": kn,
+                                                              **hbm(sp.algorithmic_bytes(SL.DST_BITPACKED), s_, sp.binary_macs), **how}
             # ... and the 1x1 int8 + RELU layers of config 5's flavour (the HBM-bound cases)
             sp1 = SL.Layer(batch=args.batch, in_h=hw, in_w=hw, channels_in=c, filter_h=1, filter_w=1,
                            channels_out=c, activation=SL.ACT_RELU)
