@@ -669,10 +669,10 @@ def test_stream_kernel_two_blocks_per_cu(shape):
     want = O.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr)
     H.set_stream(cus, 0)
     try:
-        for occ in (2, 1, 0):
+        for occ, mb in ((2, 0), (2, 2), (1, 0), (0, 0), (0, 3)):      # (mb: launches of at most mb images -- a smaller last chunk)
             H.set_stream_blocks_per_cu(occ)
-            got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, engine="stream")
-            assert np.array_equal(got, want), name
+            got, name = H.bconv2d(spec, O.DST_BITPACKED, x, w, thresholds=thr, engine="stream", max_batch=mb)
+            assert np.array_equal(got, want), (name, mb)
             assert name.startswith("bconv2d_stream<bitpacked,3x3x64,") and (",x2>" in name) == (occ == 2 or (occ == 0 and ",x2>" in name)), name
             if occ == 1:
                 assert ",x2" not in name, name
