@@ -55,6 +55,32 @@ void launch_lockstep(int grid_x, int block, F&& body) {
     });
 }
 
+// A block's LDS: exactly the bytes the launch asks for (rounded up to 16), zeroed, ENDING at an inaccessible page -- a kernel body that
+// touches LDS past its launch's allocation faults here (on the GPU it would read or overwrite the LDS of a co-resident block: since
+// round 6 two blocks of the streaming kernel share a CU, and the bitpacked instances lay out no epilogue scratch any more).
+class GuardedLds {
+ public:
+  explicit GuardedLds(size_t bytes) {
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE), need = (bytes + 15) / 16 * 16;
+    body_ = (need + page - 1) / page * page;
+    if (body_ == 0) body_ = page;
+    map_ = (uint8_t*)mmap(nullptr, body_ + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (map_ == MAP_FAILED) { map_ = nullptr; fprintf(stderr, "hostsim: mmap of a block's LDS failed\n"); abort(); }
+    mprotect(map_ + body_, page, PROT_NONE);
+    data_ = map_ + body_ - need;
+    page_ = page;
+  }
+  ~GuardedLds() { if (map_) munmap(map_, body_ + page_); }
+  GuardedLds(const GuardedLds&) = delete;
+  GuardedLds& operator=(const GuardedLds&) = delete;
+  uint8_t* data() const { return data_; }
+
+ private:
+  uint8_t* map_ = nullptr;
+  uint8_t* data_ = nullptr;
+  size_t body_ = 0, page_ = 0;
+};
+
 // A whole thread block in lock step: `block` fibers (64 per wave), a block barrier, shared LDS and a per-wave exchange area for
 // the MFMA emulation.  One set of fibers per launch; they run the blocks one after the other, with zeroed LDS for each.
 template <typename F>
@@ -63,7 +89,7 @@ void launch_block_lockstep(int grid_x, int grid_y, int block, size_t lds_bytes, 
 #pragma omp parallel for schedule(dynamic, 1)
   for (int bid = 0; bid < grid_x * grid_y; ++bid) {
     const int bx = bid % grid_x, by = bid / grid_x;
-    std::vector<uint8_t> lds(lds_bytes + 64, 0);
+    GuardedLds lds(lds_bytes);
     lce_dev::FiberBarrier block_bar(block);
     std::vector<lce_dev::FiberBarrier> wave_bar(block / 64, lce_dev::FiberBarrier(64));
     std::vector<uint32_t> xchg((block / 64) * 64, 0), mx((block / 64) * 64 * 8, 0);
