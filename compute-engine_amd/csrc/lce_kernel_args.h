@@ -152,7 +152,7 @@ struct StreamArgs {
   int32_t Wp;                  // pixels per ring row slot (padded width)
   int32_t pitch;               // bytes from one ring row slot to the next: Wp pixels + the bank skew (lce_plan.cpp, plan_stream)
   int32_t R;                   // ring row slots
-  int32_t ring_bytes;          // R * Wp * PS rounded up to 1 KiB; 4 x 8 KiB epilogue scratch + 4 KiB dump follow
+  int32_t ring_bytes;          // R * Wp * PS rounded up to 1 KiB; 4 x 8 KiB epilogue scratch (none: bitpacked output) + 4 KiB dump follow
   int32_t zero_border;         // 1: padding is 0 (exact SAME-zero), 0: +1 (one-padding)
   int32_t QG;                  // items per pixel = ceil(padded words / 4)
   int32_t IPR;                 // items per stream row = W * QG
