@@ -113,7 +113,9 @@ bconv2d_stream(const StreamArgs G, const uint8_t* __restrict__ xin, const uint8_
   // bytes of a wave's epilogue scratch (bitpacked output: ballots, no transpose -- no scratch; lce_plan.h, stream_lds_extra)
   constexpr int SCRB = DST == kDstBitpacked && !KSPLIT ? 0 : 32 * SCW * 4;
   float* const scratch = (float*)(lds0 + G.ring_bytes) + wave * (32 * SCW);   // [32 pixel rows][SCW channels]
-  const uint32_t dump = (uint32_t)G.ring_bytes + 4u * (uint32_t)SCRB + (uint32_t)lane * 64u;   // where idle lanes' items go
+  // where idle lanes' items go (an item of the 64-channel bank is two words: 32 bytes)
+  constexpr uint32_t kDumpStride = DST == kDstBitpacked && KCH == 1 ? 32u : 64u;
+  const uint32_t dump = (uint32_t)G.ring_bytes + 4u * (uint32_t)SCRB + (uint32_t)lane * kDumpStride;
   // KSPLIT: every wave's inbox for its partner's partial tile, two slots of 4 KiB (block parity), behind the dump area
   uint8_t* const inbox = lds0 + G.ring_bytes + 4 * SCRB + 4096 + wave * 8192;
   uint8_t* const outbox = lds0 + G.ring_bytes + 4 * SCRB + 4096 + (wave ^ 2) * 8192;

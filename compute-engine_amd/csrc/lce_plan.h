@@ -223,6 +223,8 @@ inline bool stream_ksplit(const HostPlan& p) { return stream_chunks(p.d) > 4; }
 // (bitpacked output: ballots, no transpose -- its instances lay out no epilogue scratch)
 inline int stream_lds_extra(const HostPlan& p) {
   if (stream_ksplit(p)) return kStreamLdsExtraKsplit;
+  // (the two-blocks-per-CU instance: a 2-KiB dump area -- its items are 32 bytes -- and no strips, hence no segment table)
+  if (p.d.dst_type == LCE_HIP_BITPACKED && stream_chunks(p.d) == 1) return 2048;
   return (p.d.dst_type == LCE_HIP_BITPACKED ? 4096 : kStreamLdsExtra) + 1024;
 }
 // Blocks of the instance that can be resident on a CU at once (lce_kernels_stream.h, stream_blocks_per_cu: bitpacked output on the

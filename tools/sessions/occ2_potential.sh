@@ -6,7 +6,7 @@
 # part on the product through the plan option (the int8 / float instances are compiled for one block per CU and refuse the option).
 OUT=gpurun_out/r06; mkdir -p $OUT
 {
-for spec in "56 64x64 bp 256 3 40" "112 64x64 bp 64 3 20" "56 64x256 bp 256 3 20"; do
+for spec in "56 64x64 bp 256 3 40" "112 64x64 bp 64 3 20" "56 64x256 bp 256 3 20" "56 64x128s2 bp 256 3 40"; do
   python tools/ab_opts.py $spec one:engine=stream,stream_blocks_per_cu=1 two:engine=stream,stream_blocks_per_cu=2 auto 2>/dev/null | grep "MEDIAN\|^# "
 done
 } > $OUT/two_blocks_per_cu_product.txt 2>&1
