@@ -4,7 +4,7 @@ OUT=gpurun_out/r06; mkdir -p $OUT
 {
 echo "## python -m pytest tests/test_gpu_parity_r6.py -x -q -k 'planner_decides or two_blocks'   (the suite's own 420 draws)"
 timeout 900 python -m pytest tests/test_gpu_parity_r6.py -x -q -k "planner_decides or two_blocks" 2>&1 | tail -3
-for s in 11 12; do
+for s in ${FUZZ_SEEDS:-11 12}; do
   echo "## LCE_FUZZ_EXAMPLES=2500 LCE_FUZZ_SEED=$s python -m pytest tests/test_gpu_parity_r6.py -x -q -k planner_decides"
   LCE_FUZZ_EXAMPLES=2500 LCE_FUZZ_SEED=$s timeout 1500 python -m pytest tests/test_gpu_parity_r6.py -x -q -k planner_decides 2>&1 | tail -3
 done
