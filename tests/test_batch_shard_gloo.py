@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2 and 3) test of the batch-sharded path: shards are a
+"""Multi-process (gloo, world_size 2, 3, 4 and 8) test of the batch-sharded path: shards are a
 partition of the batch, every rank's slab equals the same rows of the full-batch result,
 the all-gather reassembles it, and the timing reduction takes the max."""
 import importlib
@@ -52,7 +52,7 @@ def _worker(rank, world, port, global_batch, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,global_batch", [(2, 6), (2, 5), (3, 4)])
+@pytest.mark.parametrize("world,global_batch", [(2, 6), (2, 5), (3, 4), (4, 7), (8, 11), (8, 5)])      # (8 ranks = the driver's largest run; 5 images: three ranks with empty shards)
 def test_sharded_run_equals_full_batch(world, global_batch):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
